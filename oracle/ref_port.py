@@ -1,0 +1,365 @@
+"""TEST INFRASTRUCTURE ONLY - sequential CPU port of the reference's Co-GA / Co-ES generation loop.
+
+Drives oracle/coevo_oracle.c (one batch-1 forward per agent-step, one AEC episode per game) in exactly
+the reference's call order, quirks Q1-Q14 of SURVEY.md Appendix A included, with the reference's own
+host RNG calls (global torch generator for net init + GA mutation, global numpy generator for ES noise)
+so that results are comparable with the golden fixtures bit for bit wherever the argmax margins allow.
+
+Follows (file:line under /root/reference):
+  init_net / create order      MPE/fcnetwork.py:11-22, MPE/mpe_agent.py:11-21, genetic_algorithm.py:63-68,110-117
+  mutate                       agent.py:25-29
+  ga_train                     genetic_algorithm.py:51-345
+  es_train                     evolutionary_strategy.py:151-316, agent.py:31-70
+  diversity                    utils/game_logic_functions.py:12-37
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+Parity status: PINNED by tests/golden/{ga_cfg1,ga_hof2,es_small,es_fs,play_game,fc_forward}.json.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_build", "liboracle.so")
+ENV_SEED = 1870300
+ROLES = ("agent_0", "agent_1", "adversary_0")
+ROLE_D = {"agent_0": 10, "agent_1": 10, "adversary_0": 8}
+H1, H2, NACT = 512, 256, 5
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB_PATH) or \
+            os.path.getmtime(LIB_PATH) < os.path.getmtime(os.path.join(HERE, "coevo_oracle.c")):
+        subprocess.check_call(["make", "-C", HERE, "-s"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        ip = C.POINTER(C.c_int)
+        L.oracle_fc_param_count.restype = C.c_int
+        L.oracle_fc_forward.restype = C.c_int
+        L.oracle_fc_forward.argtypes = [fp, C.c_int, fp, fp, ip]
+        L.oracle_play_game.restype = C.c_int
+        L.oracle_play_game.argtypes = [fp, fp, fp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                       C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_double), ip, fp, ip]
+        L.oracle_mpe_reset.argtypes = [C.c_uint64] * 5 + [C.c_void_p]
+        L.oracle_mpe_observe.argtypes = [C.c_void_p, C.c_int, fp]
+        L.oracle_mpe_world_step.argtypes = [C.c_void_p, ip, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.oracle_mpe_set_pos_first.argtypes = [C.c_int]
+        L.oracle_diversity.restype = C.c_double
+        L.oracle_diversity.argtypes = [fp, fp, C.c_int, C.c_size_t, ip, ip, C.c_int, fp]
+        L.oracle_philox_normal4.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, fp]
+        L.oracle_perturb_philox.argtypes = [fp, fp, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32,
+                                            ip, ip, C.c_int]
+        L.oracle_es_update_philox.argtypes = [fp, C.c_int, fp, C.c_int, C.c_float, C.c_float, C.c_uint64,
+                                              C.c_uint32, ip, ip, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+# ------------------------------------------------------------------ parameter layout
+def param_shapes(D):
+    return [("fc1.weight", (H1, D)), ("fc1.bias", (H1,)), ("ln1.weight", (H1,)), ("ln1.bias", (H1,)),
+            ("fc2.weight", (H2, H1)), ("fc2.bias", (H2,)), ("ln2.weight", (H2,)), ("ln2.bias", (H2,)),
+            ("output.weight", (NACT, H2)), ("output.bias", (NACT,))]
+
+
+def param_count(D):
+    return sum(int(np.prod(s)) for _, s in param_shapes(D))
+
+
+def linear_segments(D):
+    """(offset, length) of the Linear W,b entries in the flat vector = get_weights_ES() content."""
+    segs, off = [], 0
+    for name, shp in param_shapes(D):
+        n = int(np.prod(shp))
+        if not name.startswith("ln"):
+            segs.append((off, n))
+        off += n
+    return segs
+
+
+def ln_segments(D):
+    segs, off = [], 0
+    for name, shp in param_shapes(D):
+        n = int(np.prod(shp))
+        if name.startswith("ln"):
+            segs.append((off, n))
+        off += n
+    return segs
+
+
+def weights_es(flat, D):
+    return np.concatenate([flat[o:o + n] for o, n in linear_segments(D)])
+
+
+def init_net(D):
+    """Same torch-generator consumption as FCNetwork.__init__ (three nn.Linear in module order)."""
+    fc1 = torch.nn.Linear(D, H1)
+    fc2 = torch.nn.Linear(H1, H2)
+    out = torch.nn.Linear(H2, NACT)
+    parts = [fc1.weight, fc1.bias, torch.ones(H1), torch.zeros(H1), fc2.weight, fc2.bias,
+             torch.ones(H2), torch.zeros(H2), out.weight, out.bias]
+    return np.concatenate([p.detach().numpy().ravel() for p in parts]).astype(np.float32)
+
+
+def mutate_torch(flat, D, sigma):
+    """Agent.mutate (agent.py:25-29): torch.normal per parameter tensor, in parameters() order."""
+    out = flat.copy()
+    off = 0
+    for _, shp in param_shapes(D):
+        n = int(np.prod(shp))
+        noise = torch.normal(0, sigma, size=shp).numpy().ravel()
+        out[off:off + n] = out[off:off + n] + noise
+        off += n
+    return out
+
+
+# ------------------------------------------------------------------ env stream + games
+class Stream:
+    """The seeded reset stream; ordinal 0 was consumed by initialize_env."""
+
+    def __init__(self, seed=ENV_SEED):
+        st = np.random.PCG64(seed).state["state"]
+        self.st = (st["state"] >> 64, st["state"] & (2 ** 64 - 1), st["inc"] >> 64, st["inc"] & (2 ** 64 - 1))
+        self.ordinal = 1
+
+    def next_ordinal(self):
+        o = self.ordinal
+        self.ordinal += 1
+        return o
+
+
+def fc_forward(flat, D, obs):
+    logits = np.zeros(NACT, dtype=np.float32)
+    st = C.c_int(0)
+    a = lib().oracle_fc_forward(_fp(flat), D, _fp(np.ascontiguousarray(obs, dtype=np.float32)), _fp(logits),
+                                C.byref(st))
+    return a, logits, st.value
+
+
+def play_game(stream, net_a0, net_a1, net_adv, limit=None, max_cycles=25, ordinal=None):
+    """-> dict(rewards=(agent_0, agent_1, adversary_0), steps, actions, min_margin, status)."""
+    o = stream.next_ordinal() if ordinal is None else ordinal
+    rewards = (C.c_double * 3)()
+    actions = np.zeros(3 * max_cycles + 3, dtype=np.int32)
+    mm = C.c_float(0)
+    st = C.c_int(0)
+    steps = lib().oracle_play_game(_fp(net_adv), _fp(net_a0), _fp(net_a1), *stream.st, o,
+                                   -1 if limit is None else int(limit), max_cycles, rewards, _ip(actions),
+                                   C.byref(mm), C.byref(st))
+    if st.value:
+        raise ValueError(f"oracle forward status {st.value} (NaN/inf or no action)")
+    return {"rewards": [rewards[0], rewards[1], rewards[2]], "steps": steps,
+            "actions": actions[:steps].tolist(), "min_margin": float(mm.value), "ordinal": o}
+
+
+def diversity(individual_es, population_es):
+    """diversity_penalty on get_weights_ES() vectors, numpy exactly as the reference writes it."""
+    distances = np.array([np.linalg.norm(w - individual_es) for w in population_es])
+    sigma = np.mean(distances)
+    return np.sum(np.maximum(0, 1 - distances / sigma))
+
+
+# ------------------------------------------------------------------ Co-GA
+def ga_train(args, max_cycles=25, log=None):
+    """genetic_algorithm_train restated. args: attribute bag (mutated in place when adaptive)."""
+    stream = Stream()
+    pop, hof_n, E = args.population, args.hof_size, args.elites_number
+    D = ROLE_D
+    # genetic_algorithm.py:63-68 - creation order and (swapped) roles matter for the torch RNG
+    hof = {"agent_1": [init_net(10) for _ in range(hof_n)]}
+    hof["agent_0"] = [init_net(10) for _ in range(hof_n)]
+    hof["adversary_0"] = [init_net(8) for _ in range(hof_n)]
+    for role_dim in (10, 10, 8):  # placeholder elites (Q7), overwritten in generation 0
+        for _ in range(hof_n):
+            init_net(role_dim)
+    popu = {r: [] for r in ROLES}
+    for _ in range(pop):  # :110-117 interleaved
+        for r in ROLES:
+            popu[r].append(init_net(D[r]))
+    stale = {r: popu[r][-1] for r in ROLES}  # Q3: objects left over from the init loop
+    sig_attr = {"agent_0": "mutation_power_agent_0", "agent_1": "mutation_power_agent_1",
+                "adversary_0": "mutation_power_adversary"}
+    rewards_hist = {r: [] for r in ROLES}
+    out = []
+    for gen in range(args.generations):
+        rec = {"games": [], "fitness": [], "diversity": [], "elite_ids": []}
+        fitness = {}
+        for ph, role in enumerate(ROLES):
+            fit = []
+            pop_es = [weights_es(w, D[role]) for w in popu[role]]
+            div = diversity(weights_es(stale[role], D[role]), pop_es)
+            for i in range(pop):
+                last = None
+                for k in range(hof_n):
+                    if role == "agent_0":
+                        g = play_game(stream, popu[role][i], hof["agent_1"][hof_n - 1 - k],
+                                      hof["adversary_0"][hof_n - 1 - k], args.max_timesteps_per_episode, max_cycles)
+                    elif role == "agent_1":
+                        g = play_game(stream, hof["agent_0"][hof_n - 1 - k], popu[role][i],
+                                      hof["adversary_0"][hof_n - 1 - k], args.max_timesteps_per_episode, max_cycles)
+                    else:  # Q4: both good opponents come from hof_agent_0
+                        g = play_game(stream, hof["agent_0"][hof_n - 1 - k], hof["agent_0"][hof_n - 1 - k],
+                                      popu[role][i], args.max_timesteps_per_episode, max_cycles)
+                    rec["games"].append(g)
+                    last = g["rewards"][ph]  # Q2: overwritten each k
+                fit.append(last / hof_n / (1 + div))
+            fitness[role] = fit
+            rec["fitness"].append([float(f) for f in fit])
+            rec["diversity"].append(float(div))
+        elites = {}
+        for role in ROLES:
+            order = np.argsort(fitness[role])[::-1]  # Q13
+            ids = [int(x) for x in order[:E]]
+            rec["elite_ids"].append(ids)
+            elites[role] = [popu[role][i] for i in ids]
+        best = {r: elites[r][0] for r in ROLES}
+        for r in ROLES:
+            hof[r].append(best[r])
+            hof[r].pop(0)
+        new_pop = {}
+        for r in ROLES:  # mutate_elites: clone() builds a fresh net first (burns init draws)
+            sigma = getattr(args, sig_attr[r])
+            children = []
+            for i in range(pop - 1):
+                init_net(D[r])
+                children.append(mutate_torch(elites[r][i % E], D[r], sigma))
+            new_pop[r] = [best[r]] + children
+        popu = new_pop
+        rec["hof"] = {r: [w for w in hof[r]] for r in ROLES}
+        rec["elites"] = {r: [w for w in elites[r]] for r in ROLES}
+        ev = [0.0, 0.0, 0.0]
+        for _ in range(10):
+            g = play_game(stream, best["agent_0"], best["agent_1"], best["adversary_0"],
+                          args.max_evaluation_steps, max_cycles)
+            rec["games"].append(g)
+            for s in range(3):
+                ev[s] += g["rewards"][s]
+        ev = [e / 10 for e in ev]
+        rec["eval_rewards"] = ev
+        for s, r in enumerate(ROLES):
+            rewards_hist[r].append(ev[s])
+        if args.adaptive:
+            adapt_sigma(args, gen, rewards_hist)
+        rec["sigma_after"] = [args.mutation_power_agent_0, args.mutation_power_agent_1,
+                              args.mutation_power_adversary]
+        out.append(rec)
+        if log:
+            log(gen, rec)
+    return out
+
+
+def adapt_sigma(args, gen, hist):
+    """genetic_algorithm.py:323-345 / evolutionary_strategy.py:292-316 (Q5 included)."""
+    def worse(h):
+        return gen > 10 and np.mean(h[-10:]) < np.mean(h[-20:-10])
+    if worse(hist["agent_0"]):
+        args.mutation_power_agent_0 = min(args.mutation_power_agent_1 * 1.2, args.max_mutation_power)
+    else:
+        args.mutation_power_agent_0 = max(args.mutation_power_agent_0 * 0.95, args.min_mutation_power)
+    if worse(hist["agent_1"]):
+        args.mutation_power_agent_1 = min(args.mutation_power_agent_1 * 1.2, args.max_mutation_power)
+    else:
+        args.mutation_power_agent_1 = max(args.mutation_power_agent_1 * 0.95, args.min_mutation_power)
+    if worse(hist["adversary_0"]):
+        args.mutation_power_adversary = min(args.mutation_power_adversary * 1.2, args.max_mutation_power)
+    else:
+        args.mutation_power_adversary = max(args.mutation_power_adversary * 0.95, args.min_mutation_power)
+
+
+# ------------------------------------------------------------------ Co-ES
+def perturbable(flat, D):
+    return weights_es(flat, D)
+
+
+def set_perturbable(flat, D, vec):
+    out = flat.copy()
+    i = 0
+    for o, n in linear_segments(D):
+        out[o:o + n] = vec[i:i + n]
+        i += n
+    return out
+
+
+def es_train(args, max_cycles=25):
+    stream = Stream()
+    D = ROLE_D
+    base = {r: init_net(D[r]) for r in ROLES}  # evolutionary_strategy.py:163-165
+    base_w = {r: perturbable(base[r], D[r]).astype(np.float32) for r in ROLES}
+    sig_attr = {"agent_0": "mutation_power_agent_0", "agent_1": "mutation_power_agent_1",
+                "adversary_0": "mutation_power_adversary"}
+    hist = {r: [] for r in ROLES}
+    out = []
+    for gen in range(args.generations):
+        rec = {"games": []}
+        noises = {r: [] for r in ROLES}
+        rewards = {r: [] for r in ROLES}
+        pop_w = {r: [] for r in ROLES}
+        for _ in range(args.population):
+            for s, r in enumerate(ROLES):
+                init_net(D[r])  # clone() constructs a fresh net (torch RNG only)
+                sigma = getattr(args, sig_attr[r])
+                w = perturbable(base[r], D[r])
+                noise = np.random.normal(loc=0.0, scale=sigma, size=len(w))  # agent.py:52, fp64
+                mutated = set_perturbable(base[r], D[r], (w + noise).astype(np.float32))
+                nets = {q: base[q] for q in ROLES}
+                nets[r] = mutated
+                g = play_game(stream, nets["agent_0"], nets["agent_1"], nets["adversary_0"],
+                              args.max_timesteps_per_episode, max_cycles)
+                rec["games"].append(g)
+                noises[r].append(noise.astype(np.float32))
+                rewards[r].append(g["rewards"][s])
+                pop_w[r].append(weights_es(mutated, D[r]))
+        rec["diversity"] = []
+        for r in ROLES:  # compute_weight_update :120-148
+            n_arr = np.array(noises[r], dtype=np.float32)
+            f = np.array(rewards[r], dtype=np.float32)
+            div = None
+            if args.fitness_sharing:
+                div = diversity(base_w[r], pop_w[r])
+                f = f / (1 + div)
+            sigma = getattr(args, sig_attr[r])
+            upd = (args.learning_rate / (len(n_arr) * sigma)) * np.dot(n_arr.T, f)
+            base_w[r] = base_w[r] + upd.astype(np.float32)
+            base[r] = set_perturbable(base[r], D[r], base_w[r])
+            rec["diversity"].append(None if div is None else float(div))
+        ev = [0.0, 0.0, 0.0]
+        for _ in range(10):
+            g = play_game(stream, base["agent_0"], base["agent_1"], base["adversary_0"],
+                          args.max_evaluation_steps, max_cycles)
+            rec["games"].append(g)
+            for s in range(3):
+                ev[s] += g["rewards"][s]
+        ev = [e / 10 for e in ev]
+        rec["eval_rewards"] = ev
+        for s, r in enumerate(ROLES):
+            hist[r].append(ev[s])
+        if args.adaptive:
+            adapt_sigma(args, gen, hist)
+        rec["sigma_after"] = [args.mutation_power_agent_0, args.mutation_power_agent_1,
+                              args.mutation_power_adversary]
+        rec["base"] = {r: base[r].copy() for r in ROLES}
+        out.append(rec)
+    return out

@@ -215,7 +215,21 @@ def run_ga(cfg):
     env = make_env(cfg.get("max_cycles", 25))
     args = Bag(algorithm="GA", **cfg["args"])
     LOG.games = []
-    rec = {"diversity": [], "saves": [], "plots": []}
+    rec = {"diversity": [], "saves": [], "plots": [], "argsort_in": [], "argsort_out": []}
+
+    class NpProxy:
+        """Forwards to numpy; logs what the trainer hands to np.argsort (genetic_algorithm.py:223-225),
+        i.e. the population fitness lists exactly as the reference computed them."""
+
+        def __getattr__(self, name):
+            return getattr(np, name)
+
+        @staticmethod
+        def argsort(a, *x, **k):
+            out = np.argsort(a, *x, **k)
+            rec["argsort_in"].append([(float(v), type(v).__name__) for v in a])
+            rec["argsort_out"].append([int(v) for v in out])
+            return out
 
     def div_hook(individual_weights, population_weights, args, sigma=None):
         d = ref_glf.diversity_penalty(individual_weights, population_weights, args, sigma)
@@ -234,6 +248,7 @@ def run_ga(cfg):
     ref_ga.diversity_penalty = div_hook
     ref_ga.save_model = save_hook
     ref_ga.plot_experiment_metrics = plot_hook
+    ref_ga.np = NpProxy()
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as td:
         os.chdir(td)
@@ -241,25 +256,24 @@ def run_ga(cfg):
             ref_ga.genetic_algorithm_train(env, env.agents[0], args, td)
         finally:
             os.chdir(cwd)
+            ref_ga.np = np
     pop, hof, gens = args.population, args.hof_size, args.generations
     per_gen_games = 3 * pop * hof + 10
     gens_out = []
     for g in range(gens):
         games = LOG.games[g * per_gen_games:(g + 1) * per_gen_games]
         div = rec["diversity"][g * 3 * pop:(g + 1) * 3 * pop]
-        fit, elites = [], []
-        for ph, slot in enumerate((0, 1, 2)):  # phases: agent_0, agent_1, adversary; return slots
-            f = []
-            for i in range(pop):
-                last = games[ph * pop * hof + i * hof + hof - 1]["rewards"][slot]
-                f.append(last / hof / (1 + div[ph * pop + i]))
-            fit.append(f)
-            elites.append([int(x) for x in np.argsort(f)[::-1][:args.elites_number]])
+        fit, fit_type, elites = [], [], []
+        for ph in range(3):  # phases: agent_0, agent_1, adversary
+            logged = rec["argsort_in"][g * 3 + ph]
+            fit.append([v for v, _ in logged])
+            fit_type.append(sorted(set(t for _, t in logged)))
+            elites.append(rec["argsort_out"][g * 3 + ph][::-1][:args.elites_number])
         saves = rec["saves"][g * 6:(g + 1) * 6]
         plots = rec["plots"][g * 3:(g + 1) * 3]
         gens_out.append({
             "games": games, "diversity": [div[0], div[pop], div[2 * pop]],
-            "fitness": fit, "elite_ids": elites, "saves": saves,
+            "fitness": fit, "fitness_scalar_type": fit_type, "elite_ids": elites, "saves": saves,
             "eval_rewards": [plots[0]["rewards"][-1], plots[1]["rewards"][-1], plots[2]["rewards"][-1]],
             "sigma_after": [plots[0]["mutation_power_history"][-1], plots[1]["mutation_power_history"][-1],
                             plots[2]["mutation_power_history"][-1]],

@@ -1,0 +1,107 @@
+"""The CPU oracle (oracle/) against the golden fixtures minted from the reference itself."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_port as rp
+from tests.util import Bag, SAFE_MARGIN, load_golden, sha
+
+
+def test_fc_forward_vectors():
+    for case in load_golden("fc_forward.json")["cases"]:
+        torch.manual_seed(case["torch_seed"])
+        D = case["D"]
+        w = rp.init_net(D)
+        if case["mutated"]:
+            w = rp.mutate_torch(w, D, 0.05)
+        assert sha(w) == case["weights"]["sha256"]
+        obs = np.array(case["obs"], dtype=np.float32)
+        for r in range(obs.shape[0]):
+            a, logits, st = rp.fc_forward(w, D, obs[r])
+            ref = np.array(case["logits"][r], dtype=np.float32)
+            assert st == 0
+            # tolerance: fp32 summation-order noise of a 512-term dot product
+            np.testing.assert_allclose(logits, ref, rtol=2e-5, atol=2e-6)
+            srt = np.sort(ref)[::-1]
+            if srt[0] - srt[1] > SAFE_MARGIN:
+                assert a == case["actions"][r]
+
+
+def test_play_game_vectors():
+    for case in load_golden("play_game.json")["cases"]:
+        rp.seed = None
+        torch.manual_seed(case["torch_seed"])
+        np.random.seed(case["torch_seed"])
+        a0, a1, adv = rp.init_net(10), rp.init_net(10), rp.init_net(8)
+        assert [sha(a0), sha(a1), sha(adv)] == [w["sha256"] for w in case["weights"]]
+        stream = rp.Stream()
+        for g in case["games"]:
+            got = rp.play_game(stream, a0, a1, adv, case["limit"], case["max_cycles"])
+            assert got["steps"] == g["steps"]
+            if g["min_margin"] > SAFE_MARGIN:
+                assert got["actions"] == g["actions"]
+                assert got["rewards"] == g["rewards"]  # fp64, bit for bit
+            assert abs(got["min_margin"] - g["min_margin"]) < 1e-5
+
+
+def _check_games(got_games, ref_games):
+    n_safe = 0
+    for got, ref in zip(got_games, ref_games):
+        assert got["steps"] == ref["steps"]
+        if ref["min_margin"] > SAFE_MARGIN:
+            assert got["actions"] == ref["actions"]
+            assert got["rewards"] == ref["rewards"]
+            n_safe += 1
+    return n_safe
+
+
+@pytest.mark.parametrize("name", ["ga_cfg1.json", "ga_hof2.json"])
+def test_ga_generations(name):
+    fx = load_golden(name)
+    cfg = fx["config"]
+    torch.manual_seed(cfg["seed"])
+    np.random.seed(cfg["seed"])
+    args = Bag(algorithm="GA", **cfg["args"])
+    out = rp.ga_train(args, max_cycles=cfg.get("max_cycles", 25))
+    role_files = {"agent_0": ("hall_of_fame_agent_0.pth", "elite_weights_agent_0.pth"),
+                  "agent_1": ("hall_of_fame_agent_1.pth", "elite_weights_agent_1.pth"),
+                  "adversary_0": ("hall_of_fame_adversary.pth", "elite_weights_adversary.pth")}
+    for g, (got, ref) in enumerate(zip(out, fx["generations"])):
+        n_safe = _check_games(got["games"], ref["games"])
+        assert n_safe >= 0.9 * len(ref["games"])
+        assert got["elite_ids"] == ref["elite_ids"], f"gen {g}"
+        np.testing.assert_allclose(got["diversity"], ref["diversity"], rtol=1e-5)
+        for ph in range(3):
+            np.testing.assert_allclose(got["fitness"][ph], ref["fitness"][ph], rtol=1e-5, atol=1e-7)
+        saves = {s["file"]: s["agents"] for s in ref["saves"]}
+        for role, (hf, ef) in role_files.items():
+            assert [sha(w) for w in got["hof"][role]] == [a["sha256"] for a in saves[hf]]
+            assert [sha(w) for w in got["elites"][role]] == [a["sha256"] for a in saves[ef]]
+        np.testing.assert_allclose(got["eval_rewards"], ref["eval_rewards"], rtol=1e-12)
+        assert got["sigma_after"] == ref["sigma_after"]
+
+
+@pytest.mark.parametrize("name", ["es_small.json", "es_fs.json"])
+def test_es_generations(name):
+    fx = load_golden(name)
+    cfg = fx["config"]
+    torch.manual_seed(cfg["seed"])
+    np.random.seed(cfg["seed"])
+    args = Bag(algorithm="ES", **cfg["args"])
+    out = rp.es_train(args, max_cycles=cfg.get("max_cycles", 25))
+    files = {"agent_0": "agent_0.pth", "agent_1": "agent_1.pth", "adversary_0": "adversary.pth"}
+    for g, (got, ref) in enumerate(zip(out, fx["generations"])):
+        if g == 0:
+            # generation 0 games depend only on seeded init + numpy noise: exact where margin-safe
+            _check_games(got["games"][:3 * args.population], ref["games"][:3 * args.population])
+        saves = {s["file"]: s for s in ref["saves"]}
+        for role, f in files.items():
+            w = got["base"][role]
+            # the ES update is an fp32 GEMV whose order differs (numpy BLAS vs numpy BLAS is the same
+            # here, so this is usually exact; tolerance stated for other hosts)
+            np.testing.assert_allclose(np.sum(w.astype(np.float64)), saves[f]["agent"]["sum"], rtol=1e-6)
+            np.testing.assert_allclose(rp.perturbable(w, rp.ROLE_D[role])[:6], saves[f]["perturbable"],
+                                       rtol=1e-5, atol=1e-7)
+        assert got["sigma_after"] == ref["sigma_after"]
+        if ref["diversity"][0] is not None:
+            np.testing.assert_allclose(got["diversity"], ref["diversity"], rtol=1e-5)
