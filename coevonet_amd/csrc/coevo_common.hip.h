@@ -1,0 +1,96 @@
+// Shared device helpers for libcoevo (gfx950 only).
+//
+// Canonical fp32 arithmetic (the contract with oracle/coevo_oracle.c, bit for bit):
+//   Linear     acc = bias[j]; for k = 0..K-1: acc = fmaf(W[j][k], x[k], acc)
+//   Reduce(N)  blocks of 64 consecutive indices, balanced tree inside a block with adjacent pairs first
+//              (lane xor 1,2,4,8,16,32 on one 64-wide wavefront), block sums added left to right
+//   LayerNorm  mean = Reduce(x)/N; d = x-mean; var = Reduce(d*d)/N; rstd = 1/sqrtf(var+1e-5f);
+//              y = fmaf(d*rstd, gamma, beta);  ReLU y>0?y:0
+// The library is compiled with -ffp-contract=off: only the explicit __builtin_fmaf calls fuse.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/coevo.h"
+
+namespace coevo {
+
+constexpr int H1 = COEVO_FC_H1;      // 512
+constexpr int H2 = COEVO_FC_H2;      // 256
+constexpr int NACT = COEVO_FC_NACT;  // 5
+constexpr float LN_EPS = 1e-5f;
+
+// ---- device slab layout of one FCNetwork (floats), D = observation width (10 good / 8 adversary) -------------
+//   W1t [D][512]            fc1.weight transposed: a wavefront reads 64 consecutive outputs of one input k
+//   b1, g1, be1 [512] each  fc1.bias, ln1.weight, ln1.bias
+//   W2q [4][128][64][4]     fc2.weight tiled: [output block of 64][k/4][output in block][k%4]; lane l of wave w
+//                           streams its own output row 64w+l as consecutive 16-byte pieces, a wavefront reads
+//                           1 KiB contiguous per instruction and one wave's whole stream (128 KiB) is contiguous
+//   b2, g2, be2 [256] each
+//   W3 [5][256], b3 [5]     output layer, row-major
+// The stride between nets is padded to a multiple of 64 floats so every net (and W2q) is 256-byte aligned.
+__host__ __device__ constexpr int64_t fc_off_b1(int D) { return (int64_t)D * H1; }
+__host__ __device__ constexpr int64_t fc_off_w2(int D) { return fc_off_b1(D) + 3 * H1; }
+__host__ __device__ constexpr int64_t fc_off_b2(int D) { return fc_off_w2(D) + (int64_t)H1 * H2; }
+__host__ __device__ constexpr int64_t fc_off_w3(int D) { return fc_off_b2(D) + 3 * H2; }
+__host__ __device__ constexpr int64_t fc_off_b3(int D) { return fc_off_w3(D) + NACT * H2; }
+__host__ __device__ constexpr int64_t fc_params(int D) { return fc_off_b3(D) + NACT; }
+__host__ __device__ constexpr int64_t fc_stride(int D) { return (fc_params(D) + 63) / 64 * 64; }
+
+// slab position -> canonical flat index (torch parameters() order: fc1.w[512][D], fc1.b, ln1.w, ln1.b,
+// fc2.w[256][512], fc2.b, ln2.w, ln2.b, output.w[5][256], output.b).  Only W1 and W2 are re-tiled.
+__host__ __device__ inline int64_t fc_slab_to_flat(int64_t s, int D)
+{
+    const int64_t o_b1 = fc_off_b1(D), o_w2 = fc_off_w2(D), o_b2 = fc_off_b2(D);
+    if (s < o_b1) {  // W1t[k][j] -> fc1.w[j][k]
+        int64_t k = s / H1, j = s % H1;
+        return j * D + k;
+    }
+    if (s < o_w2) return s;  // b1, g1, be1 keep their place
+    if (s < o_b2) {          // W2q[jb][kq][l][c] -> fc2.w[64*jb + l][4*kq + c]
+        int64_t t = s - o_w2;
+        int64_t c = t & 3, l = (t >> 2) & 63, kq = (t >> 8) & 127, jb = t >> 15;
+        return o_w2 + (jb * 64 + l) * H1 + kq * 4 + c;
+    }
+    return s;
+}
+
+// ---- wavefront (64 lanes) canonical tree sum: every lane returns the block sum --------------------------------
+__device__ inline float wave_tree_sum(float v)
+{
+    v = v + __shfl_xor(v, 1, 64);
+    v = v + __shfl_xor(v, 2, 64);
+    v = v + __shfl_xor(v, 4, 64);
+    v = v + __shfl_xor(v, 8, 64);
+    v = v + __shfl_xor(v, 16, 64);
+    v = v + __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// ---- MPE observation element k of env slot `slot` from the fp64 struct-of-arrays game state -------------------
+// (PettingZoo simple_adversary.observation + SimpleEnv.observe's float32 cast; field indices in mpe_env.hip)
+__device__ inline float mpe_obs_element(const double *st, int n, int g, int slot, int k)
+{
+    const int c = k & 1, e = k >> 1;
+    int src;  // fp64 field the agent's own position is subtracted from
+    if (slot == COEVO_SLOT_ADVERSARY) {
+        src = (e < 2) ? (12 + 2 * e) : (2 * (e - 1));  // lm0, lm1, agent_0, agent_1
+    } else {
+        if (e == 0) src = 16;                           // goal
+        else if (e < 3) src = 12 + 2 * (e - 1);         // lm0, lm1
+        else if (e == 3) src = 0;                       // adversary
+        else src = 2 * (slot == COEVO_SLOT_AGENT_0 ? 2 : 1);  // the other good agent
+    }
+    return (float)(st[(size_t)(src + c) * n + g] - st[(size_t)(2 * slot + c) * n + g]);
+}
+
+__device__ inline bool bad_post_relu(float y) { return __builtin_isnan(y) || (__builtin_isinf(y) && y > 0.0f); }
+__device__ inline float relu_keep_nan(float y) { return (y > 0.0f) ? y : (__builtin_isnan(y) ? y : 0.0f); }
+
+}  // namespace coevo
+
+#define COEVO_HIP_CHECK(expr)                        \
+    do {                                             \
+        hipError_t _e = (expr);                      \
+        if (_e != hipSuccess) return COEVO_ERR_HIP;  \
+    } while (0)

@@ -1,0 +1,267 @@
+// K1 - FCNetwork policy step for many (weight set x observation rows) tasks in one launch.
+//
+// Replaces FCNetwork.forward + determine_action (reference MPE/fcnetwork.py:37-90), which the reference calls
+// once per agent-step at batch 1 (utils/game_logic_functions.py:152-163).
+//
+// One workgroup (4 wavefronts of 64) = one task = one weight set applied to up to R observation rows.
+// HBM traffic per task is the weight set itself, read exactly once, fully coalesced:
+//   fc1  W1t[k][512]           each lane owns outputs t and t+256, wave reads 256 B rows (20 KB total)
+//   fc2  W2q[4][128][64][4]    wave w streams its 128 KiB block as 1 KiB wave-instructions (global_load_dwordx4),
+//                              8 in flight per lane; the R activations of each k-quad are LDS broadcast reads
+//   out  W3[5][256]            staged through LDS once
+// Arithmetic per weight byte is tiny (R FMAs per 4 bytes): the kernel is bound by HBM / Infinity-Cache
+// bandwidth, not by the VALU, so no MFMA here (per-individual weights make this a grouped GEMV).
+// All fp32 math follows the canonical order in coevo_common.hip.h, so logits equal the oracle's bit for bit.
+#include "coevo_common.hip.h"
+
+namespace coevo {
+
+template <int R>
+struct FcSmem {
+    static constexpr int RP = R | 1;  // odd row pitch: conflict-free scatter of h1 into the k-quad image
+    union {
+        float h1q[128][RP][4];  // [k/4][row][k%4]: one ds_read_b128 hands a k-quad of one row to every lane
+        float h2[R][260];       // fc2 activations, row pitch 260 keeps 16-byte alignment, shifts banks by 4
+    };
+    float xs0[R][COEVO_OBS_STRIDE];
+    float w3s[NACT][260];
+    float red[R][8];
+    float logit[R][COEVO_LOGIT_STRIDE];
+};
+
+struct FcArgs {
+    const float *slab;
+    const coevo_fc_task *tasks;
+    const float *obs;          // FROM_STATE == false
+    const double *state;       // FROM_STATE == true: [COEVO_MPE_STATE_DOUBLES][n_games]
+    const int32_t *row_game;
+    const int32_t *row_slot;
+    int n_games;
+    int32_t *actions;
+    float *logits;  // may be null
+    int32_t *status;
+};
+
+template <int R, bool FROM_STATE>
+__global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
+{
+    __shared__ FcSmem<R> sm;
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    const coevo_fc_task task = a.tasks[blockIdx.x];
+    const int D = task.D, nrows = task.n_rows, row0 = task.row_begin;
+    const float *net = a.slab + task.net_off;
+    int st = 0;
+
+    // ---- stage observations (zero padded) and the output layer -------------------------------------------
+    for (int i = t; i < R * COEVO_OBS_STRIDE; i += 256) {
+        const int r = i / COEVO_OBS_STRIDE, k = i % COEVO_OBS_STRIDE;
+        float v = 0.0f;
+        if (r < nrows && k < D) {
+            if constexpr (FROM_STATE) {
+                const int row = row0 + r;
+                v = mpe_obs_element(a.state, a.n_games, a.row_game[row], a.row_slot[row], k);
+            } else {
+                v = a.obs[(size_t)(row0 + r) * COEVO_OBS_STRIDE + k];
+            }
+            if (!__builtin_isfinite(v)) st |= COEVO_ST_BAD_INPUT;
+        }
+        sm.xs0[r][k] = v;
+    }
+    {
+        const float *W3 = net + fc_off_w3(D);
+        for (int i = t; i < NACT * H2; i += 256) sm.w3s[i >> 8][i & 255] = W3[i];
+    }
+    __syncthreads();
+
+    // ---- fc1: outputs j0 = t, j1 = t + 256; sequential-k chains from the bias -----------------------------
+    float a0[R], a1[R];
+    {
+        const float *b1 = net + fc_off_b1(D);
+        const float bb0 = b1[t], bb1 = b1[t + 256];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { a0[r] = bb0; a1[r] = bb1; }
+        for (int k = 0; k < D; ++k) {
+            const float w0 = net[(size_t)k * H1 + t], w1 = net[(size_t)k * H1 + 256 + t];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float x = sm.xs0[r][k];
+                a0[r] = __builtin_fmaf(w0, x, a0[r]);
+                a1[r] = __builtin_fmaf(w1, x, a1[r]);
+            }
+        }
+    }
+    // ---- LayerNorm(512) + ReLU: block b of the canonical reduce is wave (b & 3), half (b >> 2) -------------
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float s0 = wave_tree_sum(a0[r]), s1 = wave_tree_sum(a1[r]);
+        if (l == 0) { sm.red[r][w] = s0; sm.red[r][4 + w] = s1; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float tot = sm.red[r][0];
+#pragma unroll
+        for (int b = 1; b < 8; ++b) tot = tot + sm.red[r][b];
+        const float mean = tot * (1.0f / H1);
+        a0[r] = a0[r] - mean;
+        a1[r] = a1[r] - mean;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float s0 = wave_tree_sum(a0[r] * a0[r]), s1 = wave_tree_sum(a1[r] * a1[r]);
+        if (l == 0) { sm.red[r][w] = s0; sm.red[r][4 + w] = s1; }
+    }
+    __syncthreads();
+    {
+        const float *g1 = net + fc_off_b1(D) + H1, *be1 = g1 + H1;
+        const float ga0 = g1[t], ga1 = g1[t + 256], bt0 = be1[t], bt1 = be1[t + 256];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float tot = sm.red[r][0];
+#pragma unroll
+            for (int b = 1; b < 8; ++b) tot = tot + sm.red[r][b];
+            const float var = tot * (1.0f / H1);
+            const float rstd = 1.0f / __builtin_sqrtf(var + LN_EPS);
+            const float y0 = __builtin_fmaf(a0[r] * rstd, ga0, bt0);
+            const float y1 = __builtin_fmaf(a1[r] * rstd, ga1, bt1);
+            if (r < nrows && (bad_post_relu(y0) || bad_post_relu(y1))) st |= COEVO_ST_BAD_FC1;
+            sm.h1q[t >> 2][r][t & 3] = relu_keep_nan(y0);
+            sm.h1q[(t + 256) >> 2][r][t & 3] = relu_keep_nan(y1);
+        }
+    }
+    __syncthreads();
+
+    // ---- fc2: lane owns output 64w + l; 128 k-quads streamed as 16-byte pieces, 8 loads in flight ----------
+    float acc[R];
+    {
+        const float bb = net[fc_off_b2(D) + t];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = bb;
+        const float4 *wp = reinterpret_cast<const float4 *>(net + fc_off_w2(D)) + (size_t)w * 128 * 64 + l;
+        constexpr int U = 8;
+        for (int kq = 0; kq < 128; kq += U) {
+            float4 wv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) wv[u] = wp[(size_t)(kq + u) * 64];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float4 x = *reinterpret_cast<const float4 *>(&sm.h1q[kq + u][r][0]);
+                    acc[r] = __builtin_fmaf(wv[u].x, x.x, acc[r]);
+                    acc[r] = __builtin_fmaf(wv[u].y, x.y, acc[r]);
+                    acc[r] = __builtin_fmaf(wv[u].z, x.z, acc[r]);
+                    acc[r] = __builtin_fmaf(wv[u].w, x.w, acc[r]);
+                }
+            }
+        }
+    }
+    // ---- LayerNorm(256) + ReLU: block b = wave b ------------------------------------------------------------
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float s = wave_tree_sum(acc[r]);
+        if (l == 0) sm.red[r][w] = s;
+    }
+    __syncthreads();  // also: every wave is done reading h1q, h2 may overwrite it below
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float tot = ((sm.red[r][0] + sm.red[r][1]) + sm.red[r][2]) + sm.red[r][3];
+        acc[r] = acc[r] - tot * (1.0f / H2);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float s = wave_tree_sum(acc[r] * acc[r]);
+        if (l == 0) sm.red[r][w] = s;
+    }
+    __syncthreads();
+    {
+        const float *g2 = net + fc_off_b2(D) + H2, *be2 = g2 + H2;
+        const float ga = g2[t], bt = be2[t];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float tot = ((sm.red[r][0] + sm.red[r][1]) + sm.red[r][2]) + sm.red[r][3];
+            const float rstd = 1.0f / __builtin_sqrtf(tot * (1.0f / H2) + LN_EPS);
+            const float y = __builtin_fmaf(acc[r] * rstd, ga, bt);
+            if (r < nrows && bad_post_relu(y)) st |= COEVO_ST_BAD_FC2;
+            sm.h2[r][t] = relu_keep_nan(y);
+        }
+    }
+    __syncthreads();
+
+    // ---- output layer: one lane per (row, action), 256-long sequential chain out of LDS --------------------
+    if (t < R * NACT) {
+        const int r = t / NACT, o = t % NACT;
+        float y = net[fc_off_b3(D) + o];
+        const float4 *wr = reinterpret_cast<const float4 *>(&sm.w3s[o][0]);
+        const float4 *xr = reinterpret_cast<const float4 *>(&sm.h2[r][0]);
+#pragma unroll 8
+        for (int k = 0; k < H2 / 4; ++k) {
+            const float4 wv = wr[k], xv = xr[k];
+            y = __builtin_fmaf(wv.x, xv.x, y);
+            y = __builtin_fmaf(wv.y, xv.y, y);
+            y = __builtin_fmaf(wv.z, xv.z, y);
+            y = __builtin_fmaf(wv.w, xv.w, y);
+        }
+        sm.logit[r][o] = y;
+    }
+    __syncthreads();
+
+    // ---- first-max action (strict '>' scan from -inf), status --------------------------------------------
+    if (t < nrows) {
+        int best = -1;
+        float cur = -__builtin_inff();
+#pragma unroll
+        for (int o = 0; o < NACT; ++o) {
+            const float v = sm.logit[t][o];
+            if (!__builtin_isfinite(v)) st |= COEVO_ST_BAD_OUT;
+            if (v > cur) { cur = v; best = o; }
+        }
+        if (best < 0) { st |= COEVO_ST_NO_ACTION; best = 0; }
+        a.actions[row0 + t] = best;
+        if (a.logits) {
+#pragma unroll
+            for (int o = 0; o < NACT; ++o) a.logits[(size_t)(row0 + t) * COEVO_LOGIT_STRIDE + o] = sm.logit[t][o];
+        }
+    }
+    if (st) atomicOr(a.status, st);
+}
+
+template <bool FROM_STATE>
+static int launch_fc(const FcArgs &a, int n_tasks, int max_rows, hipStream_t s)
+{
+    if (n_tasks <= 0) return COEVO_OK;
+    if (max_rows <= 8)
+        hipLaunchKernelGGL((fc_policy_kernel<8, FROM_STATE>), dim3(n_tasks), dim3(256), 0, s, a);
+    else if (max_rows <= 16)
+        hipLaunchKernelGGL((fc_policy_kernel<16, FROM_STATE>), dim3(n_tasks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((fc_policy_kernel<32, FROM_STATE>), dim3(n_tasks), dim3(256), 0, s, a);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+}  // namespace coevo
+
+extern "C" int coevo_fc_forward_argmax(const float *slab, const coevo_fc_task *tasks, int n_tasks,
+                                       int max_rows_per_task, const float *obs, int32_t *actions, float *logits,
+                                       int32_t *status, void *stream)
+{
+    if (!slab || !tasks || !obs || !actions || !status || n_tasks < 0) return COEVO_ERR_ARG;
+    if (max_rows_per_task < 1 || max_rows_per_task > COEVO_FC_MAX_ROWS) return COEVO_ERR_ARG;
+    coevo::FcArgs a{slab, tasks, obs, nullptr, nullptr, nullptr, 0, actions, logits, status};
+    return coevo::launch_fc<false>(a, n_tasks, max_rows_per_task, (hipStream_t)stream);
+}
+
+extern "C" int coevo_mpe_policy_cycle(const float *slab, const coevo_fc_task *tasks, int n_tasks,
+                                      int max_rows_per_task, const double *state, int n_games,
+                                      const int32_t *row_game, const int32_t *row_slot, int32_t *actions,
+                                      int32_t *status, void *stream)
+{
+    if (!slab || !tasks || !state || !row_game || !row_slot || !actions || !status) return COEVO_ERR_ARG;
+    if (n_tasks < 0 || n_games <= 0) return COEVO_ERR_ARG;
+    if (max_rows_per_task < 1 || max_rows_per_task > COEVO_FC_MAX_ROWS) return COEVO_ERR_ARG;
+    coevo::FcArgs a{slab, tasks, nullptr, state, row_game, row_slot, n_games, actions, nullptr, status};
+    return coevo::launch_fc<true>(a, n_tasks, max_rows_per_task, (hipStream_t)stream);
+}

@@ -1,0 +1,204 @@
+// Device-side MPE simple_adversary for E env copies (fp64, bit-identical with the host env in
+// coevonet_amd/mpe/simple_adversary.py and with oracle/coevo_oracle.c).
+//
+// Replaces, for a whole batch of games at once, what play_MPE drives through the AEC API
+// (reference utils/game_logic_functions.py:123-212: env.observe :138, env.step :179, env.last :181,
+// rewards[agent] += reward :190, the limit/truncation breaks :197-204) and play_game's env.reset() (:217).
+//
+// State is struct-of-arrays [COEVO_MPE_STATE_DOUBLES][n_games] so that a wavefront touching 64 consecutive games
+// reads 512 contiguous bytes per field:
+//   0..5   ppos[agent][xy]   (agents: 0 adversary_0, 1 agent_0, 2 agent_1)
+//   6..11  pvel[agent][xy]
+//   12..15 landmark[l][xy]
+//   16..17 goal landmark position
+//   18     rg_prev: good reward of the latest world step (0 before the first)
+//   19..21 acc[slot]: rewards credited to the acting agent of that slot (quirk Q1)
+//   22     goal index, 23 spare
+#include "coevo_common.hip.h"
+
+namespace coevo {
+
+typedef unsigned __int128 u128;
+
+__device__ inline u128 pcg_mult()
+{
+    return (((u128)0x2360ED051FC65DA4ULL) << 64) | (u128)0x4385DF649FCCF645ULL;
+}
+
+__device__ inline uint64_t pcg_output(u128 s)
+{
+    const uint64_t hi = (uint64_t)(s >> 64), lo = (uint64_t)s;
+    const uint64_t x = hi ^ lo;
+    const unsigned r = (unsigned)(hi >> 58);
+    return (x >> r) | (x << ((64 - r) & 63));
+}
+
+// state after `delta` further steps of the 128-bit LCG (O(log delta))
+__device__ inline u128 pcg_advance(u128 state, u128 inc, uint64_t delta)
+{
+    u128 acc_mult = 1, acc_plus = 0, cur_mult = pcg_mult(), cur_plus = inc;
+    while (delta > 0) {
+        if (delta & 1) {
+            acc_mult *= cur_mult;
+            acc_plus = acc_plus * cur_mult + cur_plus;
+        }
+        cur_plus = (cur_mult + 1) * cur_plus;
+        cur_mult *= cur_mult;
+        delta >>= 1;
+    }
+    return acc_mult * state + acc_plus;
+}
+
+// numpy Generator semantics of one PettingZoo reset: choice(2) = one buffered 32-bit draw (the low half of a
+// 64-bit output for even ordinals, the kept high half for odd ones; Lemire range 2 => top bit), then ten
+// uniform(-1,1) doubles.  Two resets consume 21 raw 64-bit outputs.
+__global__ void mpe_reset_kernel(double *st, int n, coevo_pcg64 rng, uint64_t first_ordinal)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const uint64_t ordinal = first_ordinal + (uint64_t)g;
+    const u128 inc = ((u128)rng.pcg_inc_hi << 64) | rng.pcg_inc_lo;
+    u128 s = ((u128)rng.pcg_state_hi << 64) | rng.pcg_state_lo;
+    s = pcg_advance(s, inc, (ordinal >> 1) * 21);
+    s = s * pcg_mult() + inc;
+    const uint64_t c = pcg_output(s);
+    const uint32_t half = (ordinal & 1) ? (uint32_t)(c >> 32) : (uint32_t)c;
+    const int goal = (int)(((uint64_t)half * 2) >> 32);
+    if (ordinal & 1) s = pcg_advance(s, inc, 10);
+    double d[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        s = s * pcg_mult() + inc;
+        d[i] = -1.0 + 2.0 * ((double)(pcg_output(s) >> 11) * (1.0 / 9007199254740992.0));
+    }
+    const size_t N = (size_t)n;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        st[i * N + g] = d[i];        // agent positions
+        st[(6 + i) * N + g] = 0.0;   // velocities
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st[(12 + i) * N + g] = d[6 + i];
+    st[16 * N + g] = d[6 + 2 * goal];
+    st[17 * N + g] = d[7 + 2 * goal];
+    st[18 * N + g] = 0.0;
+    st[19 * N + g] = 0.0;
+    st[20 * N + g] = 0.0;
+    st[21 * N + g] = 0.0;
+    st[22 * N + g] = (double)goal;
+    st[23 * N + g] = 0.0;
+}
+
+__global__ void mpe_observe_kernel(const double *st, int n, const int32_t *row_game, const int32_t *row_slot,
+                                   int n_rows, float *obs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * COEVO_OBS_STRIDE) return;
+    const int row = i / COEVO_OBS_STRIDE, k = i % COEVO_OBS_STRIDE;
+    const int slot = row_slot[row];
+    const int D = (slot == COEVO_SLOT_ADVERSARY) ? 8 : 10;
+    obs[i] = (k < D) ? mpe_obs_element(st, n, row_game[row], slot, k) : 0.0f;
+}
+
+// One world cycle (three agent-steps) of every game.  Agent-step index of slot s in cycle c is t = 3c + s; it
+// happens only while t < limit (play_MPE breaks at timesteps >= limit, :197) and c < max_cycles (truncation, :204,
+// enforced by the caller never launching more cycles).  Credits (quirk Q1):
+//   adversary_0 acting at 3c   receives agent_0's cumulative reward  = good reward of world step c
+//   agent_0     acting at 3c+1 receives agent_1's cumulative reward  = good reward of world step c
+//   agent_1     acting at 3c+2 triggers world step c+1 and receives the adversary's reward of that step
+__global__ void mpe_step_kernel(double *st, int n, const int32_t *game_rows, const int32_t *actions, int cycle,
+                                const int32_t *game_limit, int pos_first)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const size_t N = (size_t)n;
+    const int limit = game_limit ? game_limit[g] : 0x7fffffff;
+    const int t0 = 3 * cycle;
+    if (t0 >= limit) return;
+    const double rg_prev = st[18 * N + g];
+    st[19 * N + g] = st[19 * N + g] + rg_prev;                      // adversary_0 acted
+    if (t0 + 1 < limit) st[20 * N + g] = st[20 * N + g] + rg_prev;  // agent_0 acted
+    if (t0 + 2 >= limit) return;                                    // agent_1 did not act: no world step
+    double d[3];
+    const double gx = st[16 * N + g], gy = st[17 * N + g];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int act = actions[game_rows[3 * g + i]];
+        double u[2] = {0.0, 0.0};
+        if (act == 1) u[0] = -1.0;
+        if (act == 2) u[0] = +1.0;
+        if (act == 3) u[1] = -1.0;
+        if (act == 4) u[1] = +1.0;
+        double p[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const double f = (((u[c] * 5.0) + 0.0) / 1.0) * 0.1;
+            double pos = st[(2 * i + c) * N + g], vel = st[(6 + 2 * i + c) * N + g];
+            if (pos_first) pos = pos + vel * 0.1;
+            vel = vel * 0.75;
+            vel = vel + f;
+            if (!pos_first) pos = pos + vel * 0.1;
+            st[(2 * i + c) * N + g] = pos;
+            st[(6 + 2 * i + c) * N + g] = vel;
+            p[c] = pos;
+        }
+        const double dx = p[0] - gx, dy = p[1] - gy;
+        d[i] = sqrt(dx * dx + dy * dy);
+    }
+    const double r_adv = -d[0];
+    const double m = (d[2] < d[1]) ? d[2] : d[1];
+    const double r_good = -m + d[0];
+    st[21 * N + g] = st[21 * N + g] + r_adv;  // agent_1 acted
+    st[18 * N + g] = r_good;
+}
+
+__global__ void mpe_rewards_kernel(const double *st, int n, double *rewards)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const size_t N = (size_t)n;
+    rewards[3 * (size_t)g + 0] = st[20 * N + g];  // agent_0
+    rewards[3 * (size_t)g + 1] = st[21 * N + g];  // agent_1
+    rewards[3 * (size_t)g + 2] = st[19 * N + g];  // adversary_0
+}
+
+}  // namespace coevo
+
+extern "C" int coevo_mpe_reset(double *state, int n_games, coevo_pcg64 rng, uint64_t first_ordinal, void *stream)
+{
+    if (!state || n_games <= 0) return COEVO_ERR_ARG;
+    hipLaunchKernelGGL(coevo::mpe_reset_kernel, dim3((n_games + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                       state, n_games, rng, first_ordinal);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_mpe_observe(const double *state, int n_games, const int32_t *row_game,
+                                 const int32_t *row_slot, int n_rows, float *obs, void *stream)
+{
+    if (!state || !row_game || !row_slot || !obs || n_games <= 0 || n_rows <= 0) return COEVO_ERR_ARG;
+    const int total = n_rows * COEVO_OBS_STRIDE;
+    hipLaunchKernelGGL(coevo::mpe_observe_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       state, n_games, row_game, row_slot, n_rows, obs);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_mpe_step(double *state, int n_games, const int32_t *game_rows, const int32_t *actions,
+                              int cycle, const int32_t *game_limit, int pos_first, void *stream)
+{
+    if (!state || !game_rows || !actions || n_games <= 0 || cycle < 0) return COEVO_ERR_ARG;
+    hipLaunchKernelGGL(coevo::mpe_step_kernel, dim3((n_games + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                       state, n_games, game_rows, actions, cycle, game_limit, pos_first);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_mpe_rewards(const double *state, int n_games, double *rewards, void *stream)
+{
+    if (!state || !rewards || n_games <= 0) return COEVO_ERR_ARG;
+    hipLaunchKernelGGL(coevo::mpe_rewards_kernel, dim3((n_games + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                       state, n_games, rewards);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}

@@ -1,0 +1,272 @@
+// K3/K4/K5/K8 - building offspring weights on the device, plus slab <-> canonical-order packing.
+//
+// Replaces (reference file:line): MPEAgent.clone's state_dict copy (MPE/mpe_agent.py:24-28), Agent.mutate
+// (agent.py:25-29: noise = torch.normal(0, sigma, size); param += noise for EVERY parameter, LayerNorm affine
+// included), Agent.mutate_ES (agent.py:51-53: Linear weights/biases only) and compute_weight_update
+// (evolutionary_strategy.py:120-148).
+//
+// Noise is counter-based so that no weight ever crosses PCIe: eps(seed, stream, p) for canonical flat index p is
+// element p%4 of Philox4x32-10(counter = (p/4, stream_lo, stream_hi, 'coev'), key = seed) pushed through a
+// Box-Muller transform whose log / sincos are fmaf-only polynomials (bit-identical with oracle/coevo_oracle.c).
+// A child is one streaming pass: read parent (L2/Infinity-Cache resident elite), write child once.
+#include "coevo_common.hip.h"
+
+namespace coevo {
+
+struct u32x4 { uint32_t v[4]; };
+
+__device__ inline u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return u32x4{{c0, c1, c2, c3}};
+}
+
+// ln(x), x a normal float in (0,1): exponent by bit ops, cephes logf polynomial evaluated with fmaf only
+__device__ inline float canon_logf(float x)
+{
+    const uint32_t b = __float_as_uint(x);
+    int e = (int)((b >> 23) & 0xff) - 126;
+    float m = __uint_as_float((b & 0x007fffffu) | 0x3f000000u);
+    if (m < 0.707106781186547524f) { e -= 1; m = (m + m) - 1.0f; } else { m = m - 1.0f; }
+    const float z = m * m;
+    float y = 7.0376836292E-2f;
+    y = __builtin_fmaf(y, m, -1.1514610310E-1f);
+    y = __builtin_fmaf(y, m, 1.1676998740E-1f);
+    y = __builtin_fmaf(y, m, -1.2420140846E-1f);
+    y = __builtin_fmaf(y, m, 1.4249322787E-1f);
+    y = __builtin_fmaf(y, m, -1.6668057665E-1f);
+    y = __builtin_fmaf(y, m, 2.0000714765E-1f);
+    y = __builtin_fmaf(y, m, -2.4999993993E-1f);
+    y = __builtin_fmaf(y, m, 3.3333331174E-1f);
+    y = (y * m) * z;
+    const float fe = (float)e;
+    y = __builtin_fmaf(-2.12194440e-4f, fe, y);
+    y = __builtin_fmaf(-0.5f, z, y);
+    float r = m + y;
+    r = __builtin_fmaf(0.693359375f, fe, r);
+    return r;
+}
+
+// (cos, sin)(2*pi*u), u = k/2^24: exact quadrant split, cephes polynomials on [0, pi/4], fmaf only
+__device__ inline void canon_sincos2pi(float u, float &c_out, float &s_out)
+{
+    const float t = u * 4.0f;
+    const float qf = __builtin_floorf(t);
+    const int q = (int)qf;
+    float f = t - qf;
+    const bool swap = f > 0.5f;
+    if (swap) f = 1.0f - f;
+    const float x = f * 1.57079632679489661923f;
+    const float z = x * x;
+    float sp = -1.9515295891E-4f;
+    sp = __builtin_fmaf(sp, z, 8.3321608736E-3f);
+    sp = __builtin_fmaf(sp, z, -1.6666654611E-1f);
+    float s = __builtin_fmaf(sp * z, x, x);
+    float cp = 2.443315711809948E-005f;
+    cp = __builtin_fmaf(cp, z, -1.388731625493765E-003f);
+    cp = __builtin_fmaf(cp, z, 4.166664568298827E-002f);
+    float c = __builtin_fmaf(cp * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+    if (swap) { const float tmp = s; s = c; c = tmp; }
+    switch (q & 3) {
+    case 0: c_out = c; s_out = s; break;
+    case 1: c_out = -s; s_out = c; break;
+    case 2: c_out = -c; s_out = -s; break;
+    default: c_out = s; s_out = -c; break;
+    }
+}
+
+__device__ inline void box_muller(uint32_t a, uint32_t b, float &z0, float &z1)
+{
+    const float u1 = (float)(2u * (a >> 9) + 1u) * 5.9604644775390625e-08f;
+    const float u2 = (float)(b >> 8) * 5.9604644775390625e-08f;
+    const float r = __builtin_sqrtf(-2.0f * canon_logf(u1));
+    float c, s;
+    canon_sincos2pi(u2, c, s);
+    z0 = r * c;
+    z1 = r * s;
+}
+
+__device__ inline void philox_normal4(uint64_t seed, uint32_t stream_lo, uint32_t stream_hi, uint32_t q, float z[4])
+{
+    const u32x4 o = philox4x32_10(q, stream_lo, stream_hi, 0x636f6576u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    box_muller(o.v[0], o.v[1], z[0], z[1]);
+    box_muller(o.v[2], o.v[3], z[2], z[3]);
+}
+
+// is slab position s a LayerNorm affine parameter?
+__device__ inline bool fc_slab_is_layernorm(int64_t s, int D)
+{
+    const int64_t g1 = fc_off_b1(D) + H1, g2 = fc_off_b2(D) + H2;
+    return (s >= g1 && s < g1 + 2 * H1) || (s >= g2 && s < g2 + 2 * H2);
+}
+
+// Standard normals for the four slab positions s0..s0+3 (s0 % 4 == 0).  Everywhere except W1t the four positions
+// map to four consecutive canonical indices inside one Philox block, so one block serves them; W1t (3.7 % of a
+// net) pays one block per element.
+__device__ inline void slab_quad_normals(uint64_t seed, uint32_t slo, uint32_t shi, int64_t s0, int D, int64_t P,
+                                         float z[4])
+{
+    int64_t p[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = (s0 + i < P) ? fc_slab_to_flat(s0 + i, D) : -1;
+    float zz[4];
+    int64_t have = -1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (p[i] < 0) { z[i] = 0.0f; continue; }
+        const int64_t q = p[i] >> 2;
+        if (q != have) { philox_normal4(seed, slo, shi, (uint32_t)q, zz); have = q; }
+        z[i] = zz[p[i] & 3];
+    }
+}
+
+__global__ __launch_bounds__(256) void fc_perturb_kernel(const float *parent_slab, const int32_t *parent_idx,
+                                                          float *child_slab, int child_first, int D,
+                                                          const float *sigma_dev, uint64_t seed,
+                                                          uint32_t stream_lo_first, uint32_t stream_hi,
+                                                          int skip_layernorm)
+{
+    const int c = blockIdx.y;
+    const int64_t stride = fc_stride(D), P = fc_params(D);
+    const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (s0 >= stride) return;
+    const float sigma = *sigma_dev;
+    const float *par = parent_slab + (int64_t)parent_idx[c] * stride;
+    float *ch = child_slab + (int64_t)(child_first + c) * stride;
+    const float4 pv = *reinterpret_cast<const float4 *>(par + s0);
+    float z[4];
+    slab_quad_normals(seed, stream_lo_first + (uint32_t)c, stream_hi, s0, D, P, z);
+    float in[4] = {pv.x, pv.y, pv.z, pv.w}, out[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t s = s0 + i;
+        const bool keep = (s >= P) || (skip_layernorm && fc_slab_is_layernorm(s, D));
+        const float noise = sigma * z[i];  // rounded first, then added (agent.py:28-29)
+        out[i] = keep ? in[i] : in[i] + noise;
+    }
+    *reinterpret_cast<float4 *>(ch + s0) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
+__global__ __launch_bounds__(256) void fc_gather_kernel(const float *src_slab, const int32_t *src_idx,
+                                                         float *dst_slab, int dst_first, int64_t stride)
+{
+    const int c = blockIdx.y;
+    const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (s0 >= stride) return;
+    const float4 v = *reinterpret_cast<const float4 *>(src_slab + (int64_t)src_idx[c] * stride + s0);
+    *reinterpret_cast<float4 *>(dst_slab + (int64_t)(dst_first + c) * stride + s0) = v;
+}
+
+// theta[p] += lr/(n*sigma) * sum_i fitness[i] * (sigma * eps_i[p]); i ascending, one fmaf per term
+__global__ __launch_bounds__(256) void es_update_kernel(float *theta, int D, const float *fitness, int n,
+                                                         const float *sigma_dev, float lr, uint64_t seed,
+                                                         uint32_t stream_lo_first, uint32_t stream_hi)
+{
+    const int64_t stride = fc_stride(D), P = fc_params(D);
+    const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (s0 >= stride) return;
+    const float sigma = *sigma_dev;
+    const float scale = lr / ((float)n * sigma);
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = 0; i < n; ++i) {
+        float z[4];
+        slab_quad_normals(seed, stream_lo_first + (uint32_t)i, stream_hi, s0, D, P, z);
+        const float f = fitness[i];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_fmaf(f, sigma * z[c], acc[c]);
+    }
+    float4 tv = *reinterpret_cast<float4 *>(theta + s0);
+    float th[4] = {tv.x, tv.y, tv.z, tv.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int64_t s = s0 + c;
+        if (s < P && !fc_slab_is_layernorm(s, D)) th[c] = th[c] + scale * acc[c];
+    }
+    *reinterpret_cast<float4 *>(theta + s0) = make_float4(th[0], th[1], th[2], th[3]);
+}
+
+__global__ __launch_bounds__(256) void fc_pack_kernel(const float *flat, float *slab, int D, bool to_slab)
+{
+    const int net = blockIdx.y;
+    const int64_t stride = fc_stride(D), P = fc_params(D);
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= stride) return;
+    if (to_slab) {
+        slab[(int64_t)net * stride + s] = (s < P) ? flat[(int64_t)net * P + fc_slab_to_flat(s, D)] : 0.0f;
+    } else if (s < P) {
+        const_cast<float *>(flat)[(int64_t)net * P + fc_slab_to_flat(s, D)] = slab[(int64_t)net * stride + s];
+    }
+}
+
+}  // namespace coevo
+
+using namespace coevo;
+
+static bool fc_dim_ok(int D) { return D == 8 || D == 10; }
+
+extern "C" int64_t coevo_fc_param_count(int D) { return fc_dim_ok(D) ? fc_params(D) : COEVO_ERR_ARG; }
+extern "C" int64_t coevo_fc_slab_stride(int D) { return fc_dim_ok(D) ? fc_stride(D) : COEVO_ERR_ARG; }
+
+extern "C" int coevo_fc_pack(const float *flat, float *slab, int n, int D, void *stream)
+{
+    if (!flat || !slab || n <= 0 || !fc_dim_ok(D)) return COEVO_ERR_ARG;
+    const dim3 grid((unsigned)((fc_stride(D) + 255) / 256), (unsigned)n);
+    hipLaunchKernelGGL(fc_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, flat, slab, D, true);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_fc_unpack(const float *slab, float *flat, int n, int D, void *stream)
+{
+    if (!flat || !slab || n <= 0 || !fc_dim_ok(D)) return COEVO_ERR_ARG;
+    const dim3 grid((unsigned)((fc_stride(D) + 255) / 256), (unsigned)n);
+    hipLaunchKernelGGL(fc_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float *)flat,
+                       const_cast<float *>(slab), D, false);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_fc_perturb(const float *parent_slab, const int32_t *parent_idx, float *child_slab,
+                                int child_first, int n_children, int D, const float *sigma_dev, uint64_t seed,
+                                uint32_t stream_lo_first, uint32_t stream_hi, int skip_layernorm, void *stream)
+{
+    if (!parent_slab || !parent_idx || !child_slab || !sigma_dev || !fc_dim_ok(D)) return COEVO_ERR_ARG;
+    if (n_children < 0 || child_first < 0 || n_children > 65535) return COEVO_ERR_ARG;
+    if (n_children == 0) return COEVO_OK;
+    const dim3 grid((unsigned)((fc_stride(D) / 4 + 255) / 256), (unsigned)n_children);
+    hipLaunchKernelGGL(fc_perturb_kernel, grid, dim3(256), 0, (hipStream_t)stream, parent_slab, parent_idx,
+                       child_slab, child_first, D, sigma_dev, seed, stream_lo_first, stream_hi, skip_layernorm);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_fc_gather(const float *src_slab, const int32_t *src_idx, float *dst_slab, int dst_first,
+                               int n, int D, void *stream)
+{
+    if (!src_slab || !src_idx || !dst_slab || !fc_dim_ok(D) || n < 0 || dst_first < 0 || n > 65535)
+        return COEVO_ERR_ARG;
+    if (n == 0) return COEVO_OK;
+    const dim3 grid((unsigned)((fc_stride(D) / 4 + 255) / 256), (unsigned)n);
+    hipLaunchKernelGGL(fc_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, src_slab, src_idx, dst_slab,
+                       dst_first, fc_stride(D));
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_es_update(float *theta_slab_net, int D, const float *fitness, int n, const float *sigma_dev,
+                               float lr, uint64_t seed, uint32_t stream_lo_first, uint32_t stream_hi, void *stream)
+{
+    if (!theta_slab_net || !fitness || !sigma_dev || !fc_dim_ok(D) || n <= 0) return COEVO_ERR_ARG;
+    const dim3 grid((unsigned)((fc_stride(D) / 4 + 255) / 256));
+    hipLaunchKernelGGL(es_update_kernel, grid, dim3(256), 0, (hipStream_t)stream, theta_slab_net, D, fitness, n,
+                       sigma_dev, lr, seed, stream_lo_first, stream_hi);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}

@@ -1,0 +1,143 @@
+// K6/K7 - fitness sharing, GA fitness and ranking on the device, so that selection never waits on the host.
+//
+// Replaces (reference file:line): diversity_penalty (utils/game_logic_functions.py:12-37) as called from
+// genetic_algorithm.py:131-133 / evolutionary_strategy.py:128; the GA fitness expression
+// (genetic_algorithm.py:140-146, :172-178, :205-211) and np.argsort(fitness)[::-1] (:223-225).
+#include "coevo_common.hip.h"
+
+namespace coevo {
+
+// fixed-order block reduction of one double per thread (256 threads): xor tree inside each wave, waves left to right
+__device__ inline double block_sum_f64(double v, double *scratch)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = v + __shfl_xor(v, m, 64);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) scratch[w] = v;
+    __syncthreads();
+    const double tot = ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3];
+    __syncthreads();
+    return tot;
+}
+
+// dist[i] = || w_i - w_ref ||_2 over the Linear weights and biases only (get_weights_ES default layers,
+// MPE/fcnetwork.py:161: fc1, fc2, output).  One workgroup per population member; squares accumulate in fp64 so the
+// fp32 result does not depend on the summation order.
+__global__ __launch_bounds__(256) void fc_distance_kernel(const float *ref_net, const float *pop_slab, int D,
+                                                           float *dist)
+{
+    __shared__ double scratch[4];
+    const int64_t stride = fc_stride(D), P = fc_params(D);
+    const int64_t g1 = fc_off_b1(D) + H1, g2 = fc_off_b2(D) + H2;
+    const float *wi = pop_slab + (int64_t)blockIdx.x * stride;
+    double acc = 0.0;
+    for (int64_t s0 = (int64_t)threadIdx.x * 4; s0 < stride; s0 += 1024) {
+        const float4 a = *reinterpret_cast<const float4 *>(wi + s0);
+        const float4 b = *reinterpret_cast<const float4 *>(ref_net + s0);
+        const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int64_t s = s0 + c;
+            const bool ln = (s >= g1 && s < g1 + 2 * H1) || (s >= g2 && s < g2 + 2 * H2);
+            if (s < P && !ln) {
+                const float d = av[c] - bv[c];
+                acc += (double)d * (double)d;
+            }
+        }
+    }
+    const double tot = block_sum_f64(acc, scratch);
+    if (threadIdx.x == 0) dist[blockIdx.x] = (float)sqrt(tot);
+}
+
+// score = sum_i max(0, 1 - d_i / mean(d)), mean rounded to fp32 as np.mean of an fp32 array is
+__global__ __launch_bounds__(256) void sharing_score_kernel(const float *dist, int n, float *score)
+{
+    __shared__ double scratch[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)dist[i];
+    const float sigma = (float)(block_sum_f64(s, scratch) / (double)n);
+    double sc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float sh = 1.0f - dist[i] / sigma;
+        if (sh > 0.0f) sc += (double)sh;
+    }
+    const double tot = block_sum_f64(sc, scratch);
+    if (threadIdx.x == 0) *score = (float)tot;
+}
+
+// quirk Q2: the reward variable is overwritten by every HoF game, only the LAST one (k = hof-1) survives; it is
+// still divided by hof_size and by (1 + diversity).  numpy >= 2 evaluates python_float / np.float32 in float32.
+__global__ void ga_fitness_kernel(const double *rewards, int game_first, int pop, int hof, int slot,
+                                  const float *diversity, float *fitness)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pop) return;
+    const double last = rewards[3 * (size_t)(game_first + i * hof + hof - 1) + slot];
+    const float total = (float)(last / (double)hof);
+    fitness[i] = total / (1.0f + *diversity);
+}
+
+// order = argsort(fitness)[::-1] with a stable ascending sort (ties: higher index first after the reversal);
+// NaN sorts last in ascending order like numpy.  Rank counting, n <= 4096, one workgroup.
+__device__ inline bool rank_less(float a, int ia, float b, int ib)
+{
+    const bool an = __builtin_isnan(a), bn = __builtin_isnan(b);
+    if (an || bn) return (!an && bn) || (an && bn && ia < ib);
+    return (a < b) || (a == b && ia < ib);
+}
+
+__global__ __launch_bounds__(256) void rank_desc_kernel(const float *fitness, int n, int32_t *order)
+{
+    __shared__ float f[4096];
+    for (int i = threadIdx.x; i < n; i += 256) f[i] = fitness[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float fi = f[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += rank_less(f[j], j, fi, i) ? 1 : 0;
+        order[n - 1 - rank] = i;
+    }
+}
+
+}  // namespace coevo
+
+using namespace coevo;
+
+extern "C" int coevo_fc_diversity(const float *ref_net, const float *pop_slab, int n, int D, float *dist,
+                                  float *score, void *stream)
+{
+    if (!ref_net || !pop_slab || !dist || !score || n <= 0 || (D != 8 && D != 10)) return COEVO_ERR_ARG;
+    hipLaunchKernelGGL(fc_distance_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, ref_net, pop_slab, D, dist);
+    hipLaunchKernelGGL(sharing_score_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dist, n, score);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_sharing_score(const float *dist, int n, float *score, void *stream)
+{
+    if (!dist || !score || n <= 0) return COEVO_ERR_ARG;
+    hipLaunchKernelGGL(sharing_score_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, dist, n, score);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_ga_fitness(const double *rewards, int game_first, int pop, int hof, int slot,
+                                const float *diversity, float *fitness, void *stream)
+{
+    if (!rewards || !diversity || !fitness || pop <= 0 || hof <= 0 || slot < 0 || slot > 2 || game_first < 0)
+        return COEVO_ERR_ARG;
+    hipLaunchKernelGGL(ga_fitness_kernel, dim3((pop + 127) / 128), dim3(128), 0, (hipStream_t)stream, rewards,
+                       game_first, pop, hof, slot, diversity, fitness);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_rank_desc(const float *fitness, int n, int32_t *order, void *stream)
+{
+    if (!fitness || !order || n <= 0 || n > 4096) return COEVO_ERR_ARG;
+    hipLaunchKernelGGL(rank_desc_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, fitness, n, order);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_version(void) { return COEVO_VERSION; }

@@ -1,0 +1,133 @@
+"""ctypes binding of libcoevo.so (the C ABI in include/coevo.h).
+
+PyTorch-ROCm is only plumbing here: tensors give device memory (``data_ptr()``) and streams.  There is NO CPU or
+eager fallback: if the HIP library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcoevo.so")
+
+OBS_STRIDE = 12
+LOGIT_STRIDE = 8
+FC_MAX_ROWS = 32
+MPE_STATE_DOUBLES = 24
+ST_NAMES = {1: "input contains inf or NaN", 2: "output contains inf or NaN after fc1",
+            4: "output contains inf or NaN after fc2", 8: "output contains inf or NaN",
+            16: "no action selected (current_best_position = -1)"}
+
+# numpy view of coevo_fc_task
+TASK_DTYPE = np.dtype([("net_off", "<i8"), ("row_begin", "<i4"), ("n_rows", "<i4"), ("D", "<i4"),
+                       ("reserved", "<i4")])
+
+
+class PCG64State(C.Structure):
+    _fields_ = [("state_hi", C.c_uint64), ("state_lo", C.c_uint64), ("inc_hi", C.c_uint64), ("inc_lo", C.c_uint64)]
+
+    @classmethod
+    def from_seed(cls, seed):
+        st = np.random.PCG64(seed).state["state"]
+        m = (1 << 64) - 1
+        return cls(st["state"] >> 64, st["state"] & m, st["inc"] >> 64, st["inc"] & m)
+
+
+class CoevoError(RuntimeError):
+    pass
+
+
+_lib = None
+_SIGS = {
+    "coevo_version": (C.c_int, []),
+    "coevo_fc_param_count": (C.c_int64, [C.c_int]),
+    "coevo_fc_slab_stride": (C.c_int64, [C.c_int]),
+    "coevo_fc_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "coevo_fc_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "coevo_fc_forward_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+    "coevo_mpe_reset": (C.c_int, [C.c_void_p, C.c_int, PCG64State, C.c_uint64, C.c_void_p]),
+    "coevo_mpe_observe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "coevo_mpe_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                 C.c_void_p]),
+    "coevo_mpe_rewards": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "coevo_mpe_policy_cycle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "coevo_fc_perturb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]),
+    "coevo_fc_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "coevo_es_update": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_uint64,
+                                  C.c_uint32, C.c_uint32, C.c_void_p]),
+    "coevo_fc_diversity": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "coevo_sharing_score": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "coevo_ga_fitness": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
+    "coevo_rank_desc": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+}
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def load():
+    """dlopen libcoevo.so; raises CoevoError when it has not been built (python -m coevonet_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CoevoError(f"{LIB_PATH} is missing: build the HIP extension first "
+                             "(python -m coevonet_amd.build); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise CoevoError(f"{what} failed with code {rc} "
+                         f"({'bad argument' if rc == -1 else 'HIP runtime error' if rc == -2 else 'unknown'})")
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    _check(getattr(load(), name)(*args, _stream()), name)
+
+
+def raise_on_status(status_tensor):
+    """Turn COEVO_ST_* bits into the ValueError the reference raises (MPE/fcnetwork.py:39-65,87)."""
+    st = int(status_tensor.item())
+    if st:
+        msgs = [m for b, m in ST_NAMES.items() if st & b]
+        raise ValueError("\n\t Warning: " + "; ".join(msgs))
+
+
+def fc_param_count(D):
+    return int(load().coevo_fc_param_count(D))
+
+
+def fc_slab_stride(D):
+    return int(load().coevo_fc_slab_stride(D))
+
+
+def tasks_to_device(tasks_np, device="cuda"):
+    """numpy structured array (TASK_DTYPE) -> device byte tensor usable as coevo_fc_task*"""
+    assert tasks_np.dtype == TASK_DTYPE
+    return torch.from_numpy(tasks_np.view(np.uint8).copy()).to(device)

@@ -1,0 +1,154 @@
+/*
+ * coevo.h - C ABI of libcoevo.so, the MI355X (gfx950) population-evaluation engine.
+ *
+ * The reference (CogSP/CoEvoNet) is pure Python and has no FFI; its boundary for this hot path is the Python
+ * surface initialize_env / create_agent / play_game / Agent / FCNetwork / DeepQN.  This header is
+ * what a binding for that surface binds instead of torch-CPU ops: every entry point names the reference code whose
+ * arithmetic it replaces (file:line under the reference checkout).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a DEVICE pointer owned by the caller unless named host_*;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous on it, allocate
+ *     nothing, keep no global state and are re-entrant per stream (graph-capturable);
+ *   - return value: COEVO_OK or a negative COEVO_ERR_* (argument errors are detected on the host before launch);
+ *   - numerical faults the reference raises ValueError for (NaN/inf in the forward, no action) are OR-ed into a
+ *     caller-provided device status word as COEVO_ST_* bits; the host facade turns them into ValueError;
+ *   - fp32 arithmetic follows the canonical order documented in DESIGN.md (sequential-k fmaf chains, fixed
+ *     reduction trees), fp64 for the MPE physics and rewards.
+ */
+#ifndef COEVO_H
+#define COEVO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COEVO_VERSION 100
+
+#define COEVO_OK 0
+#define COEVO_ERR_ARG (-1)   /* bad size / null pointer / unsupported shape */
+#define COEVO_ERR_HIP (-2)   /* a HIP runtime call failed (hipGetLastError has the detail) */
+
+/* device status word bits (MPE/fcnetwork.py:39,49,57,65,87; utils/game_logic_functions.py:172-177) */
+#define COEVO_ST_BAD_INPUT 1
+#define COEVO_ST_BAD_FC1 2
+#define COEVO_ST_BAD_FC2 4
+#define COEVO_ST_BAD_OUT 8
+#define COEVO_ST_NO_ACTION 16
+
+/* FCNetwork geometry (MPE/fcnetwork.py:14-22) */
+#define COEVO_FC_H1 512
+#define COEVO_FC_H2 256
+#define COEVO_FC_NACT 5
+#define COEVO_OBS_STRIDE 12      /* floats per observation row in obs buffers (D = 8 or 10, zero padded) */
+#define COEVO_LOGIT_STRIDE 8     /* floats per logits row */
+#define COEVO_FC_MAX_ROWS 32     /* rows (observations) one task may carry */
+
+/* env slots, PettingZoo agent order of simple_adversary_v3 */
+#define COEVO_SLOT_ADVERSARY 0
+#define COEVO_SLOT_AGENT_0 1
+#define COEVO_SLOT_AGENT_1 2
+
+int coevo_version(void);
+
+/* ---------------------------------------------------------------- weight slab ------------------------------ */
+/* Canonical flat order = torch parameters() order of FCNetwork (fc1.w, fc1.b, ln1.w, ln1.b, fc2.w, fc2.b, ln2.w,
+ * ln2.b, output.w, output.b): what Agent.mutate walks (agent.py:27) and state_dict() holds.  The device slab
+ * re-tiles fc1.w / fc2.w for coalesced streaming (DESIGN.md "HBM layout"). */
+int64_t coevo_fc_param_count(int D);   /* 139781 (D=10) / 138757 (D=8) */
+int64_t coevo_fc_slab_stride(int D);   /* floats between consecutive nets in a slab */
+/* flat[n][P] <-> slab[n][stride]; replaces state_dict()/load_state_dict() copies (MPE/mpe_agent.py:24-28) */
+int coevo_fc_pack(const float *flat, float *slab, int n, int D, void *stream);
+int coevo_fc_unpack(const float *slab, float *flat, int n, int D, void *stream);
+
+/* ---------------------------------------------------------------- K1: policy step -------------------------- */
+/* One task = one weight set applied to n_rows observations (rows row_begin .. row_begin+n_rows-1).  The rows of
+ * one task are the env copies that share that net in this env-cycle (an individual's HoF games; a HoF member's
+ * games against the whole population). */
+typedef struct {
+    int64_t net_off;   /* float offset of the net inside the slab */
+    int32_t row_begin;
+    int32_t n_rows;    /* 1 .. COEVO_FC_MAX_ROWS */
+    int32_t D;         /* 8 or 10 */
+    int32_t reserved;
+} coevo_fc_task;
+
+/* FCNetwork.forward + determine_action (MPE/fcnetwork.py:37-90) for every row of every task, one launch.
+ *   obs      [rows][COEVO_OBS_STRIDE] fp32          actions [rows] int32 (first index of the maximum logit)
+ *   logits   [rows][COEVO_LOGIT_STRIDE] or NULL     status  one int32, COEVO_ST_* bits OR-ed in
+ * max_rows_per_task: upper bound of n_rows over the tasks (selects the 8- or 32-row kernel). */
+int coevo_fc_forward_argmax(const float *slab, const coevo_fc_task *tasks, int n_tasks, int max_rows_per_task,
+                            const float *obs, int32_t *actions, float *logits, int32_t *status, void *stream);
+
+/* ---------------------------------------------------------------- device-side MPE simple_adversary ---------- */
+/* Replaces env.reset/observe/step/last of play_MPE (utils/game_logic_functions.py:123-212, :217) for E env
+ * copies at once.  State is struct-of-arrays, fp64, E-strided: see coevo_mpe_state_doubles(). */
+#define COEVO_MPE_STATE_DOUBLES 24   /* per game: ppos[6] pvel[6] lm[4] goal_pos[2] rg_prev acc[3] spare[2] */
+typedef struct {
+    uint64_t pcg_state_hi, pcg_state_lo, pcg_inc_hi, pcg_inc_lo;  /* numpy PCG64(seed).state */
+} coevo_pcg64;
+
+/* games g = 0..n-1 take reset ordinal first_ordinal+g of the single seeded stream (quirk Q6; ordinal 0 is the
+ * reset inside initialize_env, utils/game_logic_functions.py:54). state = [COEVO_MPE_STATE_DOUBLES][n] fp64. */
+int coevo_mpe_reset(double *state, int n_games, coevo_pcg64 rng, uint64_t first_ordinal, void *stream);
+/* obs rows for (game, slot) pairs: row r observes game row_game[r] as slot row_slot[r] (float32 casts of fp64
+ * differences, PettingZoo SimpleEnv.observe). */
+int coevo_mpe_observe(const double *state, int n_games, const int32_t *row_game, const int32_t *row_slot,
+                      int n_rows, float *obs, void *stream);
+/* One world cycle for every game: the three acting rows' actions are read through game_rows[g][3] (row index per
+ * slot), physics advanced, rewards credited with the reference's attribution (quirk Q1) honouring the per-game
+ * agent-step limit: cycle c credits adversary_0/agent_0 with the good reward of world step c and agent_1 with the
+ * adversary reward of world step c+1, each only while 3c+slot < limit.  pos_first = PettingZoo >= 1.24 order. */
+int coevo_mpe_step(double *state, int n_games, const int32_t *game_rows, const int32_t *actions, int cycle,
+                   const int32_t *game_limit, int pos_first, void *stream);
+/* play_game() return triples (agent_0, agent_1, adversary_0) -> rewards[n][3] fp64 */
+int coevo_mpe_rewards(const double *state, int n_games, double *rewards, void *stream);
+
+/* fused env-cycle: observe + policy step for all tasks (rows address (game,slot) pairs) in one launch */
+int coevo_mpe_policy_cycle(const float *slab, const coevo_fc_task *tasks, int n_tasks, int max_rows_per_task,
+                           const double *state, int n_games, const int32_t *row_game, const int32_t *row_slot,
+                           int32_t *actions, int32_t *status, void *stream);
+
+/* ---------------------------------------------------------------- K3/K4/K8: offspring on device ------------- */
+/* child = parent + sigma * eps(seed, stream, p), p = canonical flat index; Philox4x32-10 + Box-Muller with
+ * fmaf-only polynomials (bit-reproducible against the oracle).  Replaces clone()+Agent.mutate (agent.py:25-29,
+ * genetic_algorithm.py:32-48) and Agent.mutate_ES (agent.py:51-53).
+ *   parent_slab/child_slab: slabs in device layout; parent_idx[c] = net index of child c's parent in parent_slab
+ *   (device array, so elite ids chosen on device never visit the host); child c is written at net index
+ *   child_first + c; its noise stream is (stream_lo = stream_lo_first + c, stream_hi).
+ *   skip_layernorm != 0 leaves LayerNorm affine untouched (ES, MPE/fcnetwork.py:185-199). */
+int coevo_fc_perturb(const float *parent_slab, const int32_t *parent_idx, float *child_slab, int child_first,
+                     int n_children, int D, const float *sigma_dev, uint64_t seed, uint32_t stream_lo_first,
+                     uint32_t stream_hi, int skip_layernorm, void *stream);
+/* net copies inside/between slabs driven by device-resident indices: dst[dst_first+i] = src[src_idx[i]] */
+int coevo_fc_gather(const float *src_slab, const int32_t *src_idx, float *dst_slab, int dst_first, int n, int D,
+                    void *stream);
+
+/* K5: theta += lr/(n*sigma) * sum_i fitness[i] * (sigma*eps_i), noise regenerated from the streams used by
+ * coevo_fc_perturb (evolutionary_strategy.py:120-148).  theta is ONE net in slab layout. */
+int coevo_es_update(float *theta_slab_net, int D, const float *fitness, int n, const float *sigma_dev, float lr,
+                    uint64_t seed, uint32_t stream_lo_first, uint32_t stream_hi, void *stream);
+
+/* ---------------------------------------------------------------- K6/K7: fitness, sharing, selection -------- */
+/* distances d[i] = || w_i - w_ref ||_2 over the Linear weights/biases (get_weights_ES default layers) and the
+ * sharing score sum_i max(0, 1 - d_i/mean(d)) (utils/game_logic_functions.py:12-37). ref_net is one net in slab
+ * layout, pop_slab holds n nets.  dist [n] fp32, score one fp32. */
+int coevo_fc_diversity(const float *ref_net, const float *pop_slab, int n, int D, float *dist, float *score,
+                       void *stream);
+/* the score alone from n distances (used when the distances were all-gathered from several GPUs) */
+int coevo_sharing_score(const float *dist, int n, float *score, void *stream);
+/* GA fitness of one role phase (genetic_algorithm.py:140-146, quirk Q2: only the LAST HoF game counts):
+ * fitness[i] = float(rewards[(game_first + i*hof + hof-1)][slot] / hof) / (1 + *diversity)   (float32, as numpy>=2
+ * evaluates python_float / np.float32) */
+int coevo_ga_fitness(const double *rewards, int game_first, int pop, int hof, int slot, const float *diversity,
+                     float *fitness, void *stream);
+/* order = np.argsort(fitness)[::-1] (genetic_algorithm.py:223-225; stable ascending sort reversed, so ties put the
+ * HIGHER index first, quirk Q13).  n <= 4096. */
+int coevo_rank_desc(const float *fitness, int n, int32_t *order, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COEVO_H */

@@ -1,0 +1,34 @@
+"""The C-ABI library loads and exports every symbol include/coevo.h declares (no compute: runs without a GPU)."""
+import ctypes
+import os
+import re
+
+from coevonet_amd import lib as L
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, "include", "coevo.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(coevo_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from coevonet_amd.build import build
+    build()
+    dll = ctypes.CDLL(L.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(dll, n), f"{n} declared in include/coevo.h but not exported"
+    assert sorted(L.exported_symbols()) == names, "lib.py binds a different set than the header declares"
+
+
+def test_version_and_layout_constants():
+    dll = L.load()
+    assert dll.coevo_version() == 100
+    # parameter counts of the reference's FCNetwork (139 781 good / 138 757 adversary)
+    assert L.fc_param_count(10) == 139781 and L.fc_param_count(8) == 138757
+    assert L.fc_slab_stride(10) % 64 == 0 and L.fc_slab_stride(10) >= 139781
+    assert L.fc_param_count(9) < 0  # unsupported width is an argument error, not a crash

@@ -1,0 +1,333 @@
+"""HIP kernels (through the C ABI) against the CPU oracle on the same seeded inputs.  Bit-exact unless stated."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from coevonet_amd import lib as L
+from oracle import ref_port as rp
+from tests.util import SAFE_MARGIN, load_golden, sha
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def make_nets(n, D, seed, mutate=True):
+    torch.manual_seed(seed)
+    nets = []
+    for _ in range(n):
+        w = rp.init_net(D)
+        if mutate:
+            w = rp.mutate_torch(w, D, 0.05)
+        nets.append(w)
+    return np.stack(nets)
+
+
+def to_slab(flat_np, D):
+    n = flat_np.shape[0]
+    flat = torch.from_numpy(flat_np).to(DEV)
+    slab = torch.zeros(n, L.fc_slab_stride(D), dtype=torch.float32, device=DEV)
+    L.call("coevo_fc_pack", L._p(flat), L._p(slab), n, D)
+    return slab
+
+
+def test_pack_unpack_roundtrip():
+    for D in (8, 10):
+        flat = make_nets(3, D, seed=D)
+        slab = to_slab(flat, D)
+        back = torch.zeros(3, L.fc_param_count(D), dtype=torch.float32, device=DEV)
+        L.call("coevo_fc_unpack", L._p(slab), L._p(back), 3, D)
+        assert np.array_equal(back.cpu().numpy(), flat)
+        # spot-check the tiling: W2q[jb][kq][l][c] == fc2.w[64jb+l][4kq+c]
+        s = slab[1].cpu().numpy()
+        o_w2 = D * 512 + 1536
+        w2 = flat[1][o_w2:o_w2 + 256 * 512].reshape(256, 512)
+        tile = s[o_w2:o_w2 + 256 * 512].reshape(4, 128, 64, 4)
+        assert tile[2, 17, 5, 3] == w2[2 * 64 + 5, 17 * 4 + 3]
+        w1 = flat[1][:512 * D].reshape(512, D)
+        assert s[3 * 512 + 77] == w1[77, 3]
+
+
+@pytest.mark.parametrize("D,rows_per_task", [(10, [5, 5, 1, 8, 3]), (8, [5, 2, 8]), (10, [16, 9, 12]),
+                                             (8, [32, 17, 1, 29])])
+def test_fc_forward_bit_exact_vs_oracle(D, rows_per_task):
+    n_tasks = len(rows_per_task)
+    flat = make_nets(n_tasks, D, seed=41 + D + len(rows_per_task))
+    slab = to_slab(flat, D)
+    rows = sum(rows_per_task)
+    g = np.random.Generator(np.random.PCG64(5))
+    obs = np.zeros((rows, L.OBS_STRIDE), dtype=np.float32)
+    obs[:, :D] = g.uniform(-2, 2, size=(rows, D)).astype(np.float32)
+    tasks = np.zeros(n_tasks, dtype=L.TASK_DTYPE)
+    r0 = 0
+    for t, n in enumerate(rows_per_task):
+        tasks[t] = ((n_tasks - 1 - t) * L.fc_slab_stride(D), r0, n, D, 0)  # nets used in reverse order
+        r0 += n
+    d_tasks = L.tasks_to_device(tasks)
+    d_obs = torch.from_numpy(obs).to(DEV)
+    actions = torch.full((rows,), -7, dtype=torch.int32, device=DEV)
+    logits = torch.zeros(rows, L.LOGIT_STRIDE, dtype=torch.float32, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    L.call("coevo_fc_forward_argmax", L._p(slab), L._p(d_tasks), n_tasks, max(rows_per_task), L._p(d_obs),
+           L._p(actions), L._p(logits), L._p(status))
+    assert status.item() == 0
+    got_a, got_l = actions.cpu().numpy(), logits.cpu().numpy()
+    r0 = 0
+    for t, n in enumerate(rows_per_task):
+        w = flat[n_tasks - 1 - t]
+        for r in range(r0, r0 + n):
+            a, lg, st = rp.fc_forward(w, D, obs[r, :D])
+            assert st == 0
+            assert np.array_equal(got_l[r, :5].view(np.uint32), lg.view(np.uint32)), (t, r, got_l[r, :5], lg)
+            assert got_a[r] == a
+        r0 += n
+
+
+def test_fc_forward_golden_vectors():
+    """HIP forward against logits the reference's own FCNetwork produced (fixture), tolerance = fp32
+    summation-order noise of a 512-term dot product; action must agree where the margin is safe."""
+    for case in load_golden("fc_forward.json")["cases"]:
+        torch.manual_seed(case["torch_seed"])
+        D = case["D"]
+        w = rp.init_net(D)
+        if case["mutated"]:
+            w = rp.mutate_torch(w, D, 0.05)
+        assert sha(w) == case["weights"]["sha256"]
+        slab = to_slab(w[None], D)
+        obs_in = np.array(case["obs"], dtype=np.float32)
+        rows = obs_in.shape[0]
+        obs = np.zeros((rows, L.OBS_STRIDE), dtype=np.float32)
+        obs[:, :D] = obs_in
+        tasks = np.zeros(1, dtype=L.TASK_DTYPE)
+        tasks[0] = (0, 0, rows, D, 0)
+        actions = torch.zeros(rows, dtype=torch.int32, device=DEV)
+        logits = torch.zeros(rows, L.LOGIT_STRIDE, dtype=torch.float32, device=DEV)
+        status = torch.zeros(1, dtype=torch.int32, device=DEV)
+        d_tasks, d_obs = L.tasks_to_device(tasks), torch.from_numpy(obs).to(DEV)  # keep alive across the launch
+        L.call("coevo_fc_forward_argmax", L._p(slab), L._p(d_tasks), 1, rows, L._p(d_obs), L._p(actions),
+               L._p(logits), L._p(status))
+        ref = np.array(case["logits"], dtype=np.float32)
+        np.testing.assert_allclose(logits.cpu().numpy()[:, :5], ref, rtol=2e-5, atol=2e-6)
+        for r in range(rows):
+            srt = np.sort(ref[r])[::-1]
+            if srt[0] - srt[1] > SAFE_MARGIN:
+                assert actions[r].item() == case["actions"][r]
+
+
+def test_fc_forward_status_bits():
+    D = 10
+    flat = make_nets(1, D, seed=3)
+    flat[0, 5] = np.nan  # a NaN weight in fc1 poisons LayerNorm -> "after fc1" in the reference
+    slab = to_slab(flat, D)
+    obs = torch.zeros(2, L.OBS_STRIDE, dtype=torch.float32, device=DEV)
+    tasks = np.zeros(1, dtype=L.TASK_DTYPE)
+    tasks[0] = (0, 0, 2, D, 0)
+    actions = torch.zeros(2, dtype=torch.int32, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    d_tasks = L.tasks_to_device(tasks)
+    L.call("coevo_fc_forward_argmax", L._p(slab), L._p(d_tasks), 1, 2, L._p(obs), L._p(actions), None, L._p(status))
+    assert status.item() & 2
+    with pytest.raises(ValueError):
+        L.raise_on_status(status)
+    # inf observation -> "input contains inf or NaN"
+    flat = make_nets(1, D, seed=3)
+    slab = to_slab(flat, D)
+    obs[1, 2] = float("inf")
+    status.zero_()
+    L.call("coevo_fc_forward_argmax", L._p(slab), L._p(d_tasks), 1, 2, L._p(obs), L._p(actions), None, L._p(status))
+    assert status.item() & 1
+
+
+# ----------------------------------------------------------------------------------- MPE env
+def test_mpe_reset_matches_numpy_stream():
+    from coevonet_amd.mpe.simple_adversary import ResetStream
+    n, first = 301, 1
+    st = torch.zeros(L.MPE_STATE_DOUBLES, n, dtype=torch.float64, device=DEV)
+    L.call("coevo_mpe_reset", L._p(st), n, L.PCG64State.from_seed(1870300), first)
+    goal, apos, lpos = ResetStream().take(n)
+    s = st.cpu().numpy()
+    assert np.array_equal(s[0:6].T.reshape(n, 3, 2), apos)
+    assert np.array_equal(s[12:16].T.reshape(n, 2, 2), lpos)
+    assert np.array_equal(s[22].astype(np.int32), goal)
+    assert np.array_equal(s[16:18].T, lpos[np.arange(n), goal])
+    assert not s[6:12].any() and not s[18:22].any()
+    # a shard that starts at an odd/even ordinal deep in the stream sees the same values
+    st2 = torch.zeros(L.MPE_STATE_DOUBLES, 40, dtype=torch.float64, device=DEV)
+    for first2 in (200, 257):
+        L.call("coevo_mpe_reset", L._p(st2), 40, L.PCG64State.from_seed(1870300), first2)
+        assert np.array_equal(st2.cpu().numpy()[:18], s[:18, first2 - 1:first2 - 1 + 40])
+
+
+@pytest.mark.parametrize("limit,cycles", [(None, 25), (50, 17), (7, 3), (200, 67)])
+def test_mpe_step_observe_match_host_env(limit, cycles):
+    from coevonet_amd.mpe.simple_adversary import ResetStream, VecSimpleAdversary
+    n = 130
+    st = torch.zeros(L.MPE_STATE_DOUBLES, n, dtype=torch.float64, device=DEV)
+    L.call("coevo_mpe_reset", L._p(st), n, L.PCG64State.from_seed(1870300), 1)
+    env = VecSimpleAdversary(*ResetStream().take(n))
+    row_game = torch.arange(n, dtype=torch.int32, device=DEV).repeat_interleave(3).contiguous()
+    row_slot = torch.tensor([0, 1, 2], dtype=torch.int32, device=DEV).repeat(n).contiguous()
+    game_rows = torch.arange(3 * n, dtype=torch.int32, device=DEV)
+    lim = None if limit is None else torch.full((n,), limit, dtype=torch.int32, device=DEV)
+    obs = torch.zeros(3 * n, L.OBS_STRIDE, dtype=torch.float32, device=DEV)
+    g = np.random.Generator(np.random.PCG64(9))
+    acc = np.zeros((n, 3))  # adv, a0, a1 slots
+    rg_prev = np.zeros(n)
+    T = 10 ** 9 if limit is None else limit
+    for c in range(cycles):
+        L.call("coevo_mpe_observe", L._p(st), n, L._p(row_game), L._p(row_slot), 3 * n, L._p(obs))
+        o = obs.cpu().numpy().reshape(n, 3, L.OBS_STRIDE)
+        adv, a0, a1 = env.observe()
+        assert np.array_equal(o[:, 0, :8], adv) and np.array_equal(o[:, 1, :10], a0) and np.array_equal(o[:, 2, :10], a1)
+        acts = g.integers(0, 5, size=(n, 3)).astype(np.int32)
+        d_act = torch.from_numpy(acts.reshape(-1)).to(DEV)
+        L.call("coevo_mpe_step", L._p(st), n, L._p(game_rows), L._p(d_act), c, L._p(lim), 1)
+        # host model of the AEC credit rule
+        if 3 * c < T:
+            acc[:, 0] += rg_prev
+        if 3 * c + 1 < T:
+            acc[:, 1] += rg_prev
+        if 3 * c + 2 < T:
+            rg, ra = env.step(acts)
+            acc[:, 2] += ra
+            rg_prev = rg
+    rew = torch.zeros(n, 3, dtype=torch.float64, device=DEV)
+    L.call("coevo_mpe_rewards", L._p(st), n, L._p(rew))
+    r = rew.cpu().numpy()
+    assert np.array_equal(r[:, 0], acc[:, 1]) and np.array_equal(r[:, 1], acc[:, 2]) and np.array_equal(r[:, 2], acc[:, 0])
+
+
+@pytest.mark.parametrize("limit,max_cycles", [(None, 25), (50, 25), (200, 70), (7, 25)])
+def test_device_rollout_matches_oracle_play_game(limit, max_cycles):
+    """Whole games on the device (fused observe+policy launch, then step) == oracle play_game, bit for bit."""
+    n_games = 12
+    nets10 = make_nets(2 * n_games, 10, seed=77, mutate=False)
+    nets8 = make_nets(n_games, 8, seed=78, mutate=False)
+    s10, s8 = L.fc_slab_stride(10), L.fc_slab_stride(8)
+    slab = torch.cat([to_slab(nets10, 10).reshape(-1), to_slab(nets8, 8).reshape(-1)]).contiguous()
+    off8 = 2 * n_games * s10
+    # rows: game g -> rows 3g (adv), 3g+1 (a0), 3g+2 (a1); one task per row (R=1 tasks)
+    tasks = np.zeros(3 * n_games, dtype=L.TASK_DTYPE)
+    for g in range(n_games):
+        tasks[3 * g] = (off8 + g * s8, 3 * g, 1, 8, 0)
+        tasks[3 * g + 1] = (g * s10, 3 * g + 1, 1, 10, 0)
+        tasks[3 * g + 2] = ((n_games + g) * s10, 3 * g + 2, 1, 10, 0)
+    d_tasks = L.tasks_to_device(tasks)
+    row_game = torch.arange(n_games, dtype=torch.int32, device=DEV).repeat_interleave(3).contiguous()
+    row_slot = torch.tensor([0, 1, 2], dtype=torch.int32, device=DEV).repeat(n_games).contiguous()
+    game_rows = torch.arange(3 * n_games, dtype=torch.int32, device=DEV)
+    st = torch.zeros(L.MPE_STATE_DOUBLES, n_games, dtype=torch.float64, device=DEV)
+    first = 5
+    L.call("coevo_mpe_reset", L._p(st), n_games, L.PCG64State.from_seed(1870300), first)
+    actions = torch.zeros(3 * n_games, dtype=torch.int32, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    T = 3 * max_cycles if limit is None else min(limit, 3 * max_cycles)
+    lim = torch.full((n_games,), T, dtype=torch.int32, device=DEV)
+    for c in range((T + 2) // 3):
+        L.call("coevo_mpe_policy_cycle", L._p(slab), L._p(d_tasks), 3 * n_games, 1, L._p(st), n_games,
+               L._p(row_game), L._p(row_slot), L._p(actions), L._p(status))
+        L.call("coevo_mpe_step", L._p(st), n_games, L._p(game_rows), L._p(actions), c, L._p(lim), 1)
+    assert status.item() == 0
+    rew = torch.zeros(n_games, 3, dtype=torch.float64, device=DEV)
+    L.call("coevo_mpe_rewards", L._p(st), n_games, L._p(rew))
+    r = rew.cpu().numpy()
+    stream = rp.Stream()
+    for g in range(n_games):
+        want = rp.play_game(stream, nets10[g], nets10[n_games + g], nets8[g], limit, max_cycles, ordinal=first + g)
+        assert want["steps"] == T
+        assert list(r[g]) == want["rewards"], (g, r[g], want["rewards"])
+
+
+# ----------------------------------------------------------------------------------- offspring
+@pytest.mark.parametrize("D,skip_ln", [(10, 0), (8, 1)])
+def test_perturb_bit_exact_vs_oracle(D, skip_ln):
+    P = L.fc_param_count(D)
+    parents = make_nets(3, D, seed=11)
+    slab = to_slab(parents, D)
+    n_children = 5
+    pidx = np.array([2, 0, 1, 2, 0], dtype=np.int32)
+    child = torch.zeros(1 + n_children, L.fc_slab_stride(D), dtype=torch.float32, device=DEV)
+    sigma = torch.tensor([0.05], dtype=torch.float32, device=DEV)
+    seed, slo, shi = 0x1234567890ABCDEF, 1000, 7
+    d_pidx = torch.from_numpy(pidx).to(DEV)
+    L.call("coevo_fc_perturb", L._p(slab), L._p(d_pidx), L._p(child), 1, n_children, D,
+           L._p(sigma), seed, slo, shi, skip_ln)
+    back = torch.zeros(1 + n_children, P, dtype=torch.float32, device=DEV)
+    L.call("coevo_fc_unpack", L._p(child), L._p(back), 1 + n_children, D)
+    got = back.cpu().numpy()
+    segs = rp.ln_segments(D) if skip_ln else []
+    so = np.array([s[0] for s in segs], dtype=np.int32)
+    sl = np.array([s[1] for s in segs], dtype=np.int32)
+    for c in range(n_children):
+        want = np.zeros(P, dtype=np.float32)
+        rp.lib().oracle_perturb_philox(rp._fp(parents[pidx[c]]), rp._fp(want), P, C.c_float(0.05), seed, slo + c, shi,
+                                       rp._ip(so), rp._ip(sl), len(segs))
+        assert np.array_equal(got[1 + c].view(np.uint32), want.view(np.uint32)), c
+    noise = got[1] - parents[2]
+    if not skip_ln:
+        assert abs(noise.mean()) < 1e-3 and abs(noise.std() - 0.05) < 1e-3  # it is N(0, sigma)
+    assert not got[0].any()  # slot 0 untouched
+
+
+def test_es_update_bit_exact_vs_oracle():
+    D, n = 8, 37
+    P = L.fc_param_count(D)
+    theta = make_nets(1, D, seed=21)
+    slab = to_slab(theta, D)
+    g = np.random.Generator(np.random.PCG64(4))
+    fit = g.normal(size=n).astype(np.float32)
+    sigma, lr, seed, slo, shi = np.float32(0.05), np.float32(0.1), 99, 0, 3
+    d_fit, d_sigma = torch.from_numpy(fit).to(DEV), torch.tensor([sigma], device=DEV)
+    L.call("coevo_es_update", L._p(slab), D, L._p(d_fit), n, L._p(d_sigma), C.c_float(lr), seed, slo, shi)
+    back = torch.zeros(1, P, dtype=torch.float32, device=DEV)
+    L.call("coevo_fc_unpack", L._p(slab), L._p(back), 1, D)
+    want = theta[0].copy()
+    segs = rp.ln_segments(D)
+    so = np.array([s[0] for s in segs], dtype=np.int32)
+    sl = np.array([s[1] for s in segs], dtype=np.int32)
+    scale = np.float32(lr / (np.float32(n) * sigma))
+    rp.lib().oracle_es_update_philox(rp._fp(want), P, rp._fp(fit), n, C.c_float(sigma), C.c_float(scale), seed, shi,
+                                     rp._ip(so), rp._ip(sl), len(segs))
+    assert np.array_equal(back.cpu().numpy()[0].view(np.uint32), want.view(np.uint32))
+
+
+# ----------------------------------------------------------------------------------- selection
+def test_diversity_fitness_rank():
+    D, n = 10, 23
+    pop = make_nets(n, D, seed=31)
+    ref = pop[n - 1].copy()
+    slab = to_slab(pop, D)
+    ref_slab = to_slab(ref[None], D)
+    dist = torch.zeros(n, dtype=torch.float32, device=DEV)
+    score = torch.zeros(1, dtype=torch.float32, device=DEV)
+    L.call("coevo_fc_diversity", L._p(ref_slab), L._p(slab), n, D, L._p(dist), L._p(score))
+    segs = rp.linear_segments(D)
+    so = np.array([s[0] for s in segs], dtype=np.int32)
+    sl = np.array([s[1] for s in segs], dtype=np.int32)
+    want_d = np.zeros(n, dtype=np.float32)
+    rp.lib().oracle_diversity.restype = C.c_double
+    want_s = rp.lib().oracle_diversity(rp._fp(ref), rp._fp(pop), n, pop.shape[1], rp._ip(so), rp._ip(sl), len(segs),
+                                       rp._fp(want_d))
+    np.testing.assert_allclose(dist.cpu().numpy(), want_d, rtol=1.2e-7)  # <= 1 ulp: fp64 sums, rounded once
+    np.testing.assert_allclose(score.item(), want_s, rtol=1e-6)
+    # the reference's own numpy expression
+    np.testing.assert_allclose(score.item(), rp.diversity(rp.weights_es(ref, D), [rp.weights_es(w, D) for w in pop]),
+                               rtol=1e-5)
+    # GA fitness (quirk Q2) + ranking
+    popn, hof = 9, 3
+    g = np.random.Generator(np.random.PCG64(8))
+    rewards = g.normal(size=(40, 3)) * 10
+    d_rew = torch.from_numpy(rewards).to(DEV)
+    fit = torch.zeros(popn, dtype=torch.float32, device=DEV)
+    L.call("coevo_ga_fitness", L._p(d_rew), 4, popn, hof, 1, L._p(score), L._p(fit))
+    div = np.float32(score.item())
+    want = [np.float32(rewards[4 + i * hof + hof - 1, 1] / hof) / (1 + div) for i in range(popn)]
+    assert np.array_equal(fit.cpu().numpy(), np.array(want, dtype=np.float32))
+    f = g.normal(size=200).astype(np.float32)
+    f[17] = f[3]
+    f[150] = f[3]  # ties
+    order = torch.zeros(200, dtype=torch.int32, device=DEV)
+    d_f = torch.from_numpy(f).to(DEV)
+    L.call("coevo_rank_desc", L._p(d_f), 200, L._p(order))
+    assert np.array_equal(order.cpu().numpy(), np.argsort(f, kind="stable")[::-1])
