@@ -52,11 +52,13 @@ __device__ inline u128 pcg_advance(u128 state, u128 inc, uint64_t delta)
 // numpy Generator semantics of one PettingZoo reset: choice(2) = one buffered 32-bit draw (the low half of a
 // 64-bit output for even ordinals, the kept high half for odd ones; Lemire range 2 => top bit), then ten
 // uniform(-1,1) doubles.  Two resets consume 21 raw 64-bit outputs.
-__global__ void mpe_reset_kernel(double *st, int n, coevo_pcg64 rng, uint64_t first_ordinal)
+__global__ void mpe_reset_kernel(double *st, int n, int game_first, int count, coevo_pcg64 rng,
+                                 uint64_t first_ordinal)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n) return;
-    const uint64_t ordinal = first_ordinal + (uint64_t)g;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int g = game_first + i;
+    const uint64_t ordinal = first_ordinal + (uint64_t)i;
     const u128 inc = ((u128)rng.pcg_inc_hi << 64) | rng.pcg_inc_lo;
     u128 s = ((u128)rng.pcg_state_hi << 64) | rng.pcg_state_lo;
     s = pcg_advance(s, inc, (ordinal >> 1) * 21);
@@ -164,11 +166,13 @@ __global__ void mpe_rewards_kernel(const double *st, int n, double *rewards)
 
 }  // namespace coevo
 
-extern "C" int coevo_mpe_reset(double *state, int n_games, coevo_pcg64 rng, uint64_t first_ordinal, void *stream)
+extern "C" int coevo_mpe_reset(double *state, int n_games, int game_first, int count, coevo_pcg64 rng,
+                               uint64_t first_ordinal, void *stream)
 {
-    if (!state || n_games <= 0) return COEVO_ERR_ARG;
-    hipLaunchKernelGGL(coevo::mpe_reset_kernel, dim3((n_games + 127) / 128), dim3(128), 0, (hipStream_t)stream,
-                       state, n_games, rng, first_ordinal);
+    if (!state || n_games <= 0 || game_first < 0 || count < 0 || game_first + count > n_games) return COEVO_ERR_ARG;
+    if (count == 0) return COEVO_OK;
+    hipLaunchKernelGGL(coevo::mpe_reset_kernel, dim3((count + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                       state, n_games, game_first, count, rng, first_ordinal);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

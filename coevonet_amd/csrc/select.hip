@@ -67,12 +67,13 @@ __global__ __launch_bounds__(256) void sharing_score_kernel(const float *dist, i
 
 // quirk Q2: the reward variable is overwritten by every HoF game, only the LAST one (k = hof-1) survives; it is
 // still divided by hof_size and by (1 + diversity).  numpy >= 2 evaluates python_float / np.float32 in float32.
-__global__ void ga_fitness_kernel(const double *rewards, int game_first, int pop, int hof, int slot,
-                                  const float *diversity, float *fitness)
+__global__ void ga_fitness_kernel(const double *rewards, int game_first, int pop, int games_per_individual,
+                                  int hof, int slot, const float *diversity, float *fitness)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= pop) return;
-    const double last = rewards[3 * (size_t)(game_first + i * hof + hof - 1) + slot];
+    const int gpi = games_per_individual;
+    const double last = rewards[3 * (size_t)(game_first + i * gpi + gpi - 1) + slot];
     const float total = (float)(last / (double)hof);
     fitness[i] = total / (1.0f + *diversity);
 }
@@ -113,6 +114,14 @@ extern "C" int coevo_fc_diversity(const float *ref_net, const float *pop_slab, i
     return COEVO_OK;
 }
 
+extern "C" int coevo_fc_distance(const float *ref_net, const float *pop_slab, int n, int D, float *dist, void *stream)
+{
+    if (!ref_net || !pop_slab || !dist || n <= 0 || (D != 8 && D != 10)) return COEVO_ERR_ARG;
+    hipLaunchKernelGGL(fc_distance_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, ref_net, pop_slab, D, dist);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
 extern "C" int coevo_sharing_score(const float *dist, int n, float *score, void *stream)
 {
     if (!dist || !score || n <= 0) return COEVO_ERR_ARG;
@@ -121,13 +130,14 @@ extern "C" int coevo_sharing_score(const float *dist, int n, float *score, void 
     return COEVO_OK;
 }
 
-extern "C" int coevo_ga_fitness(const double *rewards, int game_first, int pop, int hof, int slot,
-                                const float *diversity, float *fitness, void *stream)
+extern "C" int coevo_ga_fitness(const double *rewards, int game_first, int pop, int games_per_individual, int hof,
+                                int slot, const float *diversity, float *fitness, void *stream)
 {
-    if (!rewards || !diversity || !fitness || pop <= 0 || hof <= 0 || slot < 0 || slot > 2 || game_first < 0)
+    if (!rewards || !diversity || !fitness || pop <= 0 || hof <= 0 || games_per_individual <= 0 || slot < 0 ||
+        slot > 2 || game_first < 0)
         return COEVO_ERR_ARG;
     hipLaunchKernelGGL(ga_fitness_kernel, dim3((pop + 127) / 128), dim3(128), 0, (hipStream_t)stream, rewards,
-                       game_first, pop, hof, slot, diversity, fitness);
+                       game_first, pop, games_per_individual, hof, slot, diversity, fitness);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

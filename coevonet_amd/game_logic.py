@@ -1,0 +1,110 @@
+"""Drop-in surface of the reference's utils/game_logic_functions.py: ``initialize_env``, ``create_agent``,
+``preprocess_observation``, ``play_game``, ``diversity_penalty`` - same names, arguments and errors.
+
+``play_game`` keeps the reference's contract (one env.reset(), one AEC episode, returns the three accumulated rewards
+with the reference's attribution).  With this package's own env object the whole episode runs on the GPU in one
+batch-of-one rollout; with any other AEC env (e.g. a real PettingZoo one) it walks the AEC loop and only the policy
+forward runs on the GPU.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .agent import MPEAgent
+from .mpe.simple_adversary import ENV_SEED, SimpleAdversaryAEC
+from .rollout import DeviceRollout, RolloutPlan, effective_steps
+
+
+def initialize_env(args):
+    """utils/game_logic_functions.py:41-55 - build the env and do the ONE seeded reset."""
+    if args.game == "simple_adversary_v3":
+        env = SimpleAdversaryAEC(render_mode="human" if getattr(args, "render", False) else None)
+    else:
+        raise ValueError(f"Unsupported game type: {args.game} (the Atari emulator is not part of this build; "
+                         "only the DeepQN policy kernel is, see coevonet_amd.deepqn)")
+    env.reset(seed=ENV_SEED)
+    return env
+
+
+def create_agent(env, args, role=None):
+    if args.game == "simple_adversary_v3":
+        return MPEAgent(env, args, role)
+    raise ValueError(f"Unsupported game type: {args.game}")
+
+
+def preprocess_observation(obs, args):
+    obs = torch.from_numpy(obs)
+    if args.precision == "float16":
+        raise ValueError("Unsupported precision: float16")
+    return obs.to(torch.float32)
+
+
+def diversity_penalty(individual_weights, population_weights, args, sigma=None):
+    """fitness-sharing niche count (utils/game_logic_functions.py:12-37) for host-resident weight vectors; the trainers
+    use the device kernel coevo_fc_diversity instead."""
+    distances = np.array([np.linalg.norm(ind - individual_weights) for ind in population_weights])
+    if sigma is None:
+        sigma = np.mean(distances)
+    return np.sum(np.maximum(0, 1 - distances / sigma))
+
+
+def _play_mpe_aec(env, player1, player2, adversary, args, eval):
+    """play_MPE (:123-212) over a foreign AEC env; forwards on the GPU one step at a time."""
+    rewards = {"agent_0": 0, "agent_1": 0, "adversary_0": 0}
+    models = {"agent_0": player1, "agent_1": player2, "adversary_0": adversary}
+    timesteps = 0
+    limit = args.max_evaluation_steps if eval else args.max_timesteps_per_episode
+    for agent in env.agent_iter():
+        if agent not in models:
+            raise ValueError(f"Unknown Agent during play_game: {agent}")
+        obs = preprocess_observation(env.observe(agent), args)
+        action = models[agent].determine_action(obs, args)
+        if action > 4:
+            raise ValueError(f"ERROR: the action {action} is greater than 4")
+        env.step(action)
+        _, reward, termination, truncation, _ = env.last()
+        rewards[agent] += reward
+        timesteps += 1
+        if limit is not None and timesteps >= limit:
+            break
+        if termination or truncation:
+            break
+    return rewards["agent_0"], rewards["agent_1"], rewards["adversary_0"]
+
+
+def _play_mpe_device(env, player1, player2, adversary, args, eval):
+    """one whole episode on the device; the env object only supplies the game's ordinal in the seeded stream"""
+    dev = "cuda"
+    ordinal = env.n_resets - 1  # the reset play_game just performed
+    s10, s8 = L.fc_slab_stride(10), L.fc_slab_stride(8)
+    slab = torch.zeros(2 * s10 + s8, dtype=torch.float32, device=dev)
+    for model, off, D in ((player1, 0, 10), (player2, s10, 10), (adversary, 2 * s10, 8)):
+        flat = torch.from_numpy(np.ascontiguousarray(model.flat())).to(dev)
+        L.call("coevo_fc_pack", L._p(flat), slab.data_ptr() + 4 * off, 1, D)
+    plan = RolloutPlan(np.array([[2, 0, 1]]), [0, s10, 2 * s10], [10, 10, 8], device=dev)
+    ro = DeviceRollout(plan, slab, env_seed=env.seed_value)
+    limit = args.max_evaluation_steps if eval else args.max_timesteps_per_episode
+    T = effective_steps(limit, env.max_cycles)
+    ro.set_limits([T])
+    ro.reset(0, 1, ordinal)
+    ro.run((T + 2) // 3)
+    ro.check_status()
+    r = ro.rewards.cpu().numpy()[0]
+    return float(r[0]), float(r[1]), float(r[2])
+
+
+def play_game(env, player1, player2, adversary=None, args=None, eval=False):
+    """utils/game_logic_functions.py:215-228"""
+    env.reset()
+    if args.game == "simple_adversary_v3":
+        if adversary is None:
+            raise ValueError("adversary not specified")
+        from .fcnetwork import FCNetwork
+        ours = isinstance(env, SimpleAdversaryAEC) and env.seed_value is not None and \
+            all(isinstance(m, FCNetwork) for m in (player1, player2, adversary))
+        if ours:
+            return _play_mpe_device(env, player1, player2, adversary, args, eval)
+        return _play_mpe_aec(env, player1, player2, adversary, args, eval)
+    raise ValueError(f"Unsupported game type: {args.game}")

@@ -1,0 +1,372 @@
+"""Co-GA on the MI355X: drop-in ``genetic_algorithm_train(env, agent, args, output_dir)`` (reference
+genetic_algorithm.py:51) over a batched engine.
+
+Per generation the reference plays 3*pop*hof + 10 sequential games; here all of them advance together on the device
+(coevonet_amd.rollout), fitness / sharing / ranking / HoF update / offspring stay on the device, and the only host
+round trip is the 10-game evaluation result that drives the adaptive mutation power.
+
+reference_exact semantics kept: Q1 reward attribution (device step kernel), Q2 only the last
+HoF game counts, Q3 diversity against the stale agent left over from the init loop, always applied, Q4 the adversary
+phase takes both good opponents from hof_agent_0, Q5 agent_0's sigma increase uses agent_1's sigma, Q6 single seeded
+reset stream addressed by game ordinal, Q7 placeholder elites only burn RNG, Q8 GA mutates LayerNorm affine, Q13
+argsort()[::-1].
+
+rng modes
+  "host_reference"  nets are initialised and mutated on the host with the very torch calls the reference makes, in its
+                    order (bit-comparable elites; used for parity) and uploaded;
+  "device_philox"   offspring are built on the device from counter-based noise (performance mode); initial nets still
+                    come from torch's default init.
+
+The 10 evaluation games of generation g depend only on g's selection, and nothing before the end of generation g+1
+depends on them (they feed the sigma used by g+1's mutation), so they ride along in generation g+1's rollout launch
+instead of costing a second sequential rollout; the last generation's evaluation is flushed on its own.
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .agent import MPEAgent
+from .fcnetwork import FCNetwork
+from .game_logic import create_agent
+from .mpe.simple_adversary import ENV_SEED
+from .rollout import DeviceRollout, HostEnvRollout, RolloutPlan, effective_steps
+
+ROLES = ("agent_0", "agent_1", "adversary_0")
+ROLE_D = {"agent_0": 10, "agent_1": 10, "adversary_0": 8}
+ROLE_SLOT = {"agent_0": 1, "agent_1": 2, "adversary_0": 0}   # env slot the role acts in
+RET_SLOT = {"agent_0": 0, "agent_1": 1, "adversary_0": 2}    # position in play_game's return triple
+SIGMA_ATTR = {"agent_0": "mutation_power_agent_0", "agent_1": "mutation_power_agent_1",
+              "adversary_0": "mutation_power_adversary"}
+N_EVAL = 10
+
+
+def adapt_mutation_power(args, gen, hist):
+    """genetic_algorithm.py:323-345 (evolutionary_strategy.py:292-316 is identical), quirk Q5 included."""
+    def worse(h):
+        return gen > 10 and np.mean(h[-10:]) < np.mean(h[-20:-10])
+    if worse(hist["agent_0"]):
+        args.mutation_power_agent_0 = min(args.mutation_power_agent_1 * 1.2, args.max_mutation_power)
+    else:
+        args.mutation_power_agent_0 = max(args.mutation_power_agent_0 * 0.95, args.min_mutation_power)
+    if worse(hist["agent_1"]):
+        args.mutation_power_agent_1 = min(args.mutation_power_agent_1 * 1.2, args.max_mutation_power)
+    else:
+        args.mutation_power_agent_1 = max(args.mutation_power_agent_1 * 0.95, args.min_mutation_power)
+    if worse(hist["adversary_0"]):
+        args.mutation_power_adversary = min(args.mutation_power_adversary * 1.2, args.max_mutation_power)
+    else:
+        args.mutation_power_adversary = max(args.mutation_power_adversary * 0.95, args.min_mutation_power)
+
+
+class GAEngine:
+    """Device-resident population / HoF / elites of the three roles and the per-generation pipeline.
+
+    shard = (rank, world): this process evaluates individuals [lo, hi) of every role (contiguous ranges, all HoF games
+    of an individual on the same GPU); fitness and distances are all-gathered by the caller-provided ``gather``."""
+
+    def __init__(self, pop, hof, elites, limit_train=None, limit_eval=None, max_cycles=25, device="cuda",
+                 env_seed=ENV_SEED, rng="device_philox", philox_seed=0, env="device", first_ordinal=1,
+                 shard=(0, 1), gather=None):
+        assert 1 <= elites <= pop and hof >= 1
+        self.pop, self.hof, self.E = pop, hof, elites
+        self.rng_mode, self.philox_seed, self.env_mode = rng, int(philox_seed), env
+        self.device = device
+        self.rank, self.world = shard
+        self.gather = gather
+        self.lo = self.rank * pop // self.world
+        self.hi = (self.rank + 1) * pop // self.world
+        self.n_local = self.hi - self.lo
+        self.T_train = effective_steps(limit_train, max_cycles)
+        self.T_eval = effective_steps(limit_eval, max_cycles)
+        self.n_cycles = (max(self.T_train, self.T_eval) + 2) // 3
+        self.first_ordinal = first_ordinal
+        self.env_seed = env_seed
+        # ---- slab layout: per role [pop | hof | elite | stale | hof_tmp] -----------------------------------
+        self.stride = {r: L.fc_slab_stride(ROLE_D[r]) for r in ROLES}
+        self.P = {r: L.fc_param_count(ROLE_D[r]) for r in ROLES}
+        self.base, off = {}, 0
+        for r in ROLES:
+            self.base[r] = {}
+            for region, count in (("pop", pop), ("hof", hof), ("elite", elites), ("stale", 1), ("hof_tmp", hof)):
+                self.base[r][region] = off
+                off += count * self.stride[r]
+        self.slab = torch.zeros(off, dtype=torch.float32, device=device)
+        # ---- game table of one generation launch -----------------------------------------------------------
+        net_off, net_D, ids = [], [], {}
+
+        def net(region, role, i):
+            key = (region, role, i)
+            if key not in ids:
+                ids[key] = len(net_off)
+                net_off.append(self.base[role][region] + i * self.stride[role])
+                net_D.append(ROLE_D[role])
+            return ids[key]
+
+        games = []
+        h = hof
+        for role in ROLES:
+            for i in range(self.lo, self.hi):
+                for k in range(h):
+                    if role == "agent_0":      # genetic_algorithm.py:136-142
+                        a0, a1, adv = net("pop", role, i), net("hof", "agent_1", h - 1 - k), net("hof", "adversary_0", h - 1 - k)
+                    elif role == "agent_1":    # :168-174
+                        a0, a1, adv = net("hof", "agent_0", h - 1 - k), net("pop", role, i), net("hof", "adversary_0", h - 1 - k)
+                    else:                      # :201-207, Q4: agent_1's seat is also filled from hof_agent_0
+                        a0, a1, adv = net("hof", "agent_0", h - 1 - k), net("hof", "agent_0", h - 1 - k), net("pop", role, i)
+                    games.append((adv, a0, a1))
+        self.n_main = len(games)
+        for _ in range(N_EVAL):  # evaluate_current_weights(best trio) = newest HoF members (:12-29, :301)
+            games.append((net("hof", "adversary_0", h - 1), net("hof", "agent_0", h - 1), net("hof", "agent_1", h - 1)))
+        self.plan = RolloutPlan(np.array(games), net_off, net_D, device=device)
+        cls = DeviceRollout if env == "device" else HostEnvRollout
+        self.ro = cls(self.plan, self.slab, env_seed=env_seed)
+        # ---- small device buffers ---------------------------------------------------------------------------
+        f32 = dict(dtype=torch.float32, device=device)
+        self.dist = {r: torch.zeros(pop, **f32) for r in ROLES}
+        self.div = {r: torch.zeros(1, **f32) for r in ROLES}
+        self.fitness = {r: torch.zeros(pop, **f32) for r in ROLES}
+        self.order = {r: torch.zeros(pop, dtype=torch.int32, device=device) for r in ROLES}
+        self.sigma = {r: torch.zeros(1, **f32) for r in ROLES}
+        self.last_reward = torch.zeros(3, pop, 3, dtype=torch.float64, device=device)  # [role][i][triple]
+        self.parent_idx = torch.tensor([c % elites for c in range(max(pop - 1, 1))], dtype=torch.int32, device=device)
+        self.hof_shift_idx = torch.arange(1, max(hof, 2), dtype=torch.int32, device=device)
+        self.iota = torch.arange(max(hof, elites, 2), dtype=torch.int32, device=device)
+        self.generation = 0
+        self.steps_per_generation = 3 * pop * hof * self.T_train + N_EVAL * self.T_eval
+
+    # ------------------------------------------------------------------ loading weights
+    def _ptr(self, role, region, i=0):
+        return self.slab.data_ptr() + 4 * (self.base[role][region] + i * self.stride[role])
+
+    def upload(self, role, region, first, flat_np):
+        """flat_np [n][P] (parameters() order) -> nets first.. of a region"""
+        flat = torch.from_numpy(np.ascontiguousarray(flat_np, dtype=np.float32)).to(self.device)
+        L.call("coevo_fc_pack", L._p(flat), self._ptr(role, region, first), flat.shape[0], ROLE_D[role])
+        return flat  # keep alive until the stream has consumed it
+
+    def download(self, role, region, first, n):
+        out = torch.zeros(n, self.P[role], dtype=torch.float32, device=self.device)
+        L.call("coevo_fc_unpack", self._ptr(role, region, first), L._p(out), n, ROLE_D[role])
+        return out.cpu().numpy()
+
+    def load_initial(self, pop_flat, hof_flat):
+        """pop_flat[role] [pop][P], hof_flat[role] [hof][P]; the stale agent of Q3 is the initial pop[pop-1]"""
+        keep = []
+        for r in ROLES:
+            keep.append(self.upload(r, "pop", 0, pop_flat[r]))
+            keep.append(self.upload(r, "hof", 0, hof_flat[r]))
+            keep.append(self.upload(r, "stale", 0, pop_flat[r][self.pop - 1:self.pop]))
+        torch.cuda.current_stream().synchronize()
+
+    # ------------------------------------------------------------------ one generation
+    def _ordinal_base(self, gen):
+        return self.first_ordinal + gen * (3 * self.pop * self.hof + N_EVAL)
+
+    def rollout(self, gen, with_prev_eval):
+        """plays generation `gen`'s 3*n_local*hof games and, riding along, the 10 evaluation games of gen-1"""
+        ro, M = self.ro, 3 * self.pop * self.hof
+        limits = np.zeros(self.plan.n_games, dtype=np.int32)
+        limits[:self.n_main] = self.T_train
+        if with_prev_eval:
+            limits[self.n_main:] = self.T_eval
+        ro.set_limits(limits)
+        base = self._ordinal_base(gen)
+        per_phase = self.n_local * self.hof
+        if self.env_mode == "device":
+            for ph in range(3):
+                ro.reset(ph * per_phase, per_phase, base + ph * self.pop * self.hof + self.lo * self.hof)
+            if with_prev_eval:
+                ro.reset(self.n_main, N_EVAL, self._ordinal_base(gen - 1) + M)
+        else:
+            ords = np.zeros(self.plan.n_games, dtype=np.int64)
+            for ph in range(3):
+                ords[ph * per_phase:(ph + 1) * per_phase] = (base + ph * self.pop * self.hof + self.lo * self.hof
+                                                             + np.arange(per_phase))
+            ords[self.n_main:] = (self._ordinal_base(gen - 1) + M + np.arange(N_EVAL)) if with_prev_eval else 0
+            ro.reset_from_ordinals(ords)
+        ro.run(self.n_cycles)
+
+    def eval_only(self, gen):
+        """flush: the evaluation games of generation `gen` alone (main games disabled)"""
+        ro, M = self.ro, 3 * self.pop * self.hof
+        limits = np.zeros(self.plan.n_games, dtype=np.int32)
+        limits[self.n_main:] = self.T_eval
+        ro.set_limits(limits)
+        if self.env_mode == "device":
+            ro.reset(0, self.n_main, 0)
+            ro.reset(self.n_main, N_EVAL, self._ordinal_base(gen) + M)
+        else:
+            ords = np.zeros(self.plan.n_games, dtype=np.int64)
+            ords[self.n_main:] = self._ordinal_base(gen) + M + np.arange(N_EVAL)
+            ro.reset_from_ordinals(ords)
+        ro.run((self.T_eval + 2) // 3)
+        return self.eval_rewards()
+
+    def rewards_host(self):
+        r = self.ro.rewards
+        return r.cpu().numpy() if torch.is_tensor(r) else r
+
+    def eval_rewards(self):
+        """mean reward triple (agent_0, agent_1, adversary_0) of the 10 evaluation games in the last rollout"""
+        self.ro.check_status()
+        r = self.rewards_host()[self.n_main:]
+        tot = [0.0, 0.0, 0.0]
+        for g in range(N_EVAL):  # python-float accumulation order of evaluate_current_weights
+            for s in range(3):
+                tot[s] += float(r[g, s])
+        return [t / 10 for t in tot]
+
+    def select(self):
+        """fitness sharing + fitness + ranking of all three roles on the device -> elite ids stay on the device"""
+        dev_rewards = self.ro.rewards if torch.is_tensor(self.ro.rewards) else \
+            torch.from_numpy(self.ro.rewards).to(self.device)
+        per_phase = self.n_local * self.hof
+        for ph, r in enumerate(ROLES):
+            D = ROLE_D[r]
+            # distances of the local shard to the stale agent (Q3), scores need every rank's distances
+            L.call("coevo_fc_distance", self._ptr(r, "stale"), self._ptr(r, "pop", self.lo), self.n_local, D,
+                   self.dist[r].data_ptr() + 4 * self.lo)
+            # last HoF game of every local individual (Q2)
+            idx = ph * per_phase + torch.arange(self.n_local, device=self.device) * self.hof + self.hof - 1
+            self.last_reward[ph, self.lo:self.hi] = dev_rewards[idx]
+        if self.world > 1:
+            self.gather(self)  # all-gather of dist[role][lo:hi] and last_reward[:, lo:hi]
+        for ph, r in enumerate(ROLES):
+            L.call("coevo_sharing_score", L._p(self.dist[r]), self.pop, L._p(self.div[r]))
+            L.call("coevo_ga_fitness", self.last_reward[ph].data_ptr(), 0, self.pop, 1, self.hof, RET_SLOT[r],
+                   L._p(self.div[r]), L._p(self.fitness[r]))
+            L.call("coevo_rank_desc", L._p(self.fitness[r]), self.pop, L._p(self.order[r]))
+
+    def breed_device(self, gen, sigmas):
+        """elites -> elite buffer, HoF FIFO, population := [best] + (pop-1) mutated clones, all on the device"""
+        for ri, r in enumerate(ROLES):
+            D = ROLE_D[r]
+            self.sigma[r].fill_(float(sigmas[r]))
+            L.call("coevo_fc_gather", self._ptr(r, "pop"), L._p(self.order[r]), self._ptr(r, "elite"), 0, self.E, D)
+            self._hof_push(r)
+            L.call("coevo_fc_gather", self._ptr(r, "elite"), L._p(self.iota), self._ptr(r, "pop"), 0, 1, D)
+            if self.pop > 1:
+                L.call("coevo_fc_perturb", self._ptr(r, "elite"), L._p(self.parent_idx), self._ptr(r, "pop"), 1,
+                       self.pop - 1, D, L._p(self.sigma[r]), self.philox_seed, 0, gen * 4 + ri, 0)
+
+    def _hof_push(self, r):
+        """hof.append(best); hof.pop(0)  (genetic_algorithm.py:270-275)"""
+        D = ROLE_D[r]
+        if self.hof > 1:
+            L.call("coevo_fc_gather", self._ptr(r, "hof"), L._p(self.hof_shift_idx), self._ptr(r, "hof_tmp"), 0,
+                   self.hof - 1, D)
+            L.call("coevo_fc_gather", self._ptr(r, "hof_tmp"), L._p(self.iota), self._ptr(r, "hof"), 0,
+                   self.hof - 1, D)
+        L.call("coevo_fc_gather", self._ptr(r, "elite"), L._p(self.iota), self._ptr(r, "hof"), self.hof - 1, 1, D)
+
+    def breed_host_reference(self, env, args, sigmas):
+        """mutate_elites as the reference runs it (genetic_algorithm.py:32-48): per role, per child a fresh net is
+        constructed (burning the torch generator) and torch.normal noise is added to every parameter."""
+        keep = []
+        for r in ROLES:
+            D = ROLE_D[r]
+            L.call("coevo_fc_gather", self._ptr(r, "pop"), L._p(self.order[r]), self._ptr(r, "elite"), 0, self.E, D)
+            self._hof_push(r)
+            L.call("coevo_fc_gather", self._ptr(r, "elite"), L._p(self.iota), self._ptr(r, "pop"), 0, 1, D)
+        elite_flat = {r: self.download(r, "elite", 0, self.E) for r in ROLES}
+        for r in ROLES:
+            children = np.empty((self.pop - 1, self.P[r]), dtype=np.float32)
+            for i in range(self.pop - 1):
+                child = FCNetwork(ROLE_D[r], 5, "float32")          # clone(): fresh net first
+                child.set_flat(elite_flat[r][i % self.E])            # load_state_dict
+                for param in child.parameters():                     # Agent.mutate
+                    param.data += torch.normal(0, sigmas[r], size=param.size())
+                children[i] = child.flat()
+            if self.pop > 1:
+                keep.append(self.upload(r, "pop", 1, children))
+        torch.cuda.current_stream().synchronize()
+
+    def elite_ids(self):
+        return {r: self.order[r][:self.E].cpu().numpy().astype(int).tolist() for r in ROLES}
+
+
+# --------------------------------------------------------------------------------------------- trainer
+class GAResult:
+    """what the reference only plots: per-generation evaluation rewards, fitness, elite ids, sigma history"""
+
+    def __init__(self):
+        self.rewards = {r: [] for r in ROLES}
+        self.fitness, self.elite_ids, self.diversity, self.sigma_after = [], [], [], []
+        self.game_rewards = []   # per generation: play_game triples of the 3*pop*hof training games, reference order
+        self.seconds = []
+
+
+def initial_population(env, args):
+    """creation order of genetic_algorithm.py:63-68 and :110-117 (torch RNG order matters for parity)"""
+    hof_n, pop = args.hof_size, args.population
+    hof = {"agent_1": [create_agent(env, args, "agent_1") for _ in range(hof_n)]}
+    hof["agent_0"] = [create_agent(env, args, "agent_0") for _ in range(hof_n)]
+    hof["adversary_0"] = [create_agent(env, args, "adversary_0") for _ in range(hof_n)]
+    for role in ("agent_1", "agent_0", "adversary_0"):  # placeholder elites, overwritten in generation 0 (Q7)
+        for _ in range(hof_n):
+            create_agent(env, args, role)
+    popu = {r: [] for r in ROLES}
+    for _ in range(pop):
+        for r in ROLES:
+            popu[r].append(create_agent(env, args, r))
+    pop_flat = {r: np.stack([a.model.flat() for a in popu[r]]) for r in ROLES}
+    hof_flat = {r: np.stack([a.model.flat() for a in hof[r]]) for r in ROLES}
+    return pop_flat, hof_flat
+
+
+def genetic_algorithm_train(env, agent, args, output_dir, rng=None, env_mode=None, collect=True, dist_ctx=None):
+    """Drop-in for genetic_algorithm.py:51.  Returns a GAResult (the reference returns None and plots instead).
+
+    rng: "host_reference" (default when args has no `coevo_rng`) reproduces the reference's torch RNG stream;
+         "device_philox" builds offspring on the device."""
+    rng = rng or getattr(args, "coevo_rng", "host_reference")
+    env_mode = env_mode or getattr(args, "coevo_env", "device")
+    first_ordinal = getattr(env, "n_resets", 1)
+    pop_flat, hof_flat = initial_population(env, args)
+    shard, gather = (0, 1), None
+    if dist_ctx is not None:
+        shard, gather = (dist_ctx.rank, dist_ctx.world), dist_ctx.gather_ga
+    eng = GAEngine(args.population, args.hof_size, args.elites_number, args.max_timesteps_per_episode,
+                   args.max_evaluation_steps, max_cycles=getattr(env, "max_cycles", 25), rng=rng,
+                   philox_seed=getattr(args, "coevo_seed", 0), env=env_mode, first_ordinal=first_ordinal,
+                   env_seed=getattr(env, "seed_value", ENV_SEED) or ENV_SEED, shard=shard, gather=gather)
+    eng.load_initial(pop_flat, hof_flat)
+    res = GAResult()
+    gens = args.generations
+    for gen in range(gens):
+        t0 = time.perf_counter()
+        eng.rollout(gen, with_prev_eval=gen > 0)
+        if gen > 0:
+            _finish_generation(args, gen - 1, eng.eval_rewards(), res)
+        eng.select()
+        sigmas = {r: getattr(args, SIGMA_ATTR[r]) for r in ROLES}
+        if rng == "host_reference":
+            eng.breed_host_reference(env, args, sigmas)
+        else:
+            eng.breed_device(gen, sigmas)
+        if collect:
+            res.game_rewards.append(eng.rewards_host()[:eng.n_main].copy())
+            res.fitness.append([eng.fitness[r].cpu().numpy().tolist() for r in ROLES])
+            res.diversity.append([float(eng.div[r].item()) for r in ROLES])
+            res.elite_ids.append([eng.elite_ids()[r] for r in ROLES])
+        res.seconds.append(time.perf_counter() - t0)
+    if gens > 0:
+        _finish_generation(args, gens - 1, eng.eval_only(gens - 1), res)
+    # keep the env's reset counter where the reference's would be
+    if hasattr(env, "n_resets"):
+        env.n_resets = first_ordinal + gens * (3 * args.population * args.hof_size + N_EVAL)
+    res.engine = eng
+    return res
+
+
+def _finish_generation(args, gen, eval_triple, res):
+    for s, r in enumerate(ROLES):
+        res.rewards[r].append(eval_triple[s])
+    if args.adaptive:
+        adapt_mutation_power(args, gen, res.rewards)
+    res.sigma_after.append([args.mutation_power_agent_0, args.mutation_power_agent_1, args.mutation_power_adversary])

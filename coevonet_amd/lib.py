@@ -50,7 +50,7 @@ _SIGS = {
     "coevo_fc_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "coevo_fc_forward_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
-    "coevo_mpe_reset": (C.c_int, [C.c_void_p, C.c_int, PCG64State, C.c_uint64, C.c_void_p]),
+    "coevo_mpe_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, PCG64State, C.c_uint64, C.c_void_p]),
     "coevo_mpe_observe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "coevo_mpe_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                  C.c_void_p]),
@@ -63,8 +63,9 @@ _SIGS = {
     "coevo_es_update": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_uint64,
                                   C.c_uint32, C.c_uint32, C.c_void_p]),
     "coevo_fc_diversity": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "coevo_fc_distance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "coevo_sharing_score": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
-    "coevo_ga_fitness": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+    "coevo_ga_fitness": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
     "coevo_rank_desc": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
 }

@@ -107,6 +107,7 @@ class SimpleAdversaryAEC:
         self.agents = list(AGENTS)
         self._index_map = {a: i for i, a in enumerate(AGENTS)}
         self.np_random = np.random.Generator(np.random.PCG64())
+        self.seed_value = None  # seed of the stream the resets are drawn from (None = OS entropy)
         self.n_resets = 0
         self._obs_spaces = {a: _Box(OBS_DIM[a]) for a in AGENTS}
         self._act_spaces = {a: _Discrete(N_ACTIONS) for a in AGENTS}
@@ -137,6 +138,7 @@ class SimpleAdversaryAEC:
     def reset(self, seed=None, options=None):
         if seed is not None:
             self.np_random = np.random.Generator(np.random.PCG64(seed))
+            self.seed_value = seed
             self.n_resets = 0
         goal, apos, lpos = draw_reset(self.np_random)
         self.n_resets += 1

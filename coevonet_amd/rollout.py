@@ -1,0 +1,197 @@
+"""Batched rollout of many simple_adversary games on one MI355X.
+
+The reference plays its games one after another (play_game -> play_MPE, utils/game_logic_functions.py:123-228), one
+batch-1 forward per agent-step.  All games of a generation are independent given the generation's weights and each
+game's ordinal in the seeded reset stream, so they are flattened here into E env copies that advance in
+lock-step world cycles.  Per cycle: every distinct weight set that acts is read ONCE (a task = one net x the rows that
+share it), all three agents of a cycle observe the same world state, then one step kernel advances all games.
+
+``RolloutPlan``   static description of a batch: which net plays which slot of which game -> task/row tables on device
+``DeviceRollout`` env state + action buffers + the cycle loop, env on the device (fused observe+policy kernel)
+``HostEnvRollout`` the same plan with the env stepped on the host cores (north_star's first configuration)
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .mpe import simple_adversary as sa
+
+LIGHT_ROWS = 8      # tasks up to this many rows use the 8-row kernel
+HEAVY_ROWS = 32     # larger row sets are cut into chunks of this size
+
+
+class RolloutPlan:
+    """game_nets: int array [n_games][3] of net ids for env slots (adversary_0, agent_0, agent_1);
+    net_off / net_D: per net id, float offset inside the slab and observation width."""
+
+    def __init__(self, game_nets, net_off, net_D, device="cuda", heavy_rows=HEAVY_ROWS):
+        game_nets = np.asarray(game_nets, dtype=np.int64)
+        self.n_games = int(game_nets.shape[0])
+        by_net = {}
+        for g in range(self.n_games):
+            for slot in range(3):
+                by_net.setdefault(int(game_nets[g, slot]), []).append((g, slot))
+        light, heavy = [], []
+        for net, rows in by_net.items():
+            d = int(net_D[net])
+            for g, slot in rows:
+                assert d == (8 if slot == 0 else 10), "net width does not match the env slot it plays"
+            if len(rows) <= LIGHT_ROWS:
+                light.append((net, rows))
+            else:
+                for i in range(0, len(rows), heavy_rows):
+                    heavy.append((net, rows[i:i + heavy_rows]))
+        # heavy tasks first in row space; inside each class keep first-game order (locality of the state reads)
+        row_game, row_slot = [], []
+        tasks = {"heavy": [], "light": []}
+        for name, lst in (("heavy", heavy), ("light", light)):
+            for net, rows in lst:
+                tasks[name].append((int(net_off[net]), len(row_game), len(rows), int(net_D[net]), 0))
+                for g, slot in rows:
+                    row_game.append(g)
+                    row_slot.append(slot)
+        self.n_rows = len(row_game)
+        assert self.n_rows == 3 * self.n_games
+        game_rows = np.zeros((self.n_games, 3), dtype=np.int32)
+        for r, (g, slot) in enumerate(zip(row_game, row_slot)):
+            game_rows[g, slot] = r
+        self.row_game_np = np.asarray(row_game, dtype=np.int32)
+        self.row_slot_np = np.asarray(row_slot, dtype=np.int32)
+        self.game_rows_np = game_rows
+        self.heavy_np = np.array(tasks["heavy"], dtype=L.TASK_DTYPE) if tasks["heavy"] else np.zeros(0, L.TASK_DTYPE)
+        self.light_np = np.array(tasks["light"], dtype=L.TASK_DTYPE) if tasks["light"] else np.zeros(0, L.TASK_DTYPE)
+        self.heavy_max = int(max([t[2] for t in tasks["heavy"]], default=0))
+        self.light_max = int(max([t[2] for t in tasks["light"]], default=0))
+        self.device = device
+        if device is not None:
+            self.row_game = torch.from_numpy(self.row_game_np).to(device)
+            self.row_slot = torch.from_numpy(self.row_slot_np).to(device)
+            self.game_rows = torch.from_numpy(game_rows.reshape(-1).copy()).to(device)
+            self.heavy = L.tasks_to_device(self.heavy_np, device) if len(self.heavy_np) else None
+            self.light = L.tasks_to_device(self.light_np, device) if len(self.light_np) else None
+
+    def distinct_weight_bytes_per_cycle(self):
+        """algorithmic bytes of one env-cycle: every distinct weight set that acts, once."""
+        seen = {}
+        for arr in (self.heavy_np, self.light_np):
+            for t in arr:
+                seen[int(t["net_off"])] = L.fc_param_count(int(t["D"])) * 4
+        return sum(seen.values())
+
+
+def effective_steps(limit, max_cycles):
+    """agent-steps one game runs: play_MPE breaks at the step limit or when max_cycles world steps truncate it."""
+    cap = 3 * max_cycles
+    return cap if limit is None else min(int(limit), cap)
+
+
+class DeviceRollout:
+    """Env copies resident on the GPU; one fused observe+policy launch per task class and one step launch per cycle."""
+
+    def __init__(self, plan: RolloutPlan, slab: torch.Tensor, env_seed=sa.ENV_SEED):
+        self.plan = plan
+        self.slab = slab
+        dev = plan.device
+        n = plan.n_games
+        self.state = torch.zeros(L.MPE_STATE_DOUBLES, n, dtype=torch.float64, device=dev)
+        self.actions = torch.zeros(plan.n_rows, dtype=torch.int32, device=dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.limits = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.rewards = torch.zeros(n, 3, dtype=torch.float64, device=dev)
+        self.rng = L.PCG64State.from_seed(env_seed)
+        self.pos_first = 1 if sa.INTEGRATE_POS_FIRST else 0
+
+    def set_limits(self, limits_np):
+        self.limits.copy_(torch.from_numpy(np.asarray(limits_np, dtype=np.int32)), non_blocking=False)
+
+    def reset(self, game_first, n_games, first_ordinal):
+        """games [game_first, game_first+n_games) take reset ordinals first_ordinal.. of the seeded stream"""
+        L.call("coevo_mpe_reset", L._p(self.state), self.plan.n_games, int(game_first), int(n_games), self.rng,
+               int(first_ordinal))
+
+    def cycle(self, c):
+        p = self.plan
+        if p.heavy is not None:
+            L.call("coevo_mpe_policy_cycle", L._p(self.slab), L._p(p.heavy), len(p.heavy_np), p.heavy_max,
+                   L._p(self.state), p.n_games, L._p(p.row_game), L._p(p.row_slot), L._p(self.actions),
+                   L._p(self.status))
+        if p.light is not None:
+            L.call("coevo_mpe_policy_cycle", L._p(self.slab), L._p(p.light), len(p.light_np), p.light_max,
+                   L._p(self.state), p.n_games, L._p(p.row_game), L._p(p.row_slot), L._p(self.actions),
+                   L._p(self.status))
+        L.call("coevo_mpe_step", L._p(self.state), p.n_games, L._p(p.game_rows), L._p(self.actions), int(c),
+               L._p(self.limits), self.pos_first)
+
+    def run(self, n_cycles):
+        for c in range(n_cycles):
+            self.cycle(c)
+        L.call("coevo_mpe_rewards", L._p(self.state), self.plan.n_games, L._p(self.rewards))
+
+    def check_status(self):
+        L.raise_on_status(self.status)
+
+
+class HostEnvRollout:
+    """Same plan, env stepped on the host cores with NumPy (struct-of-arrays); per cycle the observations go up and
+    the actions come back over PCIe.  Results are bit-identical with DeviceRollout."""
+
+    def __init__(self, plan: RolloutPlan, slab: torch.Tensor, env_seed=sa.ENV_SEED):
+        self.plan = plan
+        self.slab = slab
+        dev = plan.device
+        self.obs_host = torch.zeros(plan.n_rows, L.OBS_STRIDE, dtype=torch.float32).pin_memory()
+        self.obs = torch.zeros(plan.n_rows, L.OBS_STRIDE, dtype=torch.float32, device=dev)
+        self.actions = torch.zeros(plan.n_rows, dtype=torch.int32, device=dev)
+        self.actions_host = torch.zeros(plan.n_rows, dtype=torch.int32).pin_memory()
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.env_seed = env_seed
+        self.limits = np.zeros(plan.n_games, dtype=np.int64)
+        self.rewards = None
+        self._streams = {}
+
+    def set_limits(self, limits_np):
+        self.limits = np.asarray(limits_np, dtype=np.int64)
+
+    def reset_from_ordinals(self, ordinals):
+        """ordinals[g] = reset ordinal of game g; draws every reset up to the largest one on the host."""
+        ordinals = np.asarray(ordinals, dtype=np.int64)
+        stream = sa.ResetStream(self.env_seed, skip_initial=False)
+        goal, apos, lpos = stream.take(int(ordinals.max()) + 1)
+        self.env = sa.VecSimpleAdversary(goal[ordinals], apos[ordinals], lpos[ordinals])
+        n = self.plan.n_games
+        self.acc = np.zeros((n, 3))
+        self.rg_prev = np.zeros(n)
+
+    def cycle(self, c):
+        p = self.plan
+        adv, a0, a1 = self.env.observe()
+        o = self.obs_host.numpy()
+        o[:] = 0.0
+        for slot, arr in ((0, adv), (1, a0), (2, a1)):
+            rows = p.game_rows_np[:, slot]
+            o[rows, :arr.shape[1]] = arr
+        self.obs.copy_(self.obs_host, non_blocking=True)
+        for tasks, tnp, mx in ((p.heavy, p.heavy_np, p.heavy_max), (p.light, p.light_np, p.light_max)):
+            if tasks is not None:
+                L.call("coevo_fc_forward_argmax", L._p(self.slab), L._p(tasks), len(tnp), mx, L._p(self.obs),
+                       L._p(self.actions), None, L._p(self.status))
+        self.actions_host.copy_(self.actions, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        acts = self.actions_host.numpy()[p.game_rows_np]  # [n_games, 3]
+        t0 = 3 * c
+        m0, m1, m2 = t0 < self.limits, t0 + 1 < self.limits, t0 + 2 < self.limits
+        self.acc[m0, 0] += self.rg_prev[m0]
+        self.acc[m1, 1] += self.rg_prev[m1]
+        rg, ra = self.env.step(acts)  # games past their limit are stepped too; their credits are masked
+        self.acc[m2, 2] += ra[m2]
+        self.rg_prev[m2] = rg[m2]
+
+    def run(self, n_cycles):
+        for c in range(n_cycles):
+            self.cycle(c)
+        self.rewards = np.stack([self.acc[:, 1], self.acc[:, 2], self.acc[:, 0]], axis=1)
+
+    def check_status(self):
+        L.raise_on_status(self.status)

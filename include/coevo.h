@@ -90,9 +90,11 @@ typedef struct {
     uint64_t pcg_state_hi, pcg_state_lo, pcg_inc_hi, pcg_inc_lo;  /* numpy PCG64(seed).state */
 } coevo_pcg64;
 
-/* games g = 0..n-1 take reset ordinal first_ordinal+g of the single seeded stream (quirk Q6; ordinal 0 is the
- * reset inside initialize_env, utils/game_logic_functions.py:54). state = [COEVO_MPE_STATE_DOUBLES][n] fp64. */
-int coevo_mpe_reset(double *state, int n_games, coevo_pcg64 rng, uint64_t first_ordinal, void *stream);
+/* state = [COEVO_MPE_STATE_DOUBLES][n_games] fp64.  Games game_first .. game_first+count-1 take reset ordinals
+ * first_ordinal .. of the single seeded stream (quirk Q6; ordinal 0 is the reset inside initialize_env,
+ * utils/game_logic_functions.py:54); each game jumps straight to its ordinal, so shards need no common prefix. */
+int coevo_mpe_reset(double *state, int n_games, int game_first, int count, coevo_pcg64 rng, uint64_t first_ordinal,
+                    void *stream);
 /* obs rows for (game, slot) pairs: row r observes game row_game[r] as slot row_slot[r] (float32 casts of fp64
  * differences, PettingZoo SimpleEnv.observe). */
 int coevo_mpe_observe(const double *state, int n_games, const int32_t *row_game, const int32_t *row_slot,
@@ -137,13 +139,16 @@ int coevo_es_update(float *theta_slab_net, int D, const float *fitness, int n, c
  * layout, pop_slab holds n nets.  dist [n] fp32, score one fp32. */
 int coevo_fc_diversity(const float *ref_net, const float *pop_slab, int n, int D, float *dist, float *score,
                        void *stream);
+/* the distances alone (the part each GPU computes for its population shard) */
+int coevo_fc_distance(const float *ref_net, const float *pop_slab, int n, int D, float *dist, void *stream);
 /* the score alone from n distances (used when the distances were all-gathered from several GPUs) */
 int coevo_sharing_score(const float *dist, int n, float *score, void *stream);
 /* GA fitness of one role phase (genetic_algorithm.py:140-146, quirk Q2: only the LAST HoF game counts):
- * fitness[i] = float(rewards[(game_first + i*hof + hof-1)][slot] / hof) / (1 + *diversity)   (float32, as numpy>=2
- * evaluates python_float / np.float32) */
-int coevo_ga_fitness(const double *rewards, int game_first, int pop, int hof, int slot, const float *diversity,
-                     float *fitness, void *stream);
+ * fitness[i] = float(rewards[game_first + i*gpi + gpi-1][slot] / hof) / (1 + *diversity), gpi = games_per_individual
+ * (= hof on a raw rewards table, 1 on a table that already holds each individual's last game); float32, as
+ * numpy >= 2 evaluates python_float / np.float32.  rewards = play_game triples [games][3] fp64. */
+int coevo_ga_fitness(const double *rewards, int game_first, int pop, int games_per_individual, int hof, int slot,
+                     const float *diversity, float *fitness, void *stream);
 /* order = np.argsort(fitness)[::-1] (genetic_algorithm.py:223-225; stable ascending sort reversed, so ties put the
  * HIGHER index first, quirk Q13).  n <= 4096. */
 int coevo_rank_desc(const float *fitness, int n, int32_t *order, void *stream);

@@ -183,8 +183,22 @@ def diversity(individual_es, population_es):
 
 
 # ------------------------------------------------------------------ Co-GA
-def ga_train(args, max_cycles=25, log=None):
-    """genetic_algorithm_train restated. args: attribute bag (mutated in place when adaptive)."""
+def mutate_philox(flat, D, sigma, seed, stream_lo, stream_hi, skip_layernorm=False):
+    """child = parent + sigma*eps with the build's counter-based noise (device_philox mode)"""
+    P = param_count(D)
+    out = np.zeros(P, dtype=np.float32)
+    segs = ln_segments(D) if skip_layernorm else []
+    so = np.array([s[0] for s in segs], dtype=np.int32)
+    sl = np.array([s[1] for s in segs], dtype=np.int32)
+    lib().oracle_perturb_philox(_fp(np.ascontiguousarray(flat)), _fp(out), P, float(sigma), int(seed), int(stream_lo),
+                                int(stream_hi), _ip(so), _ip(sl), len(segs))
+    return out
+
+
+def ga_train(args, max_cycles=25, log=None, noise="torch", philox_seed=0):
+    """genetic_algorithm_train restated. args: attribute bag (mutated in place when adaptive).
+    noise="torch": the reference's own RNG calls; noise="philox": the build's device_philox offspring rule
+    (child c of role ri in generation g uses stream (c, 4g+ri); no torch draws after initialisation)."""
     stream = Stream()
     pop, hof_n, E = args.population, args.hof_size, args.elites_number
     D = ROLE_D
@@ -240,12 +254,16 @@ def ga_train(args, max_cycles=25, log=None):
             hof[r].append(best[r])
             hof[r].pop(0)
         new_pop = {}
-        for r in ROLES:  # mutate_elites: clone() builds a fresh net first (burns init draws)
+        for ri, r in enumerate(ROLES):  # mutate_elites: clone() builds a fresh net first (burns init draws)
             sigma = getattr(args, sig_attr[r])
             children = []
             for i in range(pop - 1):
-                init_net(D[r])
-                children.append(mutate_torch(elites[r][i % E], D[r], sigma))
+                if noise == "torch":
+                    init_net(D[r])
+                    children.append(mutate_torch(elites[r][i % E], D[r], sigma))
+                else:
+                    children.append(mutate_philox(elites[r][i % E], D[r], np.float32(sigma), philox_seed, i,
+                                                  gen * 4 + ri))
             new_pop[r] = [best[r]] + children
         popu = new_pop
         rec["hof"] = {r: [w for w in hof[r]] for r in ROLES}

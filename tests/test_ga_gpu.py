@@ -1,0 +1,115 @@
+"""Whole Co-GA generations on the MI355X (drop-in genetic_algorithm_train) against the golden fixtures minted from the
+reference, and against the oracle port for the device-Philox offspring mode."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from coevonet_amd import genetic_algorithm as ga
+from coevonet_amd.game_logic import create_agent, initialize_env, play_game
+from oracle import ref_port as rp
+from tests.util import SAFE_MARGIN, Bag, load_golden, sha
+
+pytestmark = pytest.mark.gpu
+ROLE_FILES = {"agent_0": ("hall_of_fame_agent_0.pth", "elite_weights_agent_0.pth"),
+              "agent_1": ("hall_of_fame_agent_1.pth", "elite_weights_agent_1.pth"),
+              "adversary_0": ("hall_of_fame_adversary.pth", "elite_weights_adversary.pth")}
+
+
+def _run(cfg, rng, env_mode):
+    torch.manual_seed(cfg["seed"])
+    np.random.seed(cfg["seed"])
+    args = Bag(algorithm="GA", **cfg["args"])
+    env = initialize_env(args)
+    env.max_cycles = cfg.get("max_cycles", 25)
+    res = ga.genetic_algorithm_train(env, env.agents[0], args, None, rng=rng, env_mode=env_mode)
+    return args, env, res
+
+
+@pytest.mark.parametrize("name", ["ga_cfg1.json", "ga_hof2.json"])
+@pytest.mark.parametrize("env_mode", ["device", "host"])
+def test_ga_matches_reference_fixture(name, env_mode):
+    """host_reference RNG: elite ids exact, fitness rel-err <= 1e-5, per-game rewards bit-exact on margin-safe games,
+    final HoF / elite weights identical (sha256) to what the reference saved."""
+    fx = load_golden(name)
+    cfg = fx["config"]
+    args, env, res = _run(cfg, "host_reference", env_mode)
+    pop, hof = args.population, args.hof_size
+    for g, ref in enumerate(fx["generations"]):
+        assert res.elite_ids[g] == ref["elite_ids"], f"generation {g}"
+        for ph in range(3):
+            np.testing.assert_allclose(res.fitness[g][ph], ref["fitness"][ph], rtol=1e-5, atol=1e-7)
+        # the score is a sum of (1 - d/mean d) terms: absolute error ~ fp32 eps of 1.0, whatever the score's size
+        np.testing.assert_allclose(res.diversity[g], ref["diversity"], rtol=1e-5, atol=2e-7)
+        got = res.game_rewards[g]
+        n_safe = 0
+        for i, rg in enumerate(ref["games"][:3 * pop * hof]):
+            if rg["min_margin"] > SAFE_MARGIN:
+                assert list(got[i]) == rg["rewards"], (g, i)
+                n_safe += 1
+        assert n_safe >= 0.9 * 3 * pop * hof
+        np.testing.assert_allclose([res.rewards[r][g] for r in ga.ROLES], ref["eval_rewards"], rtol=1e-12)
+        assert res.sigma_after[g] == ref["sigma_after"]
+    last = {s["file"]: s["agents"] for s in fx["generations"][-1]["saves"]}
+    eng = res.engine
+    for role, (hf, ef) in ROLE_FILES.items():
+        assert [sha(w) for w in eng.download(role, "hof", 0, hof)] == [a["sha256"] for a in last[hf]]
+        assert [sha(w) for w in eng.download(role, "elite", 0, args.elites_number)] == [a["sha256"] for a in last[ef]]
+    assert env.n_resets == fx["env_resets"]
+
+
+def test_ga_device_philox_matches_oracle_port():
+    """performance mode (offspring built on the device): every number equals the sequential CPU port run with the
+    same counter-based noise - elite ids, fp32 fitness bits, fp64 game rewards, final weights."""
+    cfg = {"seed": 5, "args": dict(generations=3, population=10, hof_size=3, elites_number=2, fitness_sharing=True,
+                                   max_timesteps_per_episode=40, max_evaluation_steps=75)}
+    args, env, res = _run(cfg, "device_philox", "device")
+    torch.manual_seed(cfg["seed"])
+    np.random.seed(cfg["seed"])
+    oargs = Bag(algorithm="GA", **cfg["args"])
+    want = rp.ga_train(oargs, noise="philox", philox_seed=0)
+    pop, hof = oargs.population, oargs.hof_size
+    for g, w in enumerate(want):
+        assert res.elite_ids[g] == w["elite_ids"]
+        got = res.game_rewards[g]
+        for i in range(3 * pop * hof):
+            assert list(got[i]) == w["games"][i]["rewards"], (g, i)
+        for ph in range(3):  # the sharing score's distances are summed in fp64 here, by an fp32 BLAS dot in numpy
+            np.testing.assert_allclose(res.fitness[g][ph], w["fitness"][ph], rtol=2e-6)
+        assert [res.rewards[r][g] for r in ga.ROLES] == w["eval_rewards"]
+        assert res.sigma_after[g] == w["sigma_after"]
+    eng = res.engine
+    for role in ga.ROLES:
+        assert [sha(x) for x in eng.download(role, "hof", 0, hof)] == [sha(x) for x in want[-1]["hof"][role]]
+
+
+def test_play_game_facade_matches_fixture():
+    """play_game(env, p1, p2, adversary, args) through this package's surface == the reference's returns"""
+    for case in load_golden("play_game.json")["cases"]:
+        torch.manual_seed(case["torch_seed"])
+        np.random.seed(case["torch_seed"])
+        args = Bag(max_timesteps_per_episode=case["limit"], max_evaluation_steps=case["limit"])
+        env = initialize_env(args)
+        env.max_cycles = case["max_cycles"]
+        a0, a1, adv = (create_agent(env, args, r) for r in ("agent_0", "agent_1", "adversary_0"))
+        assert [sha(a.model.flat()) for a in (a0, a1, adv)] == [w["sha256"] for w in case["weights"]]
+        for g in case["games"]:
+            got = play_game(env=env, player1=a0.model, player2=a1.model, adversary=adv.model, args=args, eval=False)
+            if g["min_margin"] > SAFE_MARGIN:
+                assert list(got) == g["rewards"]
+    with pytest.raises(ValueError):
+        play_game(env=env, player1=a0.model, player2=a1.model, adversary=None, args=args)
+
+
+def test_aec_loop_with_device_forward():
+    """foreign-env path: the AEC loop with one HIP forward per agent-step gives the same triple"""
+    from coevonet_amd.game_logic import _play_mpe_aec
+    case = load_golden("play_game.json")["cases"][3]  # limit 7: short
+    torch.manual_seed(case["torch_seed"])
+    args = Bag(max_timesteps_per_episode=case["limit"], max_evaluation_steps=case["limit"])
+    env = initialize_env(args)
+    a0, a1, adv = (create_agent(env, args, r) for r in ("agent_0", "agent_1", "adversary_0"))
+    env.reset()
+    got = _play_mpe_aec(env, a0.model, a1.model, adv.model, args, False)
+    assert list(got) == case["games"][0]["rewards"]

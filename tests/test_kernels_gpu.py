@@ -144,7 +144,7 @@ def test_mpe_reset_matches_numpy_stream():
     from coevonet_amd.mpe.simple_adversary import ResetStream
     n, first = 301, 1
     st = torch.zeros(L.MPE_STATE_DOUBLES, n, dtype=torch.float64, device=DEV)
-    L.call("coevo_mpe_reset", L._p(st), n, L.PCG64State.from_seed(1870300), first)
+    L.call("coevo_mpe_reset", L._p(st), n, 0, n, L.PCG64State.from_seed(1870300), first)
     goal, apos, lpos = ResetStream().take(n)
     s = st.cpu().numpy()
     assert np.array_equal(s[0:6].T.reshape(n, 3, 2), apos)
@@ -155,7 +155,7 @@ def test_mpe_reset_matches_numpy_stream():
     # a shard that starts at an odd/even ordinal deep in the stream sees the same values
     st2 = torch.zeros(L.MPE_STATE_DOUBLES, 40, dtype=torch.float64, device=DEV)
     for first2 in (200, 257):
-        L.call("coevo_mpe_reset", L._p(st2), 40, L.PCG64State.from_seed(1870300), first2)
+        L.call("coevo_mpe_reset", L._p(st2), 40, 0, 40, L.PCG64State.from_seed(1870300), first2)
         assert np.array_equal(st2.cpu().numpy()[:18], s[:18, first2 - 1:first2 - 1 + 40])
 
 
@@ -164,7 +164,7 @@ def test_mpe_step_observe_match_host_env(limit, cycles):
     from coevonet_amd.mpe.simple_adversary import ResetStream, VecSimpleAdversary
     n = 130
     st = torch.zeros(L.MPE_STATE_DOUBLES, n, dtype=torch.float64, device=DEV)
-    L.call("coevo_mpe_reset", L._p(st), n, L.PCG64State.from_seed(1870300), 1)
+    L.call("coevo_mpe_reset", L._p(st), n, 0, n, L.PCG64State.from_seed(1870300), 1)
     env = VecSimpleAdversary(*ResetStream().take(n))
     row_game = torch.arange(n, dtype=torch.int32, device=DEV).repeat_interleave(3).contiguous()
     row_slot = torch.tensor([0, 1, 2], dtype=torch.int32, device=DEV).repeat(n).contiguous()
@@ -219,7 +219,7 @@ def test_device_rollout_matches_oracle_play_game(limit, max_cycles):
     game_rows = torch.arange(3 * n_games, dtype=torch.int32, device=DEV)
     st = torch.zeros(L.MPE_STATE_DOUBLES, n_games, dtype=torch.float64, device=DEV)
     first = 5
-    L.call("coevo_mpe_reset", L._p(st), n_games, L.PCG64State.from_seed(1870300), first)
+    L.call("coevo_mpe_reset", L._p(st), n_games, 0, n_games, L.PCG64State.from_seed(1870300), first)
     actions = torch.zeros(3 * n_games, dtype=torch.int32, device=DEV)
     status = torch.zeros(1, dtype=torch.int32, device=DEV)
     T = 3 * max_cycles if limit is None else min(limit, 3 * max_cycles)
@@ -320,7 +320,7 @@ def test_diversity_fitness_rank():
     rewards = g.normal(size=(40, 3)) * 10
     d_rew = torch.from_numpy(rewards).to(DEV)
     fit = torch.zeros(popn, dtype=torch.float32, device=DEV)
-    L.call("coevo_ga_fitness", L._p(d_rew), 4, popn, hof, 1, L._p(score), L._p(fit))
+    L.call("coevo_ga_fitness", L._p(d_rew), 4, popn, hof, hof, 1, L._p(score), L._p(fit))
     div = np.float32(score.item())
     want = [np.float32(rewards[4 + i * hof + hof - 1, 1] / hof) / (1 + div) for i in range(popn)]
     assert np.array_equal(fit.cpu().numpy(), np.array(want, dtype=np.float32))
