@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Co-GA population evaluation on MPE simple_adversary_v3, pop=200 per GPU, HoF=5, T=200
+(BASELINE.json configs[1]).  One "step" = one full generation: 3*pop*hof training games + the 10 evaluation games of
+the best trio, fitness sharing, ranking, HoF update and (pop-1) mutated offspring per role, all on the device.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see the contract in DESIGN.md "Measurement").
+Synthetic data: random-init nets (torch default init, seed 0) and the env's own seeded reset stream.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+class Bag:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def make_args(pop, hof, elites, limit):
+    return Bag(algorithm="GA", generations=0, population=pop, hof_size=hof, game="simple_adversary_v3",
+               mutation_power_agent_0=0.05, mutation_power_agent_1=0.05, mutation_power_adversary=0.05,
+               learning_rate=0.1, max_timesteps_per_episode=limit, max_evaluation_steps=limit, elites_number=elites,
+               adaptive=True, max_mutation_power=0.2, min_mutation_power=0.001, fitness_sharing=True,
+               early_stopping=False, patience=300, min_delta=0.1, debug=False, train=True, test=False, render=False,
+               env_mode="AEC", precision="float32", save=False, average_window=50, play_against_yourself=False)
+
+
+def cpu_baseline(pop, hof, limit, budget_s=15.0):
+    """The oracle port (sequential, batch-1 forward per agent-step, one AEC episode per game: how the reference runs)
+    timed on this host, single thread, on a bounded sample of generation 0's games of the same workload."""
+    from oracle import ref_port as rp
+    torch.manual_seed(0)
+    nets10 = [rp.init_net(10) for _ in range(8)]
+    nets8 = [rp.init_net(8) for _ in range(4)]
+    stream = rp.Stream()
+    rp.play_game(stream, nets10[0], nets10[1], nets8[0], limit, 25)  # warm
+    t0 = time.perf_counter()
+    games = steps = 0
+    while time.perf_counter() - t0 < budget_s:
+        g = rp.play_game(stream, nets10[games % 8], nets10[(games + 3) % 8], nets8[games % 4], limit, 25)
+        games += 1
+        steps += g["steps"]
+    dt = time.perf_counter() - t0
+    games_per_gen = 3 * pop * hof + 10
+    return {"value": (games / dt) / games_per_gen, "unit": "generations/s", "env_steps_per_sec": steps / dt,
+            "cores": 1, "kind": "port",
+            "sample": f"{games} sequential games ({steps} agent-steps) of the same workload in {dt:.1f} s, "
+                      f"extrapolated to {games_per_gen} games/generation; selection+mutation not included"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pop-per-gpu", type=int, default=200)
+    ap.add_argument("--hof", type=int, default=5)
+    ap.add_argument("--elites", type=int, default=2)
+    ap.add_argument("--limit", type=int, default=200)
+    ap.add_argument("--env", default="device", choices=["device", "host"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    from coevonet_amd import lib as L
+    from coevonet_amd.dist import DistContext
+    from coevonet_amd.game_logic import initialize_env
+    from coevonet_amd.genetic_algorithm import GATrainer
+    from coevonet_amd.rollout import KernelTimer
+
+    ctx = DistContext()
+    if ctx.world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={ctx.world}: launch with torch.distributed.run")
+    torch.cuda.set_device(ctx.local_rank)
+    dev = torch.device("cuda", ctx.local_rank)
+    L.load()
+
+    pop = a.pop_per_gpu * ctx.world  # weak scaling: per-GPU work fixed
+    torch.manual_seed(0)
+    np.random.seed(0)
+    args = make_args(pop, a.hof, a.elites, a.limit)
+    env = initialize_env(args)
+    tr = GATrainer(env, args, rng="device_philox", env_mode=a.env, collect=False, dist_ctx=ctx)
+    eng = tr.eng
+
+    for _ in range(a.warmup):
+        tr.step()
+    timer = KernelTimer() if a.env == "device" else None
+    eng.ro.light_timer = timer
+    ctx.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tr.step()
+    torch.cuda.synchronize()
+    ctx.barrier()
+    dt = ctx.max_over_ranks(time.perf_counter() - t0, dev)
+    eng.ro.light_timer = None
+    tr.finish()
+
+    steps_per_gen = eng.steps_per_generation  # agent-steps of the whole job per generation
+    gens_per_s = a.steps / dt
+    out = {
+        "metric": "env-steps/sec (agent-steps of the whole job; generations/sec in gens_per_sec), Co-GA "
+                  "simple_adversary_v3 pop=200/GPU HoF=5",
+        "value": gens_per_s * steps_per_gen, "unit": "env-steps/s", "gens_per_sec": gens_per_s,
+        "n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"Co-GA simple_adversary_v3 pop={pop} ({a.pop_per_gpu}/GPU) HoF={a.hof} "
+                               f"elites={a.elites} T={a.limit} (env max_cycles=25 caps a game at 75 agent-steps, as in "
+                               f"the reference), fitness sharing, adaptive sigma",
+                   "population": pop, "hof": a.hof, "games_per_generation": 3 * pop * a.hof + 10,
+                   "agent_steps_per_generation": steps_per_gen, "env": a.env, "offspring": "device_philox",
+                   "parallelism": f"population shard x{ctx.world}" if ctx.world > 1 else "single GPU"},
+    }
+    if ctx.rank == 0:
+        if timer is not None:
+            d = timer.durations_ms()
+            avg_ms = float(np.mean(d))
+            # algorithmic bytes of one launch of the dominant kernel: every distinct weight set among its tasks once
+            # + observations in / actions out; state reads are the observations' fp64 sources
+            nets = {}
+            for t in eng.plan.light_np:
+                nets[int(t["net_off"])] = L.fc_param_count(int(t["D"])) * 4
+            rows = int(sum(int(t["n_rows"]) for t in eng.plan.light_np))
+            alg_bytes = sum(nets.values()) + rows * (4 * 10 + 4)
+            achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "fc_policy_kernel<8,true> (per-individual weight sets)",
+                               "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
+                               "launches_timed": len(d)}
+        if not a.no_cpu_baseline and ctx.world == 1:
+            out["cpu_baseline"] = cpu_baseline(a.pop_per_gpu, a.hof, a.limit)
+        print(json.dumps(out), flush=True)
+    ctx.shutdown()
+
+
+if __name__ == "__main__":
+    main()

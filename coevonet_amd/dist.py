@@ -1,0 +1,68 @@
+"""Multi-GPU: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI; "gloo" on CPU for tests).
+
+The hot path shards by population index: rank r plays every game of individuals [lo, hi) of each role;
+HoF / elite / stale nets are replicated (a few MB).  The only exchange per generation is one fused all-gather of, per
+role and individual, the play_game triple of its last HoF game (3 x fp64) and its distance to the stale agent (stored
+as fp64) = 3 * pop * 32 bytes (19 KB at pop 200): latency-bound, so ONE collective, not three.  Every rank then runs the
+same deterministic sharing-score / fitness / rank kernels and rebuilds the same offspring from counter-based noise, so
+no weight ever crosses xGMI.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def allgather_shards(local: torch.Tensor, world: int) -> torch.Tensor:
+    """local [R, n_local, C] (this rank's contiguous index range of every role) -> [R, world*n_local, C], rank-major
+    along the index axis.  One all_gather_into_tensor."""
+    if world == 1:
+        return local
+    R, n_local, Cc = local.shape
+    out = torch.empty(world, R, n_local, Cc, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    return out.permute(1, 0, 2, 3).reshape(R, world * n_local, Cc)
+
+
+class DistContext:
+    def __init__(self, backend=None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+            if backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+
+    def gather_ga(self, eng):
+        """fills eng.dist[role][:] and eng.last_reward[:, :, :] for the whole population from every rank's shard"""
+        from .genetic_algorithm import ROLES
+        lo, hi = eng.lo, eng.hi
+        local = torch.empty(3, hi - lo, 4, dtype=torch.float64, device=eng.last_reward.device)
+        local[:, :, :3] = eng.last_reward[:, lo:hi]
+        for ri, r in enumerate(ROLES):
+            local[ri, :, 3] = eng.dist[r][lo:hi].to(torch.float64)
+        full = allgather_shards(local, self.world)
+        eng.last_reward.copy_(full[:, :, :3])
+        for ri, r in enumerate(ROLES):
+            eng.dist[r].copy_(full[ri, :, 3].to(torch.float32))
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier()
+
+    def max_over_ranks(self, seconds: float, device) -> float:
+        if self.world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def shutdown(self):
+        if self.world > 1 and dist.is_initialized():
+            dist.destroy_process_group()

@@ -319,49 +319,69 @@ def initial_population(env, args):
     return pop_flat, hof_flat
 
 
-def genetic_algorithm_train(env, agent, args, output_dir, rng=None, env_mode=None, collect=True, dist_ctx=None):
-    """Drop-in for genetic_algorithm.py:51.  Returns a GAResult (the reference returns None and plots instead).
+class GATrainer:
+    """The generation loop of genetic_algorithm_train as an object, one ``step()`` per generation (bench.py times
+    exactly these steps)."""
 
-    rng: "host_reference" (default when args has no `coevo_rng`) reproduces the reference's torch RNG stream;
-         "device_philox" builds offspring on the device."""
-    rng = rng or getattr(args, "coevo_rng", "host_reference")
-    env_mode = env_mode or getattr(args, "coevo_env", "device")
-    first_ordinal = getattr(env, "n_resets", 1)
-    pop_flat, hof_flat = initial_population(env, args)
-    shard, gather = (0, 1), None
-    if dist_ctx is not None:
-        shard, gather = (dist_ctx.rank, dist_ctx.world), dist_ctx.gather_ga
-    eng = GAEngine(args.population, args.hof_size, args.elites_number, args.max_timesteps_per_episode,
-                   args.max_evaluation_steps, max_cycles=getattr(env, "max_cycles", 25), rng=rng,
-                   philox_seed=getattr(args, "coevo_seed", 0), env=env_mode, first_ordinal=first_ordinal,
-                   env_seed=getattr(env, "seed_value", ENV_SEED) or ENV_SEED, shard=shard, gather=gather)
-    eng.load_initial(pop_flat, hof_flat)
-    res = GAResult()
-    gens = args.generations
-    for gen in range(gens):
+    def __init__(self, env, args, rng=None, env_mode=None, collect=True, dist_ctx=None):
+        self.env, self.args, self.collect = env, args, collect
+        self.rng = rng or getattr(args, "coevo_rng", "host_reference")
+        env_mode = env_mode or getattr(args, "coevo_env", "device")
+        self.first_ordinal = getattr(env, "n_resets", 1)
+        pop_flat, hof_flat = initial_population(env, args)
+        shard, gather = (0, 1), None
+        if dist_ctx is not None and dist_ctx.world > 1:
+            shard, gather = (dist_ctx.rank, dist_ctx.world), dist_ctx.gather_ga
+        self.eng = GAEngine(args.population, args.hof_size, args.elites_number, args.max_timesteps_per_episode,
+                            args.max_evaluation_steps, max_cycles=getattr(env, "max_cycles", 25), rng=self.rng,
+                            philox_seed=getattr(args, "coevo_seed", 0), env=env_mode,
+                            first_ordinal=self.first_ordinal,
+                            env_seed=getattr(env, "seed_value", ENV_SEED) or ENV_SEED, shard=shard, gather=gather)
+        self.eng.load_initial(pop_flat, hof_flat)
+        self.res = GAResult()
+        self.res.engine = self.eng
+        self.gen = 0
+
+    def step(self):
+        """generation self.gen: play its games (+ the previous generation's 10 evaluation games), select, breed"""
+        eng, args, res, gen = self.eng, self.args, self.res, self.gen
         t0 = time.perf_counter()
         eng.rollout(gen, with_prev_eval=gen > 0)
         if gen > 0:
             _finish_generation(args, gen - 1, eng.eval_rewards(), res)
         eng.select()
         sigmas = {r: getattr(args, SIGMA_ATTR[r]) for r in ROLES}
-        if rng == "host_reference":
-            eng.breed_host_reference(env, args, sigmas)
+        if self.rng == "host_reference":
+            eng.breed_host_reference(self.env, args, sigmas)
         else:
             eng.breed_device(gen, sigmas)
-        if collect:
+        if self.collect:
             res.game_rewards.append(eng.rewards_host()[:eng.n_main].copy())
             res.fitness.append([eng.fitness[r].cpu().numpy().tolist() for r in ROLES])
             res.diversity.append([float(eng.div[r].item()) for r in ROLES])
             res.elite_ids.append([eng.elite_ids()[r] for r in ROLES])
         res.seconds.append(time.perf_counter() - t0)
-    if gens > 0:
-        _finish_generation(args, gens - 1, eng.eval_only(gens - 1), res)
-    # keep the env's reset counter where the reference's would be
-    if hasattr(env, "n_resets"):
-        env.n_resets = first_ordinal + gens * (3 * args.population * args.hof_size + N_EVAL)
-    res.engine = eng
-    return res
+        self.gen += 1
+
+    def finish(self):
+        """flush the last generation's evaluation games and leave the env's reset counter where the reference would"""
+        if self.gen > 0:
+            _finish_generation(self.args, self.gen - 1, self.eng.eval_only(self.gen - 1), self.res)
+        if hasattr(self.env, "n_resets"):
+            self.env.n_resets = self.first_ordinal + self.gen * (3 * self.args.population * self.args.hof_size + N_EVAL)
+        return self.res
+
+
+def genetic_algorithm_train(env, agent, args, output_dir, rng=None, env_mode=None, collect=True, dist_ctx=None):
+    """Drop-in for genetic_algorithm.py:51 (``agent`` is unused there too).  Returns a GAResult (the reference returns
+    None and plots instead).
+
+    rng: "host_reference" (default) reproduces the reference's torch RNG stream bit for bit;
+         "device_philox" builds offspring on the device (args.coevo_rng may select it as well)."""
+    tr = GATrainer(env, args, rng=rng, env_mode=env_mode, collect=collect, dist_ctx=dist_ctx)
+    for _ in range(args.generations):
+        tr.step()
+    return tr.finish()
 
 
 def _finish_generation(args, gen, eval_triple, res):

@@ -81,6 +81,24 @@ class RolloutPlan:
         return sum(seen.values())
 
 
+class KernelTimer:
+    """HIP-event pairs recorded on the launching stream around every launch of ONE kernel (the dominant one), so
+    bench.py can report that kernel's average duration from inside the timed region."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def start(self):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.pairs.append((e0, e1))
+        return e1
+
+    def durations_ms(self):
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in self.pairs]
+
+
 def effective_steps(limit, max_cycles):
     """agent-steps one game runs: play_MPE breaks at the step limit or when max_cycles world steps truncate it."""
     cap = 3 * max_cycles
@@ -102,6 +120,7 @@ class DeviceRollout:
         self.rewards = torch.zeros(n, 3, dtype=torch.float64, device=dev)
         self.rng = L.PCG64State.from_seed(env_seed)
         self.pos_first = 1 if sa.INTEGRATE_POS_FIRST else 0
+        self.light_timer = None  # KernelTimer or None
 
     def set_limits(self, limits_np):
         self.limits.copy_(torch.from_numpy(np.asarray(limits_np, dtype=np.int32)), non_blocking=False)
@@ -118,9 +137,12 @@ class DeviceRollout:
                    L._p(self.state), p.n_games, L._p(p.row_game), L._p(p.row_slot), L._p(self.actions),
                    L._p(self.status))
         if p.light is not None:
+            end = self.light_timer.start() if self.light_timer is not None else None
             L.call("coevo_mpe_policy_cycle", L._p(self.slab), L._p(p.light), len(p.light_np), p.light_max,
                    L._p(self.state), p.n_games, L._p(p.row_game), L._p(p.row_slot), L._p(self.actions),
                    L._p(self.status))
+            if end is not None:
+                end.record()
         L.call("coevo_mpe_step", L._p(self.state), p.n_games, L._p(p.game_rows), L._p(self.actions), int(c),
                L._p(self.limits), self.pos_first)
 
