@@ -55,16 +55,35 @@ __host__ __device__ inline int64_t fc_slab_to_flat(int64_t s, int D)
     return s;
 }
 
-// ---- wavefront (64 lanes) canonical tree sum: every lane returns the block sum --------------------------------
+// ---- canonical tree sums on one 64-wide wavefront -----------------------------------------------------------
+// The tree is: adjacent pairs first (lane xor 1), then xor 2, 4, 8, 16, 32.  After level m every group of 2m lanes
+// holds one value, so any lane permutation that maps each group onto its sibling serves the next level: DPP
+// quad_perm for xor 1 / 2, row_half_mirror for 4, row_mirror for 8 (all in the VALU, no LDS crossbar), ds_swizzle
+// for 16, v_permlane32_swap for 32.  fp32 addition is commutative, so both partners get the same bits.
+template <int CTRL>
+__device__ inline float dpp_move(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+// levels 1..16: every lane ends with the tree sum of its 32-lane half
+__device__ inline float half_tree_sum(float v)
+{
+    v = v + dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = v + dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = v + dpp_move<0x141>(v);  // row_half_mirror
+    v = v + dpp_move<0x140>(v);  // row_mirror
+    v = v + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));  // xor 16 within 32 lanes
+    return v;
+}
+
+// all six levels: every lane returns the block (64-lane) sum
 __device__ inline float wave_tree_sum(float v)
 {
-    v = v + __shfl_xor(v, 1, 64);
-    v = v + __shfl_xor(v, 2, 64);
-    v = v + __shfl_xor(v, 4, 64);
-    v = v + __shfl_xor(v, 8, 64);
-    v = v + __shfl_xor(v, 16, 64);
-    v = v + __shfl_xor(v, 32, 64);
-    return v;
+    v = half_tree_sum(v);
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
 }
 
 // ---- MPE observation element k of env slot `slot` from the fp64 struct-of-arrays game state -------------------

@@ -228,16 +228,252 @@ __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
     if (st) atomicOr(a.status, st);
 }
 
+// =====================================================================================================
+// Shared-opponent tasks (a HoF member / ES base net applied to many games): a real GEMM with M = rows, so the
+// dense layers run on the matrix cores.  v_mfma_f32_32x32x2_f32 with C-in = bias is bit-for-bit the canonical
+// sequential-k fmaf chain (tools/mfma_chain_probe.hip), so this kernel and the VALU kernel above give identical bits.
+//
+// One workgroup = one net x up to 32 rows (the M of a 32x32 tile); wave w owns output columns
+//   fc1: [128w, 128w+128) = 4 tiles, fc2: [64w, 64w+64) = 2 tiles.
+// A operand (activations, [row][k]) comes from LDS in an image laid out so that one ds_read_b128 per lane feeds four
+// consecutive MFMAs; B operand (weights) is the same 16-byte row piece stream as the VALU kernel (W2q), turned into
+// two k-pair operands for each of the wave's two column tiles by two v_permlane32_swap.
+// Accumulator layout (32x32): col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+struct FcMfmaSmem {
+    union {
+        float h1a[64][64][4];  // [k/8][lane = 32*(k&1) + row][(k>>1)&3]: A operands of fc2, 64 KiB
+        float h2[32][260];
+    };
+    float xst[COEVO_OBS_STRIDE][32];  // observations transposed [k][row]: A operands of fc1
+    float w3s[NACT][260];
+    float red[32][8];
+    float logit[32][COEVO_LOGIT_STRIDE];
+};
+
+__device__ inline int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+template <bool FROM_STATE>
+__global__ __launch_bounds__(256) void fc_policy_mfma_kernel(FcArgs a)
+{
+    __shared__ FcMfmaSmem sm;
+    const int t = threadIdx.x, w = t >> 6, l = t & 63, lc = l & 31, lh = l >> 5;
+    const coevo_fc_task task = a.tasks[blockIdx.x];
+    const int D = task.D, nrows = task.n_rows, row0 = task.row_begin;
+    const float *net = a.slab + task.net_off;
+    int st = 0;
+
+    for (int i = t; i < 32 * COEVO_OBS_STRIDE; i += 256) {
+        const int r = i / COEVO_OBS_STRIDE, k = i % COEVO_OBS_STRIDE;
+        float v = 0.0f;
+        if (r < nrows && k < D) {
+            if constexpr (FROM_STATE) {
+                const int row = row0 + r;
+                v = mpe_obs_element(a.state, a.n_games, a.row_game[row], a.row_slot[row], k);
+            } else {
+                v = a.obs[(size_t)(row0 + r) * COEVO_OBS_STRIDE + k];
+            }
+            if (!__builtin_isfinite(v)) st |= COEVO_ST_BAD_INPUT;
+        }
+        sm.xst[k][r] = v;
+    }
+    {
+        const float *W3 = net + fc_off_w3(D);
+        for (int i = t; i < NACT * H2; i += 256) sm.w3s[i >> 8][i & 255] = W3[i];
+    }
+    __syncthreads();
+
+    // ---- fc1 on the matrix cores: 4 column tiles per wave, D/2 k-pairs ---------------------------------------
+    f32x16 c1[4];
+    {
+        const float *b1 = net + fc_off_b1(D);
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {
+            const float bb = b1[128 * w + 32 * tl + lc];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c1[tl][r] = bb;
+        }
+        for (int kk = 0; kk < D; kk += 2) {
+            const float av = sm.xst[kk + lh][lc];
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl) {
+                const float bv = net[(size_t)(kk + lh) * H1 + 128 * w + 32 * tl + lc];
+                c1[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, c1[tl], 0, 0, 0);
+            }
+        }
+    }
+    // ---- LayerNorm(512): canonical blocks 2w (tiles 0,1) and 2w+1 (tiles 2,3) --------------------------------
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float s01 = half_tree_sum(c1[0][r]) + half_tree_sum(c1[1][r]);
+        const float s23 = half_tree_sum(c1[2][r]) + half_tree_sum(c1[3][r]);
+        if (lc == 0) { sm.red[mfma_row(r, l)][2 * w] = s01; sm.red[mfma_row(r, l)][2 * w + 1] = s23; }
+    }
+    __syncthreads();
+    float stat[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float *rr = sm.red[mfma_row(r, l)];
+        float tot = rr[0];
+#pragma unroll
+        for (int b = 1; b < 8; ++b) tot = tot + rr[b];
+        stat[r] = tot * (1.0f / H1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) c1[tl][r] = c1[tl][r] - stat[r];
+        const float s01 = half_tree_sum(c1[0][r] * c1[0][r]) + half_tree_sum(c1[1][r] * c1[1][r]);
+        const float s23 = half_tree_sum(c1[2][r] * c1[2][r]) + half_tree_sum(c1[3][r] * c1[3][r]);
+        if (lc == 0) { sm.red[mfma_row(r, l)][2 * w] = s01; sm.red[mfma_row(r, l)][2 * w + 1] = s23; }
+    }
+    __syncthreads();
+    {
+        const float *g1 = net + fc_off_b1(D) + H1, *be1 = g1 + H1;
+        float ga[4], bt[4];
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) { ga[tl] = g1[128 * w + 32 * tl + lc]; bt[tl] = be1[128 * w + 32 * tl + lc]; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mfma_row(r, l);
+            const float *rr = sm.red[row];
+            float tot = rr[0];
+#pragma unroll
+            for (int b = 1; b < 8; ++b) tot = tot + rr[b];
+            const float rstd = 1.0f / __builtin_sqrtf(tot * (1.0f / H1) + LN_EPS);
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl) {
+                const float y = __builtin_fmaf(c1[tl][r] * rstd, ga[tl], bt[tl]);
+                if (row < nrows && bad_post_relu(y)) st |= COEVO_ST_BAD_FC1;
+                const int k = 128 * w + 32 * tl + lc;  // this activation is input k of fc2
+                sm.h1a[k >> 3][32 * (k & 1) + row][(k >> 1) & 3] = relu_keep_nan(y);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- fc2 on the matrix cores: 2 column tiles per wave, 256 k-pairs ---------------------------------------
+    f32x16 c2[2];
+    {
+        const float *b2 = net + fc_off_b2(D);
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const float bb = b2[64 * w + 32 * tl + lc];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c2[tl][r] = bb;
+        }
+        const float4 *wp = reinterpret_cast<const float4 *>(net + fc_off_w2(D)) + (size_t)w * 128 * 64 + l;
+        constexpr int U = 4;  // k-octets per iteration: 8 weight loads in flight per lane
+        for (int ko = 0; ko < 64; ko += U) {
+            float4 wv[2 * U];
+#pragma unroll
+            for (int u = 0; u < 2 * U; ++u) wv[u] = wp[(size_t)(2 * ko + u) * 64];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float4 av = *reinterpret_cast<const float4 *>(&sm.h1a[ko + u][l][0]);
+                const float aop[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {  // the two k-quads of this octet
+                    const float4 x = wv[2 * u + q];
+                    const u32x2 s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x.x), __float_as_uint(x.y), false, false);
+                    const u32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x.z), __float_as_uint(x.w), false, false);
+                    c2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[2 * q], __uint_as_float(s0[0]), c2[0], 0, 0, 0);
+                    c2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[2 * q], __uint_as_float(s0[1]), c2[1], 0, 0, 0);
+                    c2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[2 * q + 1], __uint_as_float(s1[0]), c2[0], 0, 0, 0);
+                    c2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[2 * q + 1], __uint_as_float(s1[1]), c2[1], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- LayerNorm(256): canonical block w = this wave's two tiles -------------------------------------------
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float s = half_tree_sum(c2[0][r]) + half_tree_sum(c2[1][r]);
+        if (lc == 0) sm.red[mfma_row(r, l)][w] = s;
+    }
+    __syncthreads();  // every wave is done with h1a: h2 may overwrite it below
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float *rr = sm.red[mfma_row(r, l)];
+        stat[r] = (((rr[0] + rr[1]) + rr[2]) + rr[3]) * (1.0f / H2);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        c2[0][r] = c2[0][r] - stat[r];
+        c2[1][r] = c2[1][r] - stat[r];
+        const float s = half_tree_sum(c2[0][r] * c2[0][r]) + half_tree_sum(c2[1][r] * c2[1][r]);
+        if (lc == 0) sm.red[mfma_row(r, l)][w] = s;
+    }
+    __syncthreads();
+    {
+        const float *g2 = net + fc_off_b2(D) + H2, *be2 = g2 + H2;
+        float ga[2], bt[2];
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) { ga[tl] = g2[64 * w + 32 * tl + lc]; bt[tl] = be2[64 * w + 32 * tl + lc]; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mfma_row(r, l);
+            const float *rr = sm.red[row];
+            const float tot = ((rr[0] + rr[1]) + rr[2]) + rr[3];
+            const float rstd = 1.0f / __builtin_sqrtf(tot * (1.0f / H2) + LN_EPS);
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                const float y = __builtin_fmaf(c2[tl][r] * rstd, ga[tl], bt[tl]);
+                if (row < nrows && bad_post_relu(y)) st |= COEVO_ST_BAD_FC2;
+                sm.h2[row][64 * w + 32 * tl + lc] = relu_keep_nan(y);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- output layer (N = 5: not worth a tile), argmax, status - as in the VALU kernel ----------------------
+    if (t < 32 * NACT) {
+        const int r = t / NACT, o = t % NACT;
+        float y = net[fc_off_b3(D) + o];
+        const float4 *wr = reinterpret_cast<const float4 *>(&sm.w3s[o][0]);
+        const float4 *xr = reinterpret_cast<const float4 *>(&sm.h2[r][0]);
+#pragma unroll 8
+        for (int k = 0; k < H2 / 4; ++k) {
+            const float4 wv = wr[k], xv = xr[k];
+            y = __builtin_fmaf(wv.x, xv.x, y);
+            y = __builtin_fmaf(wv.y, xv.y, y);
+            y = __builtin_fmaf(wv.z, xv.z, y);
+            y = __builtin_fmaf(wv.w, xv.w, y);
+        }
+        sm.logit[r][o] = y;
+    }
+    __syncthreads();
+    if (t < nrows) {
+        int best = -1;
+        float cur = -__builtin_inff();
+#pragma unroll
+        for (int o = 0; o < NACT; ++o) {
+            const float v = sm.logit[t][o];
+            if (!__builtin_isfinite(v)) st |= COEVO_ST_BAD_OUT;
+            if (v > cur) { cur = v; best = o; }
+        }
+        if (best < 0) { st |= COEVO_ST_NO_ACTION; best = 0; }
+        a.actions[row0 + t] = best;
+        if (a.logits) {
+#pragma unroll
+            for (int o = 0; o < NACT; ++o) a.logits[(size_t)(row0 + t) * COEVO_LOGIT_STRIDE + o] = sm.logit[t][o];
+        }
+    }
+    if (st) atomicOr(a.status, st);
+}
+
 template <bool FROM_STATE>
 static int launch_fc(const FcArgs &a, int n_tasks, int max_rows, hipStream_t s)
 {
     if (n_tasks <= 0) return COEVO_OK;
     if (max_rows <= 8)
         hipLaunchKernelGGL((fc_policy_kernel<8, FROM_STATE>), dim3(n_tasks), dim3(256), 0, s, a);
-    else if (max_rows <= 16)
-        hipLaunchKernelGGL((fc_policy_kernel<16, FROM_STATE>), dim3(n_tasks), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((fc_policy_kernel<32, FROM_STATE>), dim3(n_tasks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((fc_policy_mfma_kernel<FROM_STATE>), dim3(n_tasks), dim3(256), 0, s, a);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }
