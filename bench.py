@@ -79,7 +79,6 @@ def main():
     from coevonet_amd.dist import DistContext
     from coevonet_amd.game_logic import initialize_env
     from coevonet_amd.genetic_algorithm import GATrainer
-    from coevonet_amd.rollout import KernelTimer
 
     ctx = DistContext()
     if ctx.world != a.gpus:
@@ -98,8 +97,10 @@ def main():
 
     for _ in range(a.warmup):
         tr.step()
-    timer = KernelTimer() if a.env == "device" else None
-    eng.ro.light_timer = timer
+    timed = a.env == "device"
+    if timed:  # HIP events around every launch of the dominant kernel, recorded on the launching stream
+        eng.ro.reset_timing()
+        eng.ro.time_light = True
     ctx.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -108,7 +109,9 @@ def main():
     torch.cuda.synchronize()
     ctx.barrier()
     dt = ctx.max_over_ranks(time.perf_counter() - t0, dev)
-    eng.ro.light_timer = None
+    light_ms = eng.ro.light_times_ms() if timed else []
+    if timed:
+        eng.ro.time_light = False
     tr.finish()
 
     steps_per_gen = eng.steps_per_generation  # agent-steps of the whole job per generation
@@ -127,8 +130,8 @@ def main():
                    "parallelism": f"population shard x{ctx.world}" if ctx.world > 1 else "single GPU"},
     }
     if ctx.rank == 0:
-        if timer is not None:
-            d = timer.durations_ms()
+        if light_ms:
+            d = light_ms
             avg_ms = float(np.mean(d))
             # algorithmic bytes of one launch of the dominant kernel: every distinct weight set among its tasks once
             # + observations in / actions out; state reads are the observations' fp64 sources
@@ -138,7 +141,7 @@ def main():
             rows = int(sum(int(t["n_rows"]) for t in eng.plan.light_np))
             alg_bytes = sum(nets.values()) + rows * (4 * 10 + 4)
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "fc_policy_kernel<8,true> (per-individual weight sets)",
+            out["roofline"] = {"bound": "hbm", "kernel": "fc_policy_kernel<5,true> (per-individual weight sets)",
                                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,

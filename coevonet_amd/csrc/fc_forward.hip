@@ -16,6 +16,10 @@
 
 namespace coevo {
 
+#ifndef COEVO_LIGHT_U
+#define COEVO_LIGHT_U 16
+#endif
+
 template <int R>
 struct FcSmem {
     static constexpr int RP = R | 1;  // odd row pitch: conflict-free scatter of h1 into the k-quad image
@@ -52,6 +56,22 @@ __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
     const float *net = a.slab + task.net_off;
     int st = 0;
 
+    // ---- every small parameter this thread will need, requested up front: one HBM round trip instead of one
+    //      per layer (they would otherwise be loaded at first use, behind a barrier, with nothing else in flight)
+    constexpr int DMAX = 10;
+    float w1a[DMAX], w1b[DMAX];
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) {
+        w1a[k] = (k < D) ? net[(size_t)k * H1 + t] : 0.0f;
+        w1b[k] = (k < D) ? net[(size_t)k * H1 + 256 + t] : 0.0f;
+    }
+    const float *b1p = net + fc_off_b1(D), *b2p = net + fc_off_b2(D);
+    const float p_b1a = b1p[t], p_b1b = b1p[t + 256];
+    const float p_g1a = b1p[H1 + t], p_g1b = b1p[H1 + t + 256];
+    const float p_be1a = b1p[2 * H1 + t], p_be1b = b1p[2 * H1 + t + 256];
+    const float p_b2 = b2p[t], p_g2 = b2p[H2 + t], p_be2 = b2p[2 * H2 + t];
+    const float p_b3 = (t < R * NACT) ? net[fc_off_b3(D) + t % NACT] : 0.0f;
+
     // ---- stage observations (zero padded) and the output layer -------------------------------------------
     for (int i = t; i < R * COEVO_OBS_STRIDE; i += 256) {
         const int r = i / COEVO_OBS_STRIDE, k = i % COEVO_OBS_STRIDE;
@@ -76,17 +96,17 @@ __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
     // ---- fc1: outputs j0 = t, j1 = t + 256; sequential-k chains from the bias -----------------------------
     float a0[R], a1[R];
     {
-        const float *b1 = net + fc_off_b1(D);
-        const float bb0 = b1[t], bb1 = b1[t + 256];
 #pragma unroll
-        for (int r = 0; r < R; ++r) { a0[r] = bb0; a1[r] = bb1; }
-        for (int k = 0; k < D; ++k) {
-            const float w0 = net[(size_t)k * H1 + t], w1 = net[(size_t)k * H1 + 256 + t];
+        for (int r = 0; r < R; ++r) { a0[r] = p_b1a; a1[r] = p_b1b; }
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float x = sm.xs0[r][k];
-                a0[r] = __builtin_fmaf(w0, x, a0[r]);
-                a1[r] = __builtin_fmaf(w1, x, a1[r]);
+        for (int k = 0; k < DMAX; ++k) {
+            if (k < D) {  // wave-uniform
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const float x = sm.xs0[r][k];
+                    a0[r] = __builtin_fmaf(w1a[k], x, a0[r]);
+                    a1[r] = __builtin_fmaf(w1b[k], x, a1[r]);
+                }
             }
         }
     }
@@ -114,8 +134,7 @@ __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
     }
     __syncthreads();
     {
-        const float *g1 = net + fc_off_b1(D) + H1, *be1 = g1 + H1;
-        const float ga0 = g1[t], ga1 = g1[t + 256], bt0 = be1[t], bt1 = be1[t + 256];
+        const float ga0 = p_g1a, ga1 = p_g1b, bt0 = p_be1a, bt1 = p_be1b;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float tot = sm.red[r][0];
@@ -135,11 +154,14 @@ __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
     // ---- fc2: lane owns output 64w + l; 128 k-quads streamed as 16-byte pieces, 8 loads in flight ----------
     float acc[R];
     {
-        const float bb = net[fc_off_b2(D) + t];
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = bb;
+        for (int r = 0; r < R; ++r) acc[r] = p_b2;
         const float4 *wp = reinterpret_cast<const float4 *>(net + fc_off_w2(D)) + (size_t)w * 128 * 64 + l;
-        constexpr int U = 8;
+        // U 16-byte loads per lane (U KiB per wave) are issued back to back, then consumed; a task therefore exposes
+        // 128/U memory latencies, hidden by the other workgroups resident on the CU.  (Deeper software pipelining was
+        // tried three ways - C++ double buffer, ping-pong buffers with sched_barrier, inline-asm loads with counted
+        // vmcnt - and hipcc either sinks the prefetch below its consumer or spills hundreds of registers.)
+        constexpr int U = COEVO_LIGHT_U;
         for (int kq = 0; kq < 128; kq += U) {
             float4 wv[U];
 #pragma unroll
@@ -177,8 +199,7 @@ __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
     }
     __syncthreads();
     {
-        const float *g2 = net + fc_off_b2(D) + H2, *be2 = g2 + H2;
-        const float ga = g2[t], bt = be2[t];
+        const float ga = p_g2, bt = p_be2;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const float tot = ((sm.red[r][0] + sm.red[r][1]) + sm.red[r][2]) + sm.red[r][3];
@@ -193,7 +214,7 @@ __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
     // ---- output layer: one lane per (row, action), 256-long sequential chain out of LDS --------------------
     if (t < R * NACT) {
         const int r = t / NACT, o = t % NACT;
-        float y = net[fc_off_b3(D) + o];
+        float y = p_b3;
         const float4 *wr = reinterpret_cast<const float4 *>(&sm.w3s[o][0]);
         const float4 *xr = reinterpret_cast<const float4 *>(&sm.h2[r][0]);
 #pragma unroll 8
@@ -256,7 +277,7 @@ struct FcMfmaSmem {
 __device__ inline int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 template <bool FROM_STATE>
-__global__ __launch_bounds__(256) void fc_policy_mfma_kernel(FcArgs a)
+__global__ __launch_bounds__(256, 2) void fc_policy_mfma_kernel(FcArgs a)
 {
     __shared__ FcMfmaSmem sm;
     const int t = threadIdx.x, w = t >> 6, l = t & 63, lc = l & 31, lh = l >> 5;
@@ -264,6 +285,29 @@ __global__ __launch_bounds__(256) void fc_policy_mfma_kernel(FcArgs a)
     const int D = task.D, nrows = task.n_rows, row0 = task.row_begin;
     const float *net = a.slab + task.net_off;
     int st = 0;
+
+    // ---- all small parameters and the whole fc1 B operand requested up front (one HBM/L2 round trip) ----------
+    constexpr int KP = 5;  // k-pairs of fc1 (D <= 10)
+    float w1[KP][4], p_b1[4], p_g1[4], p_be1[4], p_b2[2], p_g2[2], p_be2[2];
+    {
+        const float *b1p = net + fc_off_b1(D), *b2p = net + fc_off_b2(D);
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp)
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl)
+                w1[kp][tl] = (2 * kp < D) ? net[(size_t)(2 * kp + lh) * H1 + 128 * w + 32 * tl + lc] : 0.0f;
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {
+            const int j = 128 * w + 32 * tl + lc;
+            p_b1[tl] = b1p[j]; p_g1[tl] = b1p[H1 + j]; p_be1[tl] = b1p[2 * H1 + j];
+        }
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+            const int j = 64 * w + 32 * tl + lc;
+            p_b2[tl] = b2p[j]; p_g2[tl] = b2p[H2 + j]; p_be2[tl] = b2p[2 * H2 + j];
+        }
+    }
+    const float p_b3 = (t < 32 * NACT) ? net[fc_off_b3(D) + t % NACT] : 0.0f;
 
     for (int i = t; i < 32 * COEVO_OBS_STRIDE; i += 256) {
         const int r = i / COEVO_OBS_STRIDE, k = i % COEVO_OBS_STRIDE;
@@ -288,19 +332,18 @@ __global__ __launch_bounds__(256) void fc_policy_mfma_kernel(FcArgs a)
     // ---- fc1 on the matrix cores: 4 column tiles per wave, D/2 k-pairs ---------------------------------------
     f32x16 c1[4];
     {
-        const float *b1 = net + fc_off_b1(D);
 #pragma unroll
         for (int tl = 0; tl < 4; ++tl) {
-            const float bb = b1[128 * w + 32 * tl + lc];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) c1[tl][r] = bb;
+            for (int r = 0; r < 16; ++r) c1[tl][r] = p_b1[tl];
         }
-        for (int kk = 0; kk < D; kk += 2) {
-            const float av = sm.xst[kk + lh][lc];
 #pragma unroll
-            for (int tl = 0; tl < 4; ++tl) {
-                const float bv = net[(size_t)(kk + lh) * H1 + 128 * w + 32 * tl + lc];
-                c1[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, c1[tl], 0, 0, 0);
+        for (int kp = 0; kp < KP; ++kp) {
+            if (2 * kp < D) {  // wave-uniform
+                const float av = sm.xst[2 * kp + lh][lc];
+#pragma unroll
+                for (int tl = 0; tl < 4; ++tl)
+                    c1[tl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w1[kp][tl], c1[tl], 0, 0, 0);
             }
         }
     }
@@ -332,10 +375,7 @@ __global__ __launch_bounds__(256) void fc_policy_mfma_kernel(FcArgs a)
     }
     __syncthreads();
     {
-        const float *g1 = net + fc_off_b1(D) + H1, *be1 = g1 + H1;
-        float ga[4], bt[4];
-#pragma unroll
-        for (int tl = 0; tl < 4; ++tl) { ga[tl] = g1[128 * w + 32 * tl + lc]; bt[tl] = be1[128 * w + 32 * tl + lc]; }
+        const float *ga = p_g1, *bt = p_be1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = mfma_row(r, l);
@@ -358,26 +398,28 @@ __global__ __launch_bounds__(256) void fc_policy_mfma_kernel(FcArgs a)
     // ---- fc2 on the matrix cores: 2 column tiles per wave, 256 k-pairs ---------------------------------------
     f32x16 c2[2];
     {
-        const float *b2 = net + fc_off_b2(D);
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl) {
-            const float bb = b2[64 * w + 32 * tl + lc];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) c2[tl][r] = bb;
+            for (int r = 0; r < 16; ++r) c2[tl][r] = p_b2[tl];
         }
         const float4 *wp = reinterpret_cast<const float4 *>(net + fc_off_w2(D)) + (size_t)w * 128 * 64 + l;
-        constexpr int U = 4;  // k-octets per iteration: 8 weight loads in flight per lane
-        for (int ko = 0; ko < 64; ko += U) {
-            float4 wv[2 * U];
+        // software pipeline over k-octets, two register buffers in ping-pong: the other buffer's 2U weight pieces
+        // are in flight while this buffer's U octets feed 8U MFMAs
+        constexpr int U = 2;
+        float4 bufA[2 * U], bufB[2 * U];
+        auto issue = [&](float4 (&buf)[2 * U], int ko) {
 #pragma unroll
-            for (int u = 0; u < 2 * U; ++u) wv[u] = wp[(size_t)(2 * ko + u) * 64];
+            for (int u = 0; u < 2 * U; ++u) buf[u] = wp[(size_t)(2 * ko + u) * 64];
+        };
+        auto consume = [&](const float4 (&buf)[2 * U], int ko) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const float4 av = *reinterpret_cast<const float4 *>(&sm.h1a[ko + u][l][0]);
                 const float aop[4] = {av.x, av.y, av.z, av.w};
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {  // the two k-quads of this octet
-                    const float4 x = wv[2 * u + q];
+                    const float4 x = buf[2 * u + q];
                     const u32x2 s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x.x), __float_as_uint(x.y), false, false);
                     const u32x2 s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x.z), __float_as_uint(x.w), false, false);
                     c2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[2 * q], __uint_as_float(s0[0]), c2[0], 0, 0, 0);
@@ -386,7 +428,21 @@ __global__ __launch_bounds__(256) void fc_policy_mfma_kernel(FcArgs a)
                     c2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[2 * q + 1], __uint_as_float(s1[1]), c2[1], 0, 0, 0);
                 }
             }
+        };
+        issue(bufA, 0);
+        int ko = 0;
+        for (; ko < 64 - 2 * U; ko += 2 * U) {
+            issue(bufB, ko + U);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(bufA, ko);
+            issue(bufA, ko + 2 * U);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(bufB, ko + U);
         }
+        issue(bufB, ko + U);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(bufA, ko);
+        consume(bufB, ko + U);
     }
     // ---- LayerNorm(256): canonical block w = this wave's two tiles -------------------------------------------
 #pragma unroll
@@ -410,10 +466,7 @@ __global__ __launch_bounds__(256) void fc_policy_mfma_kernel(FcArgs a)
     }
     __syncthreads();
     {
-        const float *g2 = net + fc_off_b2(D) + H2, *be2 = g2 + H2;
-        float ga[2], bt[2];
-#pragma unroll
-        for (int tl = 0; tl < 2; ++tl) { ga[tl] = g2[64 * w + 32 * tl + lc]; bt[tl] = be2[64 * w + 32 * tl + lc]; }
+        const float *ga = p_g2, *bt = p_be2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = mfma_row(r, l);
@@ -433,7 +486,7 @@ __global__ __launch_bounds__(256) void fc_policy_mfma_kernel(FcArgs a)
     // ---- output layer (N = 5: not worth a tile), argmax, status - as in the VALU kernel ----------------------
     if (t < 32 * NACT) {
         const int r = t / NACT, o = t % NACT;
-        float y = net[fc_off_b3(D) + o];
+        float y = p_b3;
         const float4 *wr = reinterpret_cast<const float4 *>(&sm.w3s[o][0]);
         const float4 *xr = reinterpret_cast<const float4 *>(&sm.h2[r][0]);
 #pragma unroll 8
@@ -470,7 +523,9 @@ template <bool FROM_STATE>
 static int launch_fc(const FcArgs &a, int n_tasks, int max_rows, hipStream_t s)
 {
     if (n_tasks <= 0) return COEVO_OK;
-    if (max_rows <= 8)
+    if (max_rows <= 5)
+        hipLaunchKernelGGL((fc_policy_kernel<5, FROM_STATE>), dim3(n_tasks), dim3(256), 0, s, a);
+    else if (max_rows <= 8)
         hipLaunchKernelGGL((fc_policy_kernel<8, FROM_STATE>), dim3(n_tasks), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((fc_policy_mfma_kernel<FROM_STATE>), dim3(n_tasks), dim3(256), 0, s, a);

@@ -1,0 +1,105 @@
+// coevo_mpe_rollout - a whole batch of games in ONE C-ABI call: the replacement for the reference's per-game
+// play_game()/play_MPE() loop (utils/game_logic_functions.py:123-228) at batch scale.
+//
+// Per env-cycle it enqueues: [side stream] the shared-opponent (MFMA) policy launch || [main stream] the
+// per-individual (streaming) policy launch, joined by an event, then the env step on the main stream.  The two policy
+// launches touch disjoint rows and different bottlenecks (matrix cores fed from L2 vs HBM streaming), so they are
+// meant to overlap.  Nothing here synchronises with the host; the whole sequence can also be captured into a hipGraph
+// by the caller (capture `stream`; the side stream joins the capture through the fork event).
+#include <vector>
+
+#include "coevo_common.hip.h"
+
+struct coevo_rollout_ctx {
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    std::vector<hipEvent_t> timing;  // pairs (start, end) around the light launch of each cycle
+    int pairs_used = 0;
+};
+
+extern "C" void *coevo_rollout_ctx_create(int n_timing_pairs)
+{
+    auto *c = new coevo_rollout_ctx();
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->join, hipEventDisableTiming) != hipSuccess) {
+        delete c;
+        return nullptr;
+    }
+    c->timing.resize(2 * (size_t)(n_timing_pairs > 0 ? n_timing_pairs : 0));
+    for (auto &e : c->timing)
+        if (hipEventCreate(&e) != hipSuccess) { delete c; return nullptr; }
+    return c;
+}
+
+extern "C" void coevo_rollout_ctx_destroy(void *ctx)
+{
+    auto *c = static_cast<coevo_rollout_ctx *>(ctx);
+    if (!c) return;
+    for (auto e : c->timing) (void)hipEventDestroy(e);
+    if (c->fork) (void)hipEventDestroy(c->fork);
+    if (c->join) (void)hipEventDestroy(c->join);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    delete c;
+}
+
+extern "C" int coevo_rollout_ctx_reset_timing(void *ctx)
+{
+    auto *c = static_cast<coevo_rollout_ctx *>(ctx);
+    if (!c) return COEVO_ERR_ARG;
+    c->pairs_used = 0;
+    return COEVO_OK;
+}
+
+// elapsed milliseconds of every timed light launch so far (blocks until they have completed); returns the count
+extern "C" int coevo_rollout_ctx_light_times(void *ctx, float *ms_out, int max_out)
+{
+    auto *c = static_cast<coevo_rollout_ctx *>(ctx);
+    if (!c || !ms_out) return COEVO_ERR_ARG;
+    int n = c->pairs_used < max_out ? c->pairs_used : max_out;
+    for (int i = 0; i < n; ++i) {
+        if (hipEventSynchronize(c->timing[2 * i + 1]) != hipSuccess) return COEVO_ERR_HIP;
+        if (hipEventElapsedTime(&ms_out[i], c->timing[2 * i], c->timing[2 * i + 1]) != hipSuccess) return COEVO_ERR_HIP;
+    }
+    return n;
+}
+
+extern "C" int coevo_mpe_rollout(const coevo_rollout_desc *d, void *ctx, int time_light, void *stream)
+{
+    if (!d || !d->slab || !d->state || !d->row_game || !d->row_slot || !d->game_rows || !d->actions || !d->status)
+        return COEVO_ERR_ARG;
+    if (d->n_games <= 0 || d->n_cycles < 0 || d->n_heavy < 0 || d->n_light < 0) return COEVO_ERR_ARG;
+    if ((d->n_heavy > 0 && !d->heavy) || (d->n_light > 0 && !d->light)) return COEVO_ERR_ARG;
+    auto *c = static_cast<coevo_rollout_ctx *>(ctx);
+    hipStream_t main_s = (hipStream_t)stream;
+    const bool two = c && d->n_heavy > 0 && d->n_light > 0;
+    for (int cyc = 0; cyc < d->n_cycles; ++cyc) {
+        int rc;
+        if (two) {
+            COEVO_HIP_CHECK(hipEventRecord(c->fork, main_s));
+            COEVO_HIP_CHECK(hipStreamWaitEvent(c->side, c->fork, 0));
+        }
+        if (d->n_heavy > 0) {
+            rc = coevo_mpe_policy_cycle(d->slab, d->heavy, d->n_heavy, d->heavy_max_rows, d->state, d->n_games,
+                                        d->row_game, d->row_slot, d->actions, d->status, two ? c->side : main_s);
+            if (rc) return rc;
+            if (two) COEVO_HIP_CHECK(hipEventRecord(c->join, c->side));
+        }
+        if (d->n_light > 0) {
+            const bool timed = time_light && c && (size_t)(2 * c->pairs_used + 1) < c->timing.size();
+            if (timed) COEVO_HIP_CHECK(hipEventRecord(c->timing[2 * c->pairs_used], main_s));
+            rc = coevo_mpe_policy_cycle(d->slab, d->light, d->n_light, d->light_max_rows, d->state, d->n_games,
+                                        d->row_game, d->row_slot, d->actions, d->status, main_s);
+            if (rc) return rc;
+            if (timed) {
+                COEVO_HIP_CHECK(hipEventRecord(c->timing[2 * c->pairs_used + 1], main_s));
+                ++c->pairs_used;
+            }
+        }
+        if (two) COEVO_HIP_CHECK(hipStreamWaitEvent(main_s, c->join, 0));
+        rc = coevo_mpe_step(d->state, d->n_games, d->game_rows, d->actions, cyc, d->game_limit, d->pos_first, main_s);
+        if (rc) return rc;
+    }
+    if (d->rewards) return coevo_mpe_rewards(d->state, d->n_games, d->rewards, main_s);
+    return COEVO_OK;
+}

@@ -71,7 +71,7 @@ class GAEngine:
 
     def __init__(self, pop, hof, elites, limit_train=None, limit_eval=None, max_cycles=25, device="cuda",
                  env_seed=ENV_SEED, rng="device_philox", philox_seed=0, env="device", first_ordinal=1,
-                 shard=(0, 1), gather=None):
+                 shard=(0, 1), gather=None, timing_pairs=4096):
         assert 1 <= elites <= pop and hof >= 1
         self.pop, self.hof, self.E = pop, hof, elites
         self.rng_mode, self.philox_seed, self.env_mode = rng, int(philox_seed), env
@@ -123,8 +123,10 @@ class GAEngine:
         for _ in range(N_EVAL):  # evaluate_current_weights(best trio) = newest HoF members (:12-29, :301)
             games.append((net("hof", "adversary_0", h - 1), net("hof", "agent_0", h - 1), net("hof", "agent_1", h - 1)))
         self.plan = RolloutPlan(np.array(games), net_off, net_D, device=device)
-        cls = DeviceRollout if env == "device" else HostEnvRollout
-        self.ro = cls(self.plan, self.slab, env_seed=env_seed)
+        if env == "device":
+            self.ro = DeviceRollout(self.plan, self.slab, env_seed=env_seed, timing_pairs=timing_pairs)
+        else:
+            self.ro = HostEnvRollout(self.plan, self.slab, env_seed=env_seed)
         # ---- small device buffers ---------------------------------------------------------------------------
         f32 = dict(dtype=torch.float32, device=device)
         self.dist = {r: torch.zeros(pop, **f32) for r in ROLES}

@@ -37,6 +37,15 @@ class PCG64State(C.Structure):
         return cls(st["state"] >> 64, st["state"] & m, st["inc"] >> 64, st["inc"] & m)
 
 
+class RolloutDesc(C.Structure):
+    _fields_ = [("slab", C.c_void_p), ("heavy", C.c_void_p), ("n_heavy", C.c_int32), ("heavy_max_rows", C.c_int32),
+                ("light", C.c_void_p), ("n_light", C.c_int32), ("light_max_rows", C.c_int32),
+                ("state", C.c_void_p), ("n_games", C.c_int32), ("n_cycles", C.c_int32),
+                ("row_game", C.c_void_p), ("row_slot", C.c_void_p), ("game_rows", C.c_void_p),
+                ("actions", C.c_void_p), ("status", C.c_void_p), ("game_limit", C.c_void_p),
+                ("rewards", C.c_void_p), ("pos_first", C.c_int32), ("reserved", C.c_int32)]
+
+
 class CoevoError(RuntimeError):
     pass
 
@@ -57,6 +66,11 @@ _SIGS = {
     "coevo_mpe_rewards": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "coevo_mpe_policy_cycle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "coevo_rollout_ctx_create": (C.c_void_p, [C.c_int]),
+    "coevo_rollout_ctx_destroy": (None, [C.c_void_p]),
+    "coevo_rollout_ctx_reset_timing": (C.c_int, [C.c_void_p]),
+    "coevo_rollout_ctx_light_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
+    "coevo_mpe_rollout": (C.c_int, [C.POINTER(RolloutDesc), C.c_void_p, C.c_int, C.c_void_p]),
     "coevo_fc_perturb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]),
     "coevo_fc_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

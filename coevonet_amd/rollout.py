@@ -43,6 +43,7 @@ class RolloutPlan:
             else:
                 for i in range(0, len(rows), heavy_rows):
                     heavy.append((net, rows[i:i + heavy_rows]))
+        heavy = self._xcd_order(heavy)
         # heavy tasks first in row space; inside each class keep first-game order (locality of the state reads)
         row_game, row_slot = [], []
         tasks = {"heavy": [], "light": []}
@@ -72,6 +73,30 @@ class RolloutPlan:
             self.heavy = L.tasks_to_device(self.heavy_np, device) if len(self.heavy_np) else None
             self.light = L.tasks_to_device(self.light_np, device) if len(self.light_np) else None
 
+    @staticmethod
+    def _xcd_order(heavy):
+        """Workgroups are dealt round-robin over the 8 XCDs (blockIdx b and b+8 share one, each XCD has its own
+        4 MiB L2).  Place all chunks of one shared net at block indices of one residue class mod 8 so the net is
+        fetched into ONE L2 and re-read there; nets are spread over the 8 classes by load.  Speed only: the kernel is
+        correct under any placement."""
+        if len(heavy) < 16:
+            return heavy
+        per_net = {}
+        for net, rows in heavy:
+            per_net.setdefault(net, []).append((net, rows))
+        buckets = [[] for _ in range(8)]
+        for net, chunks in sorted(per_net.items(), key=lambda kv: -len(kv[1])):
+            min(buckets, key=len).extend(chunks)
+        out, depth = [], max(len(b) for b in buckets)
+        spare = []
+        for q in range(depth):
+            for x in range(8):
+                if q < len(buckets[x]):
+                    out.append(buckets[x][q])
+                else:
+                    spare.append(x)  # ragged tail: later blocks simply fall where they fall
+        return out
+
     def distinct_weight_bytes_per_cycle(self):
         """algorithmic bytes of one env-cycle: every distinct weight set that acts, once."""
         seen = {}
@@ -81,24 +106,6 @@ class RolloutPlan:
         return sum(seen.values())
 
 
-class KernelTimer:
-    """HIP-event pairs recorded on the launching stream around every launch of ONE kernel (the dominant one), so
-    bench.py can report that kernel's average duration from inside the timed region."""
-
-    def __init__(self):
-        self.pairs = []
-
-    def start(self):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        self.pairs.append((e0, e1))
-        return e1
-
-    def durations_ms(self):
-        torch.cuda.synchronize()
-        return [a.elapsed_time(b) for a, b in self.pairs]
-
-
 def effective_steps(limit, max_cycles):
     """agent-steps one game runs: play_MPE breaks at the step limit or when max_cycles world steps truncate it."""
     cap = 3 * max_cycles
@@ -106,9 +113,10 @@ def effective_steps(limit, max_cycles):
 
 
 class DeviceRollout:
-    """Env copies resident on the GPU; one fused observe+policy launch per task class and one step launch per cycle."""
+    """Env copies resident on the GPU.  One C-ABI call (coevo_mpe_rollout) enqueues every cycle: the shared-opponent
+    (MFMA) launch on a side HIP stream concurrently with the per-individual (streaming) launch, then the env step."""
 
-    def __init__(self, plan: RolloutPlan, slab: torch.Tensor, env_seed=sa.ENV_SEED):
+    def __init__(self, plan: RolloutPlan, slab: torch.Tensor, env_seed=sa.ENV_SEED, timing_pairs=0):
         self.plan = plan
         self.slab = slab
         dev = plan.device
@@ -120,7 +128,26 @@ class DeviceRollout:
         self.rewards = torch.zeros(n, 3, dtype=torch.float64, device=dev)
         self.rng = L.PCG64State.from_seed(env_seed)
         self.pos_first = 1 if sa.INTEGRATE_POS_FIRST else 0
-        self.light_timer = None  # KernelTimer or None
+        self.time_light = False
+        self.overlap = True
+        self.ctx = L.load().coevo_rollout_ctx_create(int(timing_pairs))
+        if not self.ctx:
+            raise L.CoevoError("coevo_rollout_ctx_create failed")
+        p = plan
+        self.desc = L.RolloutDesc(
+            slab=L._p(slab), heavy=L._p(p.heavy), n_heavy=len(p.heavy_np), heavy_max_rows=p.heavy_max,
+            light=L._p(p.light), n_light=len(p.light_np), light_max_rows=p.light_max,
+            state=L._p(self.state), n_games=n, n_cycles=0, row_game=L._p(p.row_game), row_slot=L._p(p.row_slot),
+            game_rows=L._p(p.game_rows), actions=L._p(self.actions), status=L._p(self.status),
+            game_limit=L._p(self.limits), rewards=L._p(self.rewards), pos_first=self.pos_first, reserved=0)
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                L.load().coevo_rollout_ctx_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
 
     def set_limits(self, limits_np):
         self.limits.copy_(torch.from_numpy(np.asarray(limits_np, dtype=np.int32)), non_blocking=False)
@@ -130,26 +157,20 @@ class DeviceRollout:
         L.call("coevo_mpe_reset", L._p(self.state), self.plan.n_games, int(game_first), int(n_games), self.rng,
                int(first_ordinal))
 
-    def cycle(self, c):
-        p = self.plan
-        if p.heavy is not None:
-            L.call("coevo_mpe_policy_cycle", L._p(self.slab), L._p(p.heavy), len(p.heavy_np), p.heavy_max,
-                   L._p(self.state), p.n_games, L._p(p.row_game), L._p(p.row_slot), L._p(self.actions),
-                   L._p(self.status))
-        if p.light is not None:
-            end = self.light_timer.start() if self.light_timer is not None else None
-            L.call("coevo_mpe_policy_cycle", L._p(self.slab), L._p(p.light), len(p.light_np), p.light_max,
-                   L._p(self.state), p.n_games, L._p(p.row_game), L._p(p.row_slot), L._p(self.actions),
-                   L._p(self.status))
-            if end is not None:
-                end.record()
-        L.call("coevo_mpe_step", L._p(self.state), p.n_games, L._p(p.game_rows), L._p(self.actions), int(c),
-               L._p(self.limits), self.pos_first)
-
     def run(self, n_cycles):
-        for c in range(n_cycles):
-            self.cycle(c)
-        L.call("coevo_mpe_rewards", L._p(self.state), self.plan.n_games, L._p(self.rewards))
+        self.desc.n_cycles = int(n_cycles)
+        ctx = self.ctx if self.overlap else None
+        L.call("coevo_mpe_rollout", L.C.byref(self.desc), ctx, 1 if self.time_light else 0)
+
+    def light_times_ms(self, max_out=100000):
+        buf = (L.C.c_float * max_out)()
+        n = L.load().coevo_rollout_ctx_light_times(self.ctx, buf, max_out)
+        if n < 0:
+            raise L.CoevoError(f"coevo_rollout_ctx_light_times failed with code {n}")
+        return [buf[i] for i in range(n)]
+
+    def reset_timing(self):
+        L.load().coevo_rollout_ctx_reset_timing(self.ctx)
 
     def check_status(self):
         L.raise_on_status(self.status)

@@ -113,6 +113,29 @@ int coevo_mpe_policy_cycle(const float *slab, const coevo_fc_task *tasks, int n_
                            const double *state, int n_games, const int32_t *row_game, const int32_t *row_slot,
                            int32_t *actions, int32_t *status, void *stream);
 
+/* A whole batch of games in one call (play_game/play_MPE at batch scale): n_cycles world cycles, each = the
+ * shared-opponent policy launch (tasks `heavy`, > 8 rows each, matrix cores) on a side stream concurrently with the
+ * per-individual policy launch (tasks `light`, <= 8 rows each, weight streaming) on `stream`, then coevo_mpe_step;
+ * finally coevo_mpe_rewards if `rewards` is not NULL.  ctx (side stream + fork/join events + optional HIP timing
+ * events around every light launch) comes from coevo_rollout_ctx_create and is owned by the caller; ctx == NULL runs
+ * everything on `stream`.  Asynchronous; no host synchronisation. */
+typedef struct {
+    const float *slab;
+    const coevo_fc_task *heavy; int32_t n_heavy; int32_t heavy_max_rows;
+    const coevo_fc_task *light; int32_t n_light; int32_t light_max_rows;
+    double *state; int32_t n_games; int32_t n_cycles;
+    const int32_t *row_game; const int32_t *row_slot; const int32_t *game_rows;
+    int32_t *actions; int32_t *status;
+    const int32_t *game_limit;   /* per game agent-step limit, or NULL */
+    double *rewards;             /* [n_games][3] or NULL */
+    int32_t pos_first; int32_t reserved;
+} coevo_rollout_desc;
+void *coevo_rollout_ctx_create(int n_timing_pairs);
+void coevo_rollout_ctx_destroy(void *ctx);
+int coevo_rollout_ctx_reset_timing(void *ctx);
+int coevo_rollout_ctx_light_times(void *ctx, float *host_ms_out, int max_out);  /* returns the count; blocks */
+int coevo_mpe_rollout(const coevo_rollout_desc *desc, void *ctx, int time_light, void *stream);
+
 /* ---------------------------------------------------------------- K3/K4/K8: offspring on device ------------- */
 /* child = parent + sigma * eps(seed, stream, p), p = canonical flat index; Philox4x32-10 + Box-Muller with
  * fmaf-only polynomials (bit-reproducible against the oracle).  Replaces clone()+Agent.mutate (agent.py:25-29,
