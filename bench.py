@@ -73,6 +73,9 @@ def main():
     ap.add_argument("--limit", type=int, default=200)
     ap.add_argument("--env", default="device", choices=["device", "host"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every launch eagerly instead of replaying the "
+                    "captured hipGraph of a generation's rollout")
+    ap.add_argument("--no-overlap", action="store_true")
     a = ap.parse_args()
 
     from coevonet_amd import lib as L
@@ -95,16 +98,21 @@ def main():
     tr = GATrainer(env, args, rng="device_philox", env_mode=a.env, collect=False, dist_ctx=ctx)
     eng = tr.eng
 
-    for _ in range(a.warmup):
-        tr.step()
     timed = a.env == "device"
-    if timed:  # HIP events around every launch of the dominant kernel, recorded on the launching stream
+    if timed:
+        eng.ro.use_graph = not a.no_graph
+        eng.ro.overlap = not a.no_overlap
+        eng.ro.time_light = True  # before the warm-up, so the (timed) graph is captured outside the timed region
+    for i in range(a.warmup):
+        tr.step()
+    if timed:  # duration of every launch of the dominant kernel in the timed region from here on
+        torch.cuda.synchronize()
+        eng.ro.collect_stamps()
         eng.ro.reset_timing()
-        eng.ro.time_light = True
     ctx.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
         tr.step()
     torch.cuda.synchronize()
     ctx.barrier()
@@ -142,6 +150,10 @@ def main():
             alg_bytes = sum(nets.values()) + rows * (4 * 10 + 4)
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "fc_policy_kernel<5,true> (per-individual weight sets)",
+                               "timing": ("HIP events around each launch on its stream" if a.no_graph else
+                                          "in-kernel 100 MHz clock stamps, first workgroup start to last workgroup "
+                                          "end (HIP events cannot be read back from replayed hipGraphs; "
+                                          "--no-graph uses events)"),
                                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,

@@ -44,12 +44,30 @@ struct FcArgs {
     int32_t *actions;
     float *logits;  // may be null
     int32_t *status;
+    unsigned long long *stamps;  // may be null: [COEVO_STAMP_SLOTS][2] = {min workgroup start, max workgroup end}
 };
+
+// 100 MHz wall clock; the first/last workgroup of a launch bracket its duration (used where HIP events cannot be:
+// inside hipGraph replays)
+// (workgroups spread over COEVO_STAMP_SLOTS slot pairs so that hundreds of simultaneous atomics do not serialise on
+// one address; the host takes the min / max over the slots)
+__device__ inline void stamp_begin(unsigned long long *stamps)
+{
+    if (stamps && threadIdx.x == 0)
+        atomicMin(&stamps[2 * (blockIdx.x % COEVO_STAMP_SLOTS)], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
+__device__ inline void stamp_end(unsigned long long *stamps)
+{
+    if (stamps && threadIdx.x == 0)
+        atomicMax(&stamps[2 * (blockIdx.x % COEVO_STAMP_SLOTS) + 1],
+                  (unsigned long long)__builtin_amdgcn_s_memrealtime());
+}
 
 template <int R, bool FROM_STATE>
 __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
 {
     __shared__ FcSmem<R> sm;
+    stamp_begin(a.stamps);
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
     const coevo_fc_task task = a.tasks[blockIdx.x];
     const int D = task.D, nrows = task.n_rows, row0 = task.row_begin;
@@ -247,6 +265,7 @@ __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
         }
     }
     if (st) atomicOr(a.status, st);
+    stamp_end(a.stamps);
 }
 
 // =====================================================================================================
@@ -280,6 +299,9 @@ template <bool FROM_STATE>
 __global__ __launch_bounds__(256, 2) void fc_policy_mfma_kernel(FcArgs a)
 {
     __shared__ FcMfmaSmem sm;
+    // these workgroups are the long pole of a cycle when they share CUs with the streaming kernel's waves: let their
+    // (few) waves win issue arbitration; the streaming waves are waiting on HBM most of the time anyway
+    __builtin_amdgcn_s_setprio(3);
     const int t = threadIdx.x, w = t >> 6, l = t & 63, lc = l & 31, lh = l >> 5;
     const coevo_fc_task task = a.tasks[blockIdx.x];
     const int D = task.D, nrows = task.n_rows, row0 = task.row_begin;
@@ -541,18 +563,33 @@ extern "C" int coevo_fc_forward_argmax(const float *slab, const coevo_fc_task *t
 {
     if (!slab || !tasks || !obs || !actions || !status || n_tasks < 0) return COEVO_ERR_ARG;
     if (max_rows_per_task < 1 || max_rows_per_task > COEVO_FC_MAX_ROWS) return COEVO_ERR_ARG;
-    coevo::FcArgs a{slab, tasks, obs, nullptr, nullptr, nullptr, 0, actions, logits, status};
+    coevo::FcArgs a{slab, tasks, obs, nullptr, nullptr, nullptr, 0, actions, logits, status, nullptr};
     return coevo::launch_fc<false>(a, n_tasks, max_rows_per_task, (hipStream_t)stream);
 }
+
+extern "C" int coevo_mpe_policy_cycle_stamped(const float *slab, const coevo_fc_task *tasks, int n_tasks,
+                                              int max_rows_per_task, const double *state, int n_games,
+                                              const int32_t *row_game, const int32_t *row_slot, int32_t *actions,
+                                              int32_t *status, uint64_t *stamps, void *stream);
 
 extern "C" int coevo_mpe_policy_cycle(const float *slab, const coevo_fc_task *tasks, int n_tasks,
                                       int max_rows_per_task, const double *state, int n_games,
                                       const int32_t *row_game, const int32_t *row_slot, int32_t *actions,
                                       int32_t *status, void *stream)
 {
+    return coevo_mpe_policy_cycle_stamped(slab, tasks, n_tasks, max_rows_per_task, state, n_games, row_game, row_slot,
+                                          actions, status, nullptr, stream);
+}
+
+extern "C" int coevo_mpe_policy_cycle_stamped(const float *slab, const coevo_fc_task *tasks, int n_tasks,
+                                              int max_rows_per_task, const double *state, int n_games,
+                                              const int32_t *row_game, const int32_t *row_slot, int32_t *actions,
+                                              int32_t *status, uint64_t *stamps, void *stream)
+{
     if (!slab || !tasks || !state || !row_game || !row_slot || !actions || !status) return COEVO_ERR_ARG;
     if (n_tasks < 0 || n_games <= 0) return COEVO_ERR_ARG;
     if (max_rows_per_task < 1 || max_rows_per_task > COEVO_FC_MAX_ROWS) return COEVO_ERR_ARG;
-    coevo::FcArgs a{slab, tasks, nullptr, state, row_game, row_slot, n_games, actions, nullptr, status};
+    coevo::FcArgs a{slab, tasks, nullptr, state, row_game, row_slot, n_games, actions, nullptr, status,
+                    reinterpret_cast<unsigned long long *>(stamps)};
     return coevo::launch_fc<true>(a, n_tasks, max_rows_per_task, (hipStream_t)stream);
 }

@@ -10,6 +10,14 @@
 
 #include "coevo_common.hip.h"
 
+__global__ void stamps_init_kernel(uint64_t *stamps, int n)
+{
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        stamps[2 * i] = ~0ull;
+        stamps[2 * i + 1] = 0ull;
+    }
+}
+
 struct coevo_rollout_ctx {
     hipStream_t side = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
@@ -20,7 +28,9 @@ struct coevo_rollout_ctx {
 extern "C" void *coevo_rollout_ctx_create(int n_timing_pairs)
 {
     auto *c = new coevo_rollout_ctx();
-    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+    int prio_lo = 0, prio_hi = 0;  // numerically lowest = highest priority
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->join, hipEventDisableTiming) != hipSuccess) {
         delete c;
@@ -73,6 +83,14 @@ extern "C" int coevo_mpe_rollout(const coevo_rollout_desc *d, void *ctx, int tim
     auto *c = static_cast<coevo_rollout_ctx *>(ctx);
     hipStream_t main_s = (hipStream_t)stream;
     const bool two = c && d->n_heavy > 0 && d->n_light > 0;
+    // HIP events cannot be read back from inside a captured graph (external event-record nodes are rejected by this
+    // runtime), so event timing is for eager enqueues only; graph replays use the kernels' own clock stamps instead
+    auto record_timing = [&](hipEvent_t e) { return hipEventRecord(e, main_s); };
+    if (d->light_stamps && d->n_cycles > 0) {  // [cycle][2] = {UINT64_MAX, 0}, re-armed by every enqueue / replay
+        hipLaunchKernelGGL(stamps_init_kernel, dim3(1), dim3(256), 0, main_s, d->light_stamps,
+                           d->n_cycles * COEVO_STAMP_SLOTS);
+        COEVO_HIP_CHECK(hipGetLastError());
+    }
     for (int cyc = 0; cyc < d->n_cycles; ++cyc) {
         int rc;
         if (two) {
@@ -87,12 +105,13 @@ extern "C" int coevo_mpe_rollout(const coevo_rollout_desc *d, void *ctx, int tim
         }
         if (d->n_light > 0) {
             const bool timed = time_light && c && (size_t)(2 * c->pairs_used + 1) < c->timing.size();
-            if (timed) COEVO_HIP_CHECK(hipEventRecord(c->timing[2 * c->pairs_used], main_s));
-            rc = coevo_mpe_policy_cycle(d->slab, d->light, d->n_light, d->light_max_rows, d->state, d->n_games,
-                                        d->row_game, d->row_slot, d->actions, d->status, main_s);
+            if (timed) COEVO_HIP_CHECK(record_timing(c->timing[2 * c->pairs_used]));
+            rc = coevo_mpe_policy_cycle_stamped(d->slab, d->light, d->n_light, d->light_max_rows, d->state,
+                                                d->n_games, d->row_game, d->row_slot, d->actions, d->status,
+                                                d->light_stamps ? d->light_stamps + 2 * COEVO_STAMP_SLOTS * cyc : nullptr, main_s);
             if (rc) return rc;
             if (timed) {
-                COEVO_HIP_CHECK(hipEventRecord(c->timing[2 * c->pairs_used + 1], main_s));
+                COEVO_HIP_CHECK(record_timing(c->timing[2 * c->pairs_used + 1]));
                 ++c->pairs_used;
             }
         }

@@ -216,6 +216,8 @@ class GAEngine:
     def eval_rewards(self):
         """mean reward triple (agent_0, agent_1, adversary_0) of the 10 evaluation games in the last rollout"""
         self.ro.check_status()
+        if hasattr(self.ro, "collect_stamps"):
+            self.ro.collect_stamps()  # check_status synchronised: this replay's kernel clock stamps are final
         r = self.rewards_host()[self.n_main:]
         tot = [0.0, 0.0, 0.0]
         for g in range(N_EVAL):  # python-float accumulation order of evaluate_current_weights

@@ -18,6 +18,7 @@ OBS_STRIDE = 12
 LOGIT_STRIDE = 8
 FC_MAX_ROWS = 32
 MPE_STATE_DOUBLES = 24
+STAMP_SLOTS = 32
 ST_NAMES = {1: "input contains inf or NaN", 2: "output contains inf or NaN after fc1",
             4: "output contains inf or NaN after fc2", 8: "output contains inf or NaN",
             16: "no action selected (current_best_position = -1)"}
@@ -43,7 +44,8 @@ class RolloutDesc(C.Structure):
                 ("state", C.c_void_p), ("n_games", C.c_int32), ("n_cycles", C.c_int32),
                 ("row_game", C.c_void_p), ("row_slot", C.c_void_p), ("game_rows", C.c_void_p),
                 ("actions", C.c_void_p), ("status", C.c_void_p), ("game_limit", C.c_void_p),
-                ("rewards", C.c_void_p), ("pos_first", C.c_int32), ("reserved", C.c_int32)]
+                ("rewards", C.c_void_p), ("pos_first", C.c_int32), ("reserved", C.c_int32),
+                ("light_stamps", C.c_void_p)]
 
 
 class CoevoError(RuntimeError):
@@ -71,6 +73,9 @@ _SIGS = {
     "coevo_rollout_ctx_reset_timing": (C.c_int, [C.c_void_p]),
     "coevo_rollout_ctx_light_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "coevo_mpe_rollout": (C.c_int, [C.POINTER(RolloutDesc), C.c_void_p, C.c_int, C.c_void_p]),
+    "coevo_mpe_policy_cycle_stamped": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p]),
     "coevo_fc_perturb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]),
     "coevo_fc_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

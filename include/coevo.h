@@ -45,6 +45,7 @@ extern "C" {
 #define COEVO_OBS_STRIDE 12      /* floats per observation row in obs buffers (D = 8 or 10, zero padded) */
 #define COEVO_LOGIT_STRIDE 8     /* floats per logits row */
 #define COEVO_FC_MAX_ROWS 32     /* rows (observations) one task may carry */
+#define COEVO_STAMP_SLOTS 32     /* clock-stamp slot pairs per timed launch (see coevo_mpe_policy_cycle_stamped) */
 
 /* env slots, PettingZoo agent order of simple_adversary_v3 */
 #define COEVO_SLOT_ADVERSARY 0
@@ -129,12 +130,23 @@ typedef struct {
     const int32_t *game_limit;   /* per game agent-step limit, or NULL */
     double *rewards;             /* [n_games][3] or NULL */
     int32_t pos_first; int32_t reserved;
+    uint64_t *light_stamps;      /* [n_cycles][COEVO_STAMP_SLOTS][2] or NULL: per light launch and slot {earliest
+                                    workgroup start, latest workgroup end} in 100 MHz s_memrealtime ticks (min / max
+                                    over the slots = the launch) - kernel timing that survives graph replay */
 } coevo_rollout_desc;
 void *coevo_rollout_ctx_create(int n_timing_pairs);
 void coevo_rollout_ctx_destroy(void *ctx);
 int coevo_rollout_ctx_reset_timing(void *ctx);
 int coevo_rollout_ctx_light_times(void *ctx, float *host_ms_out, int max_out);  /* returns the count; blocks */
 int coevo_mpe_rollout(const coevo_rollout_desc *desc, void *ctx, int time_light, void *stream);
+
+/* coevo_mpe_policy_cycle that also brackets the launch with device clock stamps: stamps[COEVO_STAMP_SLOTS][2],
+ * workgroup b folds its start into stamps[b % SLOTS][0] (min) and its end into [..][1] (max); caller-initialised to
+ * {UINT64_MAX, 0}; stamps may be NULL */
+int coevo_mpe_policy_cycle_stamped(const float *slab, const coevo_fc_task *tasks, int n_tasks, int max_rows_per_task,
+                                   const double *state, int n_games, const int32_t *row_game,
+                                   const int32_t *row_slot, int32_t *actions, int32_t *status, uint64_t *stamps,
+                                   void *stream);
 
 /* ---------------------------------------------------------------- K3/K4/K8: offspring on device ------------- */
 /* child = parent + sigma * eps(seed, stream, p), p = canonical flat index; Philox4x32-10 + Box-Muller with

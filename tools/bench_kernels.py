@@ -55,6 +55,15 @@ def main():
         L.call("coevo_mpe_step", L._p(ro.state), p.n_games, L._p(p.game_rows), L._p(ro.actions), 0,
                L._p(ro.limits), ro.pos_first)
 
+    stamps = torch.zeros(L.STAMP_SLOTS, 2, dtype=torch.int64, device="cuda")
+
+    def light_stamped():
+        L.call("coevo_mpe_policy_cycle_stamped", L._p(ro.slab), L._p(p.light), len(p.light_np), p.light_max,
+               L._p(ro.state), p.n_games, L._p(p.row_game), L._p(p.row_slot), L._p(ro.actions), L._p(ro.status),
+               L._p(stamps))
+
+    med, mn = timeit(light_stamped, a.reps)
+    print(f"light with clock stamps: median {med:7.1f} us  min {mn:7.1f} us")
     light_bytes = sum({int(t["net_off"]): L.fc_param_count(int(t["D"])) * 4 for t in p.light_np}.values())
     heavy_bytes = sum(L.fc_param_count(int(t["D"])) * 4 for t in p.heavy_np)
     for name, fn, nbytes in (("light (VALU, per-individual nets)", light, light_bytes),
