@@ -21,9 +21,10 @@ def allgather_shards(local: torch.Tensor, world: int) -> torch.Tensor:
     if world == 1:
         return local
     R, n_local, Cc = local.shape
-    out = torch.empty(world, R, n_local, Cc, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous())
-    return out.permute(1, 0, 2, 3).reshape(R, world * n_local, Cc)
+    flat_in = local.contiguous().reshape(-1)
+    out = torch.empty(world * flat_in.numel(), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, flat_in)  # flat in, flat out: the form both RCCL and gloo accept
+    return out.reshape(world, R, n_local, Cc).permute(1, 0, 2, 3).reshape(R, world * n_local, Cc)
 
 
 class DistContext:

@@ -1,0 +1,141 @@
+"""Host-side mirror of the reference interface (no GPU): parameter layout, RNG-order parity of construction and
+mutation with the reference's fixtures, plan building, sigma adaptation, loud failure without the HIP library."""
+import numpy as np
+import pytest
+import torch
+
+from coevonet_amd import lib as L
+from coevonet_amd.agent import MPEAgent
+from coevonet_amd.fcnetwork import FCNetwork
+from coevonet_amd.game_logic import create_agent, diversity_penalty, initialize_env, play_game
+from coevonet_amd.genetic_algorithm import adapt_mutation_power, initial_population
+from coevonet_amd.rollout import RolloutPlan, effective_steps
+from tests.util import Bag, load_golden, sha
+
+
+def test_fcnetwork_matches_reference_weights_and_mutation():
+    """same torch seed -> byte-identical parameters as the reference's FCNetwork (fixture sha), also after
+    Agent.mutate (every parameter, LayerNorm affine included)"""
+    for case in load_golden("fc_forward.json")["cases"]:
+        torch.manual_seed(case["torch_seed"])
+        args = Bag()
+        net = FCNetwork(case["D"], 5, "float32")
+        if case["mutated"]:
+            for p in net.parameters():
+                p.data += torch.normal(0, 0.05, size=p.size())
+        assert sha(net.flat()) == case["weights"]["sha256"]
+        assert net.flat().size == L.fc_param_count(case["D"])
+
+
+def test_weight_get_set_surface():
+    torch.manual_seed(0)
+    args = Bag()
+    net = FCNetwork(10, 5, "float32")
+    es = net.get_weights_ES()
+    per = net.get_perturbable_weights()
+    assert es.shape == per.shape == (138245,) and np.array_equal(es, per)  # LayerNorm excluded
+    assert [n for n, _ in net.named_modules()] == ["", "fc1", "ln1", "fc2", "ln2", "output"]
+    net.set_perturbable_weights(per + 1.0, args)
+    assert np.allclose(net.get_perturbable_weights(), per + 1.0)
+    assert np.all(net.state_dict()["ln1.weight"].numpy() == 1.0)  # untouched
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    other = FCNetwork(10, 5, "float32")
+    other.load_state_dict(sd)
+    assert sha(other.flat()) == sha(net.flat())
+    with pytest.raises(ValueError):
+        net.set_weights({"fc1.weight": torch.zeros(3, 3)}, layers=["fc1"])
+    with pytest.raises(ValueError):
+        FCNetwork(10, 5, "float16")
+
+
+def test_agent_clone_and_create_order_consume_rng_like_reference():
+    fx = load_golden("play_game.json")["cases"][0]
+    torch.manual_seed(fx["torch_seed"])
+    args = Bag()
+    env = initialize_env(args)
+    agents = [create_agent(env, args, r) for r in ("agent_0", "agent_1", "adversary_0")]
+    assert [sha(a.model.flat()) for a in agents] == [w["sha256"] for w in fx["weights"]]
+    c = agents[0].clone(env, args, "agent_0")
+    assert isinstance(c, MPEAgent) and sha(c.model.flat()) == sha(agents[0].model.flat())
+    with pytest.raises(ValueError):
+        create_agent(env, Bag(game="pong_v3"), None)
+    with pytest.raises(ValueError):
+        play_game(env, agents[0].model, agents[1].model, None, args)
+
+
+def test_initial_population_matches_ga_fixture_weights():
+    """creation order of genetic_algorithm.py:63-68,110-117: generation-0 HoF members are what the fixture's saved
+    HoF lists contain before the first push"""
+    fx = load_golden("ga_hof2.json")
+    cfg = fx["config"]
+    torch.manual_seed(cfg["seed"])
+    args = Bag(algorithm="GA", **cfg["args"])
+    env = initialize_env(args)
+    pop_flat, hof_flat = initial_population(env, args)
+    saves = {s["file"]: s["agents"] for s in fx["generations"][0]["saves"]}
+    # after generation 0 the HoF is [initial hof[1], best]: the survivor must be the initial member 1
+    assert sha(hof_flat["agent_0"][1]) == saves["hall_of_fame_agent_0.pth"][0]["sha256"]
+    assert sha(hof_flat["adversary_0"][1]) == saves["hall_of_fame_adversary.pth"][0]["sha256"]
+    best = fx["generations"][0]["elite_ids"][0][0]
+    assert sha(pop_flat["agent_0"][best]) == saves["hall_of_fame_agent_0.pth"][1]["sha256"]
+
+
+def test_rollout_plan_groups_rows_by_weight_set():
+    pop, hof = 7, 3
+    games, off, D = [], {}, {}
+    for i in range(pop):
+        off[i], D[i] = 1000 * i, 10
+    for k in range(hof):
+        off[100 + k], D[100 + k] = 10 ** 6 + k, 10
+        off[200 + k], D[200 + k] = 2 * 10 ** 6 + k, 8
+    for i in range(pop):
+        for k in range(hof):
+            games.append((200 + k, i, 100 + k))
+    plan = RolloutPlan(np.array(games), off, D, device=None)
+    assert plan.n_rows == 3 * len(games)
+    assert len(plan.light_np) == pop + 2 * hof and plan.light_max == pop and len(plan.heavy_np) == 0
+    rows_seen = set()
+    for t in plan.light_np:
+        rows = range(int(t["row_begin"]), int(t["row_begin"]) + int(t["n_rows"]))
+        for r in rows:
+            g, slot = plan.row_game_np[r], plan.row_slot_np[r]
+            assert off[games[g][slot]] == int(t["net_off"]) and plan.game_rows_np[g, slot] == r
+            rows_seen.add(r)
+    assert rows_seen == set(range(plan.n_rows))
+    big = RolloutPlan(np.array([(200, i, 100) for i in range(70)]), {**{i: i for i in range(70)}, 100: 5000, 200: 9000},
+                      {**{i: 10 for i in range(70)}, 100: 10, 200: 8}, device=None)
+    assert [int(t["n_rows"]) for t in big.heavy_np] == [32, 32, 6, 32, 32, 6] and big.heavy_max == 32
+    with pytest.raises(AssertionError):
+        RolloutPlan(np.array([(0, 0, 0)]), {0: 0}, {0: 10}, device=None)  # a 10-wide net in the adversary seat
+
+
+def test_effective_steps_and_sigma_adaptation():
+    assert effective_steps(None, 25) == 75 and effective_steps(200, 25) == 75 and effective_steps(50, 25) == 50
+    assert effective_steps(200, 70) == 200
+    args = Bag(mutation_power_agent_0=0.05, mutation_power_agent_1=0.1, mutation_power_adversary=0.05,
+               max_mutation_power=0.2, min_mutation_power=0.001)
+    hist = {"agent_0": list(range(20, 0, -1)), "agent_1": list(range(20)), "adversary_0": [0.0] * 20}
+    adapt_mutation_power(args, 19, hist)
+    assert args.mutation_power_agent_0 == pytest.approx(0.1 * 1.2)  # quirk Q5: agent_1's sigma is the base
+    assert args.mutation_power_agent_1 == pytest.approx(0.1 * 0.95)
+    assert args.mutation_power_adversary == pytest.approx(0.05 * 0.95)
+    adapt_mutation_power(args, 5, hist)  # gen <= 10: always decay
+    assert args.mutation_power_agent_0 == pytest.approx(0.12 * 0.95)
+
+
+def test_diversity_penalty_host_version():
+    g = np.random.Generator(np.random.PCG64(0))
+    w = [g.normal(size=50).astype(np.float32) for _ in range(6)]
+    d = diversity_penalty(w[-1], w, Bag())
+    dist = np.array([np.linalg.norm(x - w[-1]) for x in w])
+    assert d == pytest.approx(np.sum(np.maximum(0, 1 - dist / dist.mean())))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """no CPU fallback: without libcoevo.so every product entry point raises"""
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "libcoevo.so"))
+    with pytest.raises(L.CoevoError):
+        L.load()
+    with pytest.raises(L.CoevoError):
+        L.fc_param_count(10)
