@@ -1,0 +1,294 @@
+"""Co-ES on the MI355X: drop-in ``evolution_strategy_train(env, args, output_dir)`` (reference
+evolutionary_strategy.py:151) over the batched rollout engine.
+
+Reference semantics kept: per generation ``pop`` iterations x 3 roles, each one
+perturbed copy of the role's base net (Linear weights/biases only, LayerNorm untouched) playing ONE game against the two
+current base nets, in the interleaved order agent_0, agent_1, adversary_0 (game ordinal 3j+role); the role's reward slot
+(subject to quirk Q1) is the raw fitness - no rank transform, no antithetic pairs; update theta += lr/(n*sigma) *
+sum_i f_i eps_i; optional fitness sharing f/(1+D); 10 evaluation games of the updated trio; adaptive sigma (Q5);
+early stopping.  hof_size is unused, as in the reference (Q12).
+
+rng modes
+  "host_reference"  noise from the global numpy generator in the reference's call order, perturbed nets and the update
+                    computed on the host exactly as the reference does (fp64 noise, fp32 GEMV) and uploaded - parity;
+  "device_philox"   perturbed nets are materialised once per generation on the device from counter-based noise and the
+                    update regenerates the same noise (no noise matrix is ever stored: the reference keeps n x P).
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .game_logic import create_agent
+from .genetic_algorithm import N_EVAL, RET_SLOT, ROLE_D, ROLES, SIGMA_ATTR, adapt_mutation_power
+from .mpe.simple_adversary import ENV_SEED
+from .rollout import DeviceRollout, HostEnvRollout, RolloutPlan, effective_steps
+
+
+class ESEngine:
+    def __init__(self, pop, limit_train=None, limit_eval=None, max_cycles=25, device="cuda", env_seed=ENV_SEED,
+                 rng="device_philox", philox_seed=0, env="device", first_ordinal=1):
+        self.pop, self.rng_mode, self.philox_seed, self.env_mode, self.device = pop, rng, int(philox_seed), env, device
+        self.T_train = effective_steps(limit_train, max_cycles)
+        self.T_eval = effective_steps(limit_eval, max_cycles)
+        self.n_cycles = (max(self.T_train, self.T_eval) + 2) // 3
+        self.first_ordinal = first_ordinal
+        self.stride = {r: L.fc_slab_stride(ROLE_D[r]) for r in ROLES}
+        self.P = {r: L.fc_param_count(ROLE_D[r]) for r in ROLES}
+        self.base, off = {}, 0
+        for r in ROLES:
+            self.base[r] = {"base": off, "pert": off + self.stride[r]}
+            off += (1 + pop) * self.stride[r]
+        self.slab = torch.zeros(off, dtype=torch.float32, device=device)
+        net_off, net_D, ids = [], [], {}
+
+        def net(region, role, i=0):
+            key = (region, role, i)
+            if key not in ids:
+                ids[key] = len(net_off)
+                net_off.append(self.base[role][region] + i * self.stride[role])
+                net_D.append(ROLE_D[role])
+            return ids[key]
+
+        games = []
+        for j in range(pop):  # evolutionary_strategy.py:236-251: mutate_weights for agent_0, agent_1, adversary_0
+            for r in ROLES:
+                seat = {q: net("base", q) for q in ROLES}
+                seat[r] = net("pert", r, j)
+                games.append((seat["adversary_0"], seat["agent_0"], seat["agent_1"]))
+        self.n_main = len(games)
+        # Unlike Co-GA, the evaluation games cannot ride in the next generation's launch: generation g+1 perturbs with
+        # sigma_{g+1}, which the adaptive rule derives from generation g's evaluation (evolutionary_strategy.py:272-316).
+        # They get their own 10-game rollout after each update.
+        eval_games = [(net("base", "adversary_0"), net("base", "agent_0"), net("base", "agent_1"))] * N_EVAL
+        cls = DeviceRollout if env == "device" else HostEnvRollout
+        self.plan = RolloutPlan(np.array(games), net_off, net_D, device=device)
+        self.ro = cls(self.plan, self.slab, env_seed=env_seed)
+        self.eval_plan = RolloutPlan(np.array(eval_games), net_off, net_D, device=device)
+        self.eval_ro = cls(self.eval_plan, self.slab, env_seed=env_seed)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.fitness = {r: torch.zeros(pop, **f32) for r in ROLES}
+        self.dist = {r: torch.zeros(pop, **f32) for r in ROLES}
+        self.div = {r: torch.zeros(1, **f32) for r in ROLES}
+        self.sigma = {r: torch.zeros(1, **f32) for r in ROLES}
+        self.zero_idx = torch.zeros(pop, dtype=torch.int32, device=device)
+        self.game_idx = {r: torch.arange(pop, device=device) * 3 + ri for ri, r in enumerate(ROLES)}
+        self.steps_per_generation = 3 * pop * self.T_train + N_EVAL * self.T_eval
+
+    def _ptr(self, role, region, i=0):
+        return self.slab.data_ptr() + 4 * (self.base[role][region] + i * self.stride[role])
+
+    def upload(self, role, region, first, flat_np):
+        flat = torch.from_numpy(np.ascontiguousarray(flat_np, dtype=np.float32)).to(self.device)
+        L.call("coevo_fc_pack", L._p(flat), self._ptr(role, region, first), flat.shape[0], ROLE_D[role])
+        return flat
+
+    def download(self, role, region, first, n):
+        out = torch.zeros(n, self.P[role], dtype=torch.float32, device=self.device)
+        L.call("coevo_fc_unpack", self._ptr(role, region, first), L._p(out), n, ROLE_D[role])
+        return out.cpu().numpy()
+
+    def _ordinal_base(self, gen):
+        return self.first_ordinal + gen * (3 * self.pop + N_EVAL)
+
+    def perturb_device(self, gen, sigmas):
+        for ri, r in enumerate(ROLES):
+            self.sigma[r].fill_(float(sigmas[r]))
+            L.call("coevo_fc_perturb", self._ptr(r, "base"), L._p(self.zero_idx), self._ptr(r, "pert"), 0, self.pop,
+                   ROLE_D[r], L._p(self.sigma[r]), self.philox_seed, 0, gen * 4 + ri, 1)
+
+    def rollout(self, gen):
+        """the 3*pop training games of generation `gen` (game ordinal 3j + role in the seeded stream)"""
+        ro = self.ro
+        ro.set_limits(np.full(self.plan.n_games, self.T_train, dtype=np.int32))
+        if self.env_mode == "device":
+            ro.reset(0, self.n_main, self._ordinal_base(gen))
+        else:
+            ro.reset_from_ordinals(self._ordinal_base(gen) + np.arange(self.n_main))
+        ro.run((self.T_train + 2) // 3)
+
+    def evaluate(self, gen):
+        """evaluate_current_weights: 10 games of the current base trio -> mean reward triple (:22-59, :272)"""
+        ro = self.eval_ro
+        ro.set_limits(np.full(N_EVAL, self.T_eval, dtype=np.int32))
+        first = self._ordinal_base(gen) + 3 * self.pop
+        if self.env_mode == "device":
+            ro.reset(0, N_EVAL, first)
+        else:
+            ro.reset_from_ordinals(first + np.arange(N_EVAL))
+        ro.run((self.T_eval + 2) // 3)
+        ro.check_status()
+        r = ro.rewards.cpu().numpy() if torch.is_tensor(ro.rewards) else ro.rewards
+        tot = [0.0, 0.0, 0.0]
+        for g in range(N_EVAL):
+            for s in range(3):
+                tot[s] += float(r[g, s])
+        return [t / 10 for t in tot]
+
+    def rewards_host(self):
+        r = self.ro.rewards
+        return r.cpu().numpy() if torch.is_tensor(r) else r
+
+    def update_device(self, gen, lr, fitness_sharing):
+        """compute_weight_update (evolutionary_strategy.py:120-148) + base += update, on the device"""
+        rew = self.ro.rewards if torch.is_tensor(self.ro.rewards) else torch.from_numpy(self.ro.rewards).to(self.device)
+        for ri, r in enumerate(ROLES):
+            f = rew[self.game_idx[r], RET_SLOT[r]].to(torch.float32)  # np.array(rewards, dtype=float32)
+            if fitness_sharing:
+                L.call("coevo_fc_diversity", self._ptr(r, "base"), self._ptr(r, "pert"), self.pop, ROLE_D[r],
+                       L._p(self.dist[r]), L._p(self.div[r]))
+                f = f / (1.0 + self.div[r])
+            self.fitness[r].copy_(f)
+            L.call("coevo_es_update", self._ptr(r, "base"), ROLE_D[r], L._p(self.fitness[r]), self.pop,
+                   L._p(self.sigma[r]), L.C.c_float(lr), self.philox_seed, 0, gen * 4 + ri)
+
+
+class ESResult:
+    def __init__(self):
+        self.rewards = {r: [] for r in ROLES}
+        self.diversity, self.sigma_after, self.game_rewards, self.seconds = [], [], [], []
+        self.stopped_at = None
+
+
+def _linear_mask(D):
+    """boolean mask over the flat parameter vector: True on Linear weights/biases (the perturbable entries)"""
+    from .fcnetwork import param_shapes
+    m = []
+    for name, shp in param_shapes(D):
+        m.append(np.full(int(np.prod(shp)), not name.startswith("ln"), dtype=bool))
+    return np.concatenate(m)
+
+
+class ESTrainer:
+    def __init__(self, env, args, rng=None, env_mode=None, collect=True):
+        self.env, self.args, self.collect = env, args, collect
+        self.rng = rng or getattr(args, "coevo_rng", "host_reference")
+        env_mode = env_mode or getattr(args, "coevo_env", "device")
+        self.first_ordinal = getattr(env, "n_resets", 1)
+        agents = {r: create_agent(env, args, role=r) for r in ROLES}  # evolutionary_strategy.py:163-165
+        self.eng = ESEngine(args.population, args.max_timesteps_per_episode, args.max_evaluation_steps,
+                            max_cycles=getattr(env, "max_cycles", 25), rng=self.rng,
+                            philox_seed=getattr(args, "coevo_seed", 0), env=env_mode,
+                            first_ordinal=self.first_ordinal,
+                            env_seed=getattr(env, "seed_value", ENV_SEED) or ENV_SEED)
+        keep = [self.eng.upload(r, "base", 0, agents[r].model.flat()[None]) for r in ROLES]
+        torch.cuda.current_stream().synchronize()
+        self.base_flat = {r: agents[r].model.flat().copy() for r in ROLES}  # host copy (host_reference mode)
+        self.mask = {r: _linear_mask(ROLE_D[r]) for r in ROLES}
+        self.res = ESResult()
+        self.gen = 0
+        self.best = {r: -float("inf") for r in ROLES}
+        self.no_improve = {r: 0 for r in ROLES}
+
+    # -- host_reference: the reference's own numpy calls, in its order ------------------------------------------
+    def _perturb_host(self):
+        args, eng, pop = self.args, self.eng, self.args.population
+        self.noises = {r: np.empty((pop, int(self.mask[r].sum())), dtype=np.float32) for r in ROLES}
+        pert = {r: np.repeat(self.base_flat[r][None], pop, axis=0) for r in ROLES}
+        for j in range(pop):
+            for r in ROLES:
+                w = self.base_flat[r][self.mask[r]]
+                noise = np.random.normal(loc=0.0, scale=getattr(args, SIGMA_ATTR[r]), size=len(w))  # agent.py:52
+                pert[r][j, self.mask[r]] = (w + noise).astype(np.float32)   # torch.tensor(..., float32)
+                self.noises[r][j] = noise.astype(np.float32)                # evolutionary_strategy.py:74
+        keep = [eng.upload(r, "pert", 0, pert[r]) for r in ROLES]
+        torch.cuda.current_stream().synchronize()
+        self.pert_host = pert
+
+    def _update_host(self):
+        args, eng = self.args, self.eng
+        rew = eng.rewards_host()
+        divs = []
+        for ri, r in enumerate(ROLES):
+            f = np.array([rew[3 * j + ri, RET_SLOT[r]] for j in range(args.population)], dtype=np.float32)
+            div = None
+            if args.fitness_sharing:
+                base_w = self.base_flat[r][self.mask[r]]
+                d = np.array([np.linalg.norm(p[self.mask[r]] - base_w) for p in self.pert_host[r]])
+                div = np.sum(np.maximum(0, 1 - d / np.mean(d)))
+                f = f / (1 + div)
+            sigma = getattr(args, SIGMA_ATTR[r])
+            upd = (args.learning_rate / (len(self.noises[r]) * sigma)) * np.dot(self.noises[r].T, f)
+            new = self.base_flat[r].copy()
+            new[self.mask[r]] = self.base_flat[r][self.mask[r]] + upd.astype(np.float32)
+            self.base_flat[r] = new
+            divs.append(None if div is None else float(div))
+        keep = [eng.upload(r, "base", 0, self.base_flat[r][None]) for r in ROLES]
+        torch.cuda.current_stream().synchronize()
+        return divs
+
+    def step(self):
+        """one generation in the reference's order: perturb (sigma_g) -> 3*pop games -> update -> 10 evaluation games
+        -> adaptive sigma / early stopping.  Returns False when early stopping fired."""
+        eng, args, res, gen = self.eng, self.args, self.res, self.gen
+        t0 = time.perf_counter()
+        sigmas = {r: getattr(args, SIGMA_ATTR[r]) for r in ROLES}
+        if self.rng == "host_reference":
+            self._perturb_host()
+        else:
+            eng.perturb_device(gen, sigmas)
+        eng.rollout(gen)
+        if self.rng == "host_reference":
+            eng.ro.check_status()
+            divs = self._update_host()
+        else:
+            eng.update_device(gen, args.learning_rate, args.fitness_sharing)
+            divs = [float(eng.div[r].item()) if args.fitness_sharing else None for r in ROLES] if self.collect else None
+        if self.collect:
+            res.game_rewards.append(eng.rewards_host()[:eng.n_main].copy())
+            res.diversity.append(divs)
+        stop = self._finish_generation(gen, eng.evaluate(gen))
+        res.seconds.append(time.perf_counter() - t0)
+        self.gen += 1
+        return not stop
+
+    def _finish_generation(self, gen, ev):
+        """bookkeeping after generation `gen`'s evaluation games; returns True when early stopping fires"""
+        args, res = self.args, self.res
+        for s, r in enumerate(ROLES):
+            res.rewards[r].append(ev[s])
+        if args.adaptive:
+            adapt_mutation_power(args, gen, res.rewards)
+        res.sigma_after.append([args.mutation_power_agent_0, args.mutation_power_agent_1, args.mutation_power_adversary])
+        if getattr(args, "early_stopping", False):  # evolutionary_strategy.py:320-354
+            for s, r in enumerate(ROLES):
+                if ev[s] > self.best[r] + args.min_delta:
+                    self.best[r], self.no_improve[r] = ev[s], 0
+                else:
+                    self.no_improve[r] += 1
+            for r in ROLES:
+                if self.no_improve[r] >= args.patience:
+                    res.stopped_at = gen
+                    return True
+        return False
+
+    def finish(self):
+        self.eng.ro.check_status()
+        if hasattr(self.env, "n_resets"):
+            self.env.n_resets = self.first_ordinal + self.gen * (3 * self.args.population + N_EVAL)
+        return self.res
+
+    def base_agents(self):
+        """the three trained agents, as the reference returns them (evolutionary_strategy.py:393)"""
+        out = []
+        for r in ROLES:
+            a = create_agent(self.env, self.args, role=r)
+            a.model.set_flat(self.eng.download(r, "base", 0, 1)[0])
+            out.append(a)
+        return tuple(out)
+
+
+def evolution_strategy_train(env, args, output_dir, rng=None, env_mode=None, collect=True, return_result=False):
+    """Drop-in for evolutionary_strategy.py:151: returns (agent_0, agent_1, adversary) like the reference; with
+    return_result=True also the ESResult history (what the reference only plots)."""
+    tr = ESTrainer(env, args, rng=rng, env_mode=env_mode, collect=collect)
+    for _ in range(args.generations):
+        if not tr.step():
+            break
+    res = tr.finish()
+    res.engine = tr.eng
+    agents = tr.base_agents()
+    return (agents, res) if return_result else agents

@@ -321,7 +321,25 @@ def set_perturbable(flat, D, vec):
     return out
 
 
-def es_train(args, max_cycles=25):
+def es_update_philox(theta, D, fitness, sigma, lr, seed, stream_hi):
+    """theta += lr/(n*sigma) * sum_i f_i * (sigma*eps_i) with regenerated counter-based noise (device_philox mode)"""
+    P = param_count(D)
+    out = np.ascontiguousarray(theta, dtype=np.float32).copy()
+    segs = ln_segments(D)
+    so = np.array([s[0] for s in segs], dtype=np.int32)
+    sl = np.array([s[1] for s in segs], dtype=np.int32)
+    f = np.ascontiguousarray(fitness, dtype=np.float32)
+    n = len(f)
+    scale = np.float32(lr) / (np.float32(n) * np.float32(sigma))
+    lib().oracle_es_update_philox(_fp(out), P, _fp(f), n, float(np.float32(sigma)), float(scale), int(seed),
+                                  int(stream_hi), _ip(so), _ip(sl), len(segs))
+    return out
+
+
+def es_train(args, max_cycles=25, noise="numpy", philox_seed=0):
+    """evolution_strategy_train restated; noise="numpy": the reference's own RNG calls; noise="philox": the build's
+    device_philox rule (perturbed net j of role ri in generation g uses stream (j, 4g+ri), fp32 noise, fp32 update)."""
+    mode = noise
     stream = Stream()
     D = ROLE_D
     base = {r: init_net(D[r]) for r in ROLES}  # evolutionary_strategy.py:163-165
@@ -337,8 +355,19 @@ def es_train(args, max_cycles=25):
         pop_w = {r: [] for r in ROLES}
         for _ in range(args.population):
             for s, r in enumerate(ROLES):
-                init_net(D[r])  # clone() constructs a fresh net (torch RNG only)
                 sigma = getattr(args, sig_attr[r])
+                if mode == "philox":
+                    mutated = mutate_philox(base[r], D[r], np.float32(sigma), philox_seed, _, gen * 4 + s,
+                                            skip_layernorm=True)
+                    nets = {q: base[q] for q in ROLES}
+                    nets[r] = mutated
+                    g = play_game(stream, nets["agent_0"], nets["agent_1"], nets["adversary_0"],
+                                  args.max_timesteps_per_episode, max_cycles)
+                    rec["games"].append(g)
+                    rewards[r].append(g["rewards"][s])
+                    pop_w[r].append(weights_es(mutated, D[r]))
+                    continue
+                init_net(D[r])  # clone() constructs a fresh net (torch RNG only)
                 w = perturbable(base[r], D[r])
                 noise = np.random.normal(loc=0.0, scale=sigma, size=len(w))  # agent.py:52, fp64
                 mutated = set_perturbable(base[r], D[r], (w + noise).astype(np.float32))
@@ -351,14 +380,20 @@ def es_train(args, max_cycles=25):
                 rewards[r].append(g["rewards"][s])
                 pop_w[r].append(weights_es(mutated, D[r]))
         rec["diversity"] = []
-        for r in ROLES:  # compute_weight_update :120-148
-            n_arr = np.array(noises[r], dtype=np.float32)
+        for ri, r in enumerate(ROLES):  # compute_weight_update :120-148
             f = np.array(rewards[r], dtype=np.float32)
             div = None
             if args.fitness_sharing:
                 div = diversity(base_w[r], pop_w[r])
                 f = f / (1 + div)
             sigma = getattr(args, sig_attr[r])
+            if mode == "philox":
+                base[r] = es_update_philox(base[r], D[r], f, sigma, args.learning_rate, philox_seed, gen * 4 + ri)
+                base_w[r] = perturbable(base[r], D[r])
+                rec["diversity"].append(None if div is None else float(div))
+                rec.setdefault("fitness", []).append([float(x) for x in f])
+                continue
+            n_arr = np.array(noises[r], dtype=np.float32)
             upd = (args.learning_rate / (len(n_arr) * sigma)) * np.dot(n_arr.T, f)
             base_w[r] = base_w[r] + upd.astype(np.float32)
             base[r] = set_perturbable(base[r], D[r], base_w[r])
