@@ -545,7 +545,11 @@ template <bool FROM_STATE>
 static int launch_fc(const FcArgs &a, int n_tasks, int max_rows, hipStream_t s)
 {
     if (n_tasks <= 0) return COEVO_OK;
-    if (max_rows <= 5)
+    if (max_rows <= 1)
+        hipLaunchKernelGGL((fc_policy_kernel<1, FROM_STATE>), dim3(n_tasks), dim3(256), 0, s, a);
+    else if (max_rows <= 2)
+        hipLaunchKernelGGL((fc_policy_kernel<2, FROM_STATE>), dim3(n_tasks), dim3(256), 0, s, a);
+    else if (max_rows <= 5)
         hipLaunchKernelGGL((fc_policy_kernel<5, FROM_STATE>), dim3(n_tasks), dim3(256), 0, s, a);
     else if (max_rows <= 8)
         hipLaunchKernelGGL((fc_policy_kernel<8, FROM_STATE>), dim3(n_tasks), dim3(256), 0, s, a);

@@ -164,32 +164,51 @@ __global__ __launch_bounds__(256) void fc_gather_kernel(const float *src_slab, c
     *reinterpret_cast<float4 *>(dst_slab + (int64_t)(dst_first + c) * stride + s0) = v;
 }
 
-// theta[p] += lr/(n*sigma) * sum_i fitness[i] * (sigma * eps_i[p]); i ascending, one fmaf per term
-__global__ __launch_bounds__(256) void es_update_kernel(float *theta, int D, const float *fitness, int n,
-                                                         const float *sigma_dev, float lr, uint64_t seed,
-                                                         uint32_t stream_lo_first, uint32_t stream_hi)
+// theta[p] += lr/(n*sigma) * sum_i fitness[i] * (pert_i[p] - theta[p]), i ascending, one fmaf per term.
+// The perturbation is read back from the materialised perturbed nets (one coalesced streaming pass over n*4P bytes)
+// instead of being regenerated: 0.3 ms instead of 2 ms per role at n = 1000.  LayerNorm entries are never perturbed
+// (their difference is exactly 0) and are skipped.
+__global__ __launch_bounds__(256) void es_update_kernel(float *theta, const float *pert_slab, int D,
+                                                         const float *fitness, int n, const float *sigma_dev, float lr)
 {
     const int64_t stride = fc_stride(D), P = fc_params(D);
     const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (s0 >= stride) return;
     const float sigma = *sigma_dev;
     const float scale = lr / ((float)n * sigma);
+    const float4 tv = *reinterpret_cast<const float4 *>(theta + s0);
+    const float th[4] = {tv.x, tv.y, tv.z, tv.w};
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (int i = 0; i < n; ++i) {
-        float z[4];
-        slab_quad_normals(seed, stream_lo_first + (uint32_t)i, stream_hi, s0, D, P, z);
-        const float f = fitness[i];
+    const float *pp = pert_slab + s0;
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        float4 pv[8];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = __builtin_fmaf(f, sigma * z[c], acc[c]);
+        for (int u = 0; u < 8; ++u) pv[u] = *reinterpret_cast<const float4 *>(pp + (int64_t)(i + u) * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float f = fitness[i + u];
+            acc[0] = __builtin_fmaf(f, pv[u].x - th[0], acc[0]);
+            acc[1] = __builtin_fmaf(f, pv[u].y - th[1], acc[1]);
+            acc[2] = __builtin_fmaf(f, pv[u].z - th[2], acc[2]);
+            acc[3] = __builtin_fmaf(f, pv[u].w - th[3], acc[3]);
+        }
     }
-    float4 tv = *reinterpret_cast<float4 *>(theta + s0);
-    float th[4] = {tv.x, tv.y, tv.z, tv.w};
+    for (; i < n; ++i) {
+        const float4 pv = *reinterpret_cast<const float4 *>(pp + (int64_t)i * stride);
+        const float f = fitness[i];
+        acc[0] = __builtin_fmaf(f, pv.x - th[0], acc[0]);
+        acc[1] = __builtin_fmaf(f, pv.y - th[1], acc[1]);
+        acc[2] = __builtin_fmaf(f, pv.z - th[2], acc[2]);
+        acc[3] = __builtin_fmaf(f, pv.w - th[3], acc[3]);
+    }
+    float out[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int64_t s = s0 + c;
-        if (s < P && !fc_slab_is_layernorm(s, D)) th[c] = th[c] + scale * acc[c];
+        out[c] = (s < P && !fc_slab_is_layernorm(s, D)) ? th[c] + scale * acc[c] : th[c];
     }
-    *reinterpret_cast<float4 *>(theta + s0) = make_float4(th[0], th[1], th[2], th[3]);
+    *reinterpret_cast<float4 *>(theta + s0) = make_float4(out[0], out[1], out[2], out[3]);
 }
 
 __global__ __launch_bounds__(256) void fc_pack_kernel(const float *flat, float *slab, int D, bool to_slab)
@@ -260,13 +279,13 @@ extern "C" int coevo_fc_gather(const float *src_slab, const int32_t *src_idx, fl
     return COEVO_OK;
 }
 
-extern "C" int coevo_es_update(float *theta_slab_net, int D, const float *fitness, int n, const float *sigma_dev,
-                               float lr, uint64_t seed, uint32_t stream_lo_first, uint32_t stream_hi, void *stream)
+extern "C" int coevo_es_update(float *theta_slab_net, const float *pert_slab, int D, const float *fitness, int n,
+                               const float *sigma_dev, float lr, void *stream)
 {
-    if (!theta_slab_net || !fitness || !sigma_dev || !fc_dim_ok(D) || n <= 0) return COEVO_ERR_ARG;
+    if (!theta_slab_net || !pert_slab || !fitness || !sigma_dev || !fc_dim_ok(D) || n <= 0) return COEVO_ERR_ARG;
     const dim3 grid((unsigned)((fc_stride(D) / 4 + 255) / 256));
-    hipLaunchKernelGGL(es_update_kernel, grid, dim3(256), 0, (hipStream_t)stream, theta_slab_net, D, fitness, n,
-                       sigma_dev, lr, seed, stream_lo_first, stream_hi);
+    hipLaunchKernelGGL(es_update_kernel, grid, dim3(256), 0, (hipStream_t)stream, theta_slab_net, pert_slab, D,
+                       fitness, n, sigma_dev, lr);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

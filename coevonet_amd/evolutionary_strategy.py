@@ -142,8 +142,8 @@ class ESEngine:
                        L._p(self.dist[r]), L._p(self.div[r]))
                 f = f / (1.0 + self.div[r])
             self.fitness[r].copy_(f)
-            L.call("coevo_es_update", self._ptr(r, "base"), ROLE_D[r], L._p(self.fitness[r]), self.pop,
-                   L._p(self.sigma[r]), L.C.c_float(lr), self.philox_seed, 0, gen * 4 + ri)
+            L.call("coevo_es_update", self._ptr(r, "base"), self._ptr(r, "pert"), ROLE_D[r], L._p(self.fitness[r]),
+                   self.pop, L._p(self.sigma[r]), L.C.c_float(lr))
 
 
 class ESResult:

@@ -76,25 +76,20 @@ class RolloutPlan:
     @staticmethod
     def _xcd_order(heavy):
         """Workgroups are dealt round-robin over the 8 XCDs (blockIdx b and b+8 share one, each XCD has its own
-        4 MiB L2).  Place all chunks of one shared net at block indices of one residue class mod 8 so the net is
-        fetched into ONE L2 and re-read there; nets are spread over the 8 classes by load.  Speed only: the kernel is
-        correct under any placement."""
+        4 MiB L2).  The net-sorted chunk list is cut into 8 equal runs, run x goes to block indices = x (mod 8): every
+        XCD class carries the same load and sees only one or two distinct nets, which it keeps in its own L2 (with
+        fewer than 8 shared nets, as in Co-ES, a net is spread over several classes rather than leaving XCDs idle).
+        Speed only: the kernel is correct under any placement."""
         if len(heavy) < 16:
             return heavy
-        per_net = {}
-        for net, rows in heavy:
-            per_net.setdefault(net, []).append((net, rows))
-        buckets = [[] for _ in range(8)]
-        for net, chunks in sorted(per_net.items(), key=lambda kv: -len(kv[1])):
-            min(buckets, key=len).extend(chunks)
-        out, depth = [], max(len(b) for b in buckets)
-        spare = []
-        for q in range(depth):
+        by_net = sorted(heavy, key=lambda t: t[0])          # chunks of one net adjacent
+        n = len(by_net)
+        buckets = [by_net[b * n // 8:(b + 1) * n // 8] for b in range(8)]  # equal load; 1-2 nets per XCD class
+        out = []
+        for q in range(max(len(b) for b in buckets)):
             for x in range(8):
                 if q < len(buckets[x]):
                     out.append(buckets[x][q])
-                else:
-                    spare.append(x)  # ragged tail: later blocks simply fall where they fall
         return out
 
     def distinct_weight_bytes_per_cycle(self):

@@ -163,10 +163,11 @@ int coevo_fc_perturb(const float *parent_slab, const int32_t *parent_idx, float 
 int coevo_fc_gather(const float *src_slab, const int32_t *src_idx, float *dst_slab, int dst_first, int n, int D,
                     void *stream);
 
-/* K5: theta += lr/(n*sigma) * sum_i fitness[i] * (sigma*eps_i), noise regenerated from the streams used by
- * coevo_fc_perturb (evolutionary_strategy.py:120-148).  theta is ONE net in slab layout. */
-int coevo_es_update(float *theta_slab_net, int D, const float *fitness, int n, const float *sigma_dev, float lr,
-                    uint64_t seed, uint32_t stream_lo_first, uint32_t stream_hi, void *stream);
+/* K5: theta += lr/(n*sigma) * sum_i fitness[i] * (pert_i - theta) over the Linear weights/biases, i ascending
+ * (compute_weight_update, evolutionary_strategy.py:120-148; the reference multiplies the stored n x P noise matrix).
+ * theta is ONE net in slab layout, pert_slab the n perturbed nets coevo_fc_perturb materialised from it. */
+int coevo_es_update(float *theta_slab_net, const float *pert_slab, int D, const float *fitness, int n,
+                    const float *sigma_dev, float lr, void *stream);
 
 /* ---------------------------------------------------------------- K6/K7: fitness, sharing, selection -------- */
 /* distances d[i] = || w_i - w_ref ||_2 over the Linear weights/biases (get_weights_ES default layers) and the

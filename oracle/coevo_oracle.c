@@ -20,7 +20,7 @@
  *   oracle_diversity         utils/game_logic_functions.py:12-37
  *   oracle_perturb_philox    agent.py:25-29 (GA) / :51-53 (ES) with the build's counter-based noise
  *                            (device_philox mode; not a reference RNG stream)
- *   oracle_es_update_philox  evolutionary_strategy.py:120-148
+ *   oracle_es_update_from_pert  evolutionary_strategy.py:120-148
  *   oracle_deepqn_forward    Atari/deepqn.py:39-48
  *
  * CANONICAL fp32 ARITHMETIC (the HIP kernels reproduce exactly this, so HIP == oracle bit for bit;
@@ -451,25 +451,19 @@ void oracle_perturb_philox(const float *parent, float *child, int P, float sigma
     }
 }
 
-/* theta[p] += scale * sum_i fitness[i] * (sigma * z_i[p]), i in stream order, fp32 sequential
- * (evolutionary_strategy.py:144 with regenerated noise). stream_lo = i, stream_hi fixed. */
-void oracle_es_update_philox(float *theta, int P, const float *fitness, int n, float sigma, float scale,
-                             uint64_t seed, uint32_t stream_hi, const int *skip_off, const int *skip_len,
-                             int nskip)
+/* theta[p] += scale * sum_i fitness[i] * (pert_i[p] - theta[p]), i ascending, one fmaf per term, fp32
+ * (evolutionary_strategy.py:144 with the perturbation read back from the perturbed nets).  pert = [n][P] flat. */
+void oracle_es_update_from_pert(float *theta, int P, const float *pert, const float *fitness, int n, float scale,
+                                const int *skip_off, const int *skip_len, int nskip)
 {
-    for (int q = 0; q * 4 < P; ++q) {
-        float acc[4] = {0, 0, 0, 0};
-        for (int i = 0; i < n; ++i) {
-            float z[4];
-            oracle_philox_normal4(seed, (uint32_t)i, stream_hi, (uint32_t)q, z);
-            for (int c = 0; c < 4; ++c) acc[c] = fmaf(fitness[i], sigma * z[c], acc[c]);
-        }
-        for (int c = 0; c < 4 && q * 4 + c < P; ++c) {
-            int p = q * 4 + c, skipped = 0;
-            for (int g = 0; g < nskip; ++g)
-                if (p >= skip_off[g] && p < skip_off[g] + skip_len[g]) skipped = 1;
-            if (!skipped) theta[p] = theta[p] + scale * acc[c];
-        }
+    for (int p = 0; p < P; ++p) {
+        int skipped = 0;
+        for (int g = 0; g < nskip; ++g)
+            if (p >= skip_off[g] && p < skip_off[g] + skip_len[g]) skipped = 1;
+        if (skipped) continue;
+        float acc = 0.0f;
+        for (int i = 0; i < n; ++i) acc = fmaf(fitness[i], pert[(size_t)i * P + p] - theta[p], acc);
+        theta[p] = theta[p] + scale * acc;
     }
 }
 

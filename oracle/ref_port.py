@@ -64,8 +64,7 @@ def lib():
         L.oracle_philox_normal4.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, fp]
         L.oracle_perturb_philox.argtypes = [fp, fp, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32,
                                             ip, ip, C.c_int]
-        L.oracle_es_update_philox.argtypes = [fp, C.c_int, fp, C.c_int, C.c_float, C.c_float, C.c_uint64,
-                                              C.c_uint32, ip, ip, C.c_int]
+        L.oracle_es_update_from_pert.argtypes = [fp, C.c_int, fp, fp, C.c_int, C.c_float, ip, ip, C.c_int]
         _lib = L
     return _lib
 
@@ -321,18 +320,18 @@ def set_perturbable(flat, D, vec):
     return out
 
 
-def es_update_philox(theta, D, fitness, sigma, lr, seed, stream_hi):
-    """theta += lr/(n*sigma) * sum_i f_i * (sigma*eps_i) with regenerated counter-based noise (device_philox mode)"""
+def es_update_from_pert(theta, D, pert, fitness, sigma, lr):
+    """theta += lr/(n*sigma) * sum_i f_i * (pert_i - theta) over the Linear entries (device_philox mode)"""
     P = param_count(D)
     out = np.ascontiguousarray(theta, dtype=np.float32).copy()
     segs = ln_segments(D)
     so = np.array([s[0] for s in segs], dtype=np.int32)
     sl = np.array([s[1] for s in segs], dtype=np.int32)
     f = np.ascontiguousarray(fitness, dtype=np.float32)
+    pert = np.ascontiguousarray(pert, dtype=np.float32)
     n = len(f)
     scale = np.float32(lr) / (np.float32(n) * np.float32(sigma))
-    lib().oracle_es_update_philox(_fp(out), P, _fp(f), n, float(np.float32(sigma)), float(scale), int(seed),
-                                  int(stream_hi), _ip(so), _ip(sl), len(segs))
+    lib().oracle_es_update_from_pert(_fp(out), P, _fp(pert), _fp(f), n, float(scale), _ip(so), _ip(sl), len(segs))
     return out
 
 
@@ -353,6 +352,7 @@ def es_train(args, max_cycles=25, noise="numpy", philox_seed=0):
         noises = {r: [] for r in ROLES}
         rewards = {r: [] for r in ROLES}
         pop_w = {r: [] for r in ROLES}
+        pert_full = {r: [] for r in ROLES}
         for _ in range(args.population):
             for s, r in enumerate(ROLES):
                 sigma = getattr(args, sig_attr[r])
@@ -366,6 +366,7 @@ def es_train(args, max_cycles=25, noise="numpy", philox_seed=0):
                     rec["games"].append(g)
                     rewards[r].append(g["rewards"][s])
                     pop_w[r].append(weights_es(mutated, D[r]))
+                    pert_full[r].append(mutated)
                     continue
                 init_net(D[r])  # clone() constructs a fresh net (torch RNG only)
                 w = perturbable(base[r], D[r])
@@ -388,7 +389,7 @@ def es_train(args, max_cycles=25, noise="numpy", philox_seed=0):
                 f = f / (1 + div)
             sigma = getattr(args, sig_attr[r])
             if mode == "philox":
-                base[r] = es_update_philox(base[r], D[r], f, sigma, args.learning_rate, philox_seed, gen * 4 + ri)
+                base[r] = es_update_from_pert(base[r], D[r], np.stack(pert_full[r]), f, sigma, args.learning_rate)
                 base_w[r] = perturbable(base[r], D[r])
                 rec["diversity"].append(None if div is None else float(div))
                 rec.setdefault("fitness", []).append([float(x) for x in f])

@@ -81,7 +81,7 @@ def test_es_device_philox_matches_oracle_port():
         np.testing.assert_allclose(res.diversity[g], w["diversity"], rtol=1e-5, atol=1e-6)  # n terms of fp32 eps
     for a, r in zip(agents, ROLES):
         # the sharing score enters the update through an fp32 division: distances are fp64-summed here, BLAS in numpy
-        np.testing.assert_allclose(a.model.flat(), want[-1]["base"][r], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(a.model.flat(), want[-1]["base"][r], rtol=1e-4, atol=5e-6)
 
 
 def test_es_device_philox_without_sharing_is_bit_exact():

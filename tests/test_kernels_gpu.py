@@ -274,22 +274,28 @@ def test_es_update_bit_exact_vs_oracle():
     D, n = 8, 37
     P = L.fc_param_count(D)
     theta = make_nets(1, D, seed=21)
-    slab = to_slab(theta, D)
+    stride = L.fc_slab_stride(D)
+    slab = torch.zeros(1 + n, stride, dtype=torch.float32, device=DEV)
+    slab[0] = to_slab(theta, D)[0]
     g = np.random.Generator(np.random.PCG64(4))
     fit = g.normal(size=n).astype(np.float32)
-    sigma, lr, seed, slo, shi = np.float32(0.05), np.float32(0.1), 99, 0, 3
-    d_fit, d_sigma = torch.from_numpy(fit).to(DEV), torch.tensor([sigma], device=DEV)
-    L.call("coevo_es_update", L._p(slab), D, L._p(d_fit), n, L._p(d_sigma), C.c_float(lr), seed, slo, shi)
+    sigma, lr, seed, shi = np.float32(0.05), np.float32(0.1), 99, 3
+    d_sigma = torch.tensor([sigma], device=DEV)
+    zero_idx = torch.zeros(n, dtype=torch.int32, device=DEV)
+    L.call("coevo_fc_perturb", L._p(slab), L._p(zero_idx), L._p(slab), 1, n, D, L._p(d_sigma), seed, 0, shi, 1)
+    pert = torch.zeros(n, P, dtype=torch.float32, device=DEV)
+    L.call("coevo_fc_unpack", slab.data_ptr() + 4 * stride, L._p(pert), n, D)
+    d_fit = torch.from_numpy(fit).to(DEV)
+    L.call("coevo_es_update", L._p(slab), slab.data_ptr() + 4 * stride, D, L._p(d_fit), n, L._p(d_sigma), C.c_float(lr))
     back = torch.zeros(1, P, dtype=torch.float32, device=DEV)
     L.call("coevo_fc_unpack", L._p(slab), L._p(back), 1, D)
-    want = theta[0].copy()
-    segs = rp.ln_segments(D)
-    so = np.array([s[0] for s in segs], dtype=np.int32)
-    sl = np.array([s[1] for s in segs], dtype=np.int32)
-    scale = np.float32(lr / (np.float32(n) * sigma))
-    rp.lib().oracle_es_update_philox(rp._fp(want), P, rp._fp(fit), n, C.c_float(sigma), C.c_float(scale), seed, shi,
-                                     rp._ip(so), rp._ip(sl), len(segs))
+    want = rp.es_update_from_pert(theta[0], D, pert.cpu().numpy(), fit, sigma, lr)
     assert np.array_equal(back.cpu().numpy()[0].view(np.uint32), want.view(np.uint32))
+    assert np.abs(want - theta[0]).max() > 0  # it moved
+    ln = np.zeros(P, dtype=bool)
+    for o, ln_n in rp.ln_segments(D):
+        ln[o:o + ln_n] = True
+    assert np.array_equal(want[ln], theta[0][ln])  # LayerNorm affine untouched (MPE/fcnetwork.py:185-199)
 
 
 # ----------------------------------------------------------------------------------- selection
