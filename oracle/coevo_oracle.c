@@ -467,4 +467,84 @@ void oracle_es_update_from_pert(float *theta, int P, const float *pert, const fl
     }
 }
 
+/* ------------------------------------------------------------------ DeepQN.forward (Atari/deepqn.py:39-48)
+ * flat parameter order = torch parameters() order of DeepQN (Atari/deepqn.py:16-37): conv1.w[32][C][8][8] conv1.b
+ * conv2.w[64][32][4][4] conv2.b conv3.w[64][64][3][3] conv3.b fc1.w[512][3136] fc1.b output.w[n][512] output.b
+ * vbn1.w vbn1.b vbn2.w vbn2.b vbn3.w vbn3.b.
+ * frame: uint8 [84][84][C] (HWC, what the env hands over; preprocess_observation's permute is an index change).
+ * Canonical order: x = u8 / 255.0f; conv = bias, then fmaf over taps in (ci, ky, kx) order; BatchNorm in TRAINING
+ * mode with batch 1 = per-sample, per-channel statistics over the spatial positions: positions in
+ * blocks of 64 (the last one zero-padded), canonical tree inside, blocks left to right; mean = S / N, var = S2 / N
+ * (biased), rstd = 1/sqrtf(var + 1e-5f), y = fmaf(d * rstd, gamma, beta), ReLU; fc = sequential-k chains. */
+static float reduce_canon_padded(const float *v, int n)
+{
+    float s = 0.0f;
+    for (int b = 0; b * 64 < n; ++b) {
+        float blk[64];
+        for (int i = 0; i < 64; ++i) blk[i] = (b * 64 + i < n) ? v[b * 64 + i] : 0.0f;
+        float t = block_tree64(blk, 64);
+        s = (b == 0) ? t : s + t;
+    }
+    return s;
+}
+
+static void conv_bn_relu(const float *in, int cin, int hin, const float *w, const float *b, const float *gamma,
+                         const float *beta, int cout, int k, int stride, int hout, float *out)
+{
+    const int npos = hout * hout;
+    float *tmp = (float *)malloc(sizeof(float) * npos);
+    for (int co = 0; co < cout; ++co) {
+        float *o = out + (size_t)co * npos;
+        for (int oy = 0; oy < hout; ++oy)
+            for (int ox = 0; ox < hout; ++ox) {
+                float acc = b[co];
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int ky = 0; ky < k; ++ky)
+                        for (int kx = 0; kx < k; ++kx)
+                            acc = fmaf(w[(((size_t)co * cin + ci) * k + ky) * k + kx],
+                                       in[((size_t)ci * hin + oy * stride + ky) * hin + ox * stride + kx], acc);
+                o[oy * hout + ox] = acc;
+            }
+        float mean = reduce_canon_padded(o, npos) / (float)npos;
+        for (int p = 0; p < npos; ++p) { o[p] = o[p] - mean; tmp[p] = o[p] * o[p]; }
+        float var = reduce_canon_padded(tmp, npos) / (float)npos;
+        float rstd = 1.0f / sqrtf(var + LN_EPS);
+        for (int p = 0; p < npos; ++p) {
+            float y = fmaf(o[p] * rstd, gamma[co], beta[co]);
+            o[p] = (y > 0.0f) ? y : (isnan(y) ? y : 0.0f);
+        }
+    }
+    free(tmp);
+}
+
+long oracle_dqn_param_count(int C, int n)
+{
+    return 32L * C * 64 + 32 + 64L * 32 * 16 + 64 + 64L * 64 * 9 + 64 + 512L * 3136 + 512 + 512L * n + n + 2 * (32 + 64 + 64);
+}
+
+int oracle_dqn_forward(const float *p, int C, int n, const unsigned char *frame, float *logits)
+{
+    const float *w1 = p, *b1 = w1 + 32 * C * 64, *w2 = b1 + 32, *b2 = w2 + 64 * 32 * 16, *w3 = b2 + 64,
+                *b3 = w3 + 64 * 64 * 9, *wf = b3 + 64, *bf = wf + 512 * 3136, *wo = bf + 512, *bo = wo + 512 * n,
+                *g1 = bo + n, *be1 = g1 + 32, *g2 = be1 + 32, *be2 = g2 + 64, *g3 = be2 + 64, *be3 = g3 + 64;
+    float *x = (float *)malloc(sizeof(float) * C * 84 * 84);
+    float *a1 = (float *)malloc(sizeof(float) * 32 * 400), *a2 = (float *)malloc(sizeof(float) * 64 * 81);
+    float *a3 = (float *)malloc(sizeof(float) * 3136), *h = (float *)malloc(sizeof(float) * 512);
+    for (int y = 0; y < 84; ++y)
+        for (int xx = 0; xx < 84; ++xx)
+            for (int c = 0; c < C; ++c) x[((size_t)c * 84 + y) * 84 + xx] = (float)frame[((size_t)y * 84 + xx) * C + c] / 255.0f;
+    conv_bn_relu(x, C, 84, w1, b1, g1, be1, 32, 8, 4, 20, a1);
+    conv_bn_relu(a1, 32, 20, w2, b2, g2, be2, 64, 4, 2, 9, a2);
+    conv_bn_relu(a2, 64, 9, w3, b3, g3, be3, 64, 3, 1, 7, a3);
+    linear_seq(wf, bf, a3, h, 512, 3136);
+    for (int j = 0; j < 512; ++j) h[j] = (h[j] > 0.0f) ? h[j] : (isnan(h[j]) ? h[j] : 0.0f);
+    linear_seq(wo, bo, h, logits, n, 512);
+    int best = -1;
+    float cur = -INFINITY;
+    for (int i = 0; i < n; ++i)
+        if (logits[i] > cur) { cur = logits[i]; best = i; }
+    free(x); free(a1); free(a2); free(a3); free(h);
+    return best;
+}
+
 int oracle_version(void) { return 1; }

@@ -65,6 +65,9 @@ def lib():
         L.oracle_perturb_philox.argtypes = [fp, fp, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32,
                                             ip, ip, C.c_int]
         L.oracle_es_update_from_pert.argtypes = [fp, C.c_int, fp, fp, C.c_int, C.c_float, ip, ip, C.c_int]
+        L.oracle_dqn_param_count.restype = C.c_long
+        L.oracle_dqn_forward.restype = C.c_int
+        L.oracle_dqn_forward.argtypes = [fp, C.c_int, C.c_int, C.c_void_p, fp]
         _lib = L
     return _lib
 
@@ -417,3 +420,33 @@ def es_train(args, max_cycles=25, noise="numpy", philox_seed=0):
         rec["base"] = {r: base[r].copy() for r in ROLES}
         out.append(rec)
     return out
+
+
+# ------------------------------------------------------------------ DeepQN (Atari/deepqn.py)
+def dqn_init(C, n_actions):
+    """flat parameters in parameters() order, consuming the torch generator like DeepQN.__init__ (:16-37)"""
+    conv1 = torch.nn.Conv2d(C, 32, kernel_size=8, stride=4)
+    conv2 = torch.nn.Conv2d(32, 64, kernel_size=4, stride=2)
+    conv3 = torch.nn.Conv2d(64, 64, kernel_size=3, stride=1)
+    fc1 = torch.nn.Linear(64 * 7 * 7, 512)
+    out = torch.nn.Linear(512, n_actions)
+    parts = [conv1.weight, conv1.bias, conv2.weight, conv2.bias, conv3.weight, conv3.bias, fc1.weight, fc1.bias,
+             out.weight, out.bias, torch.ones(32), torch.zeros(32), torch.ones(64), torch.zeros(64), torch.ones(64),
+             torch.zeros(64)]
+    return np.concatenate([p.detach().numpy().ravel() for p in parts]).astype(np.float32), [tuple(p.shape) for p in parts]
+
+
+def dqn_mutate_torch(flat, shapes, sigma):
+    out, off = flat.copy(), 0
+    for shp in shapes:
+        n = int(np.prod(shp))
+        out[off:off + n] = out[off:off + n] + torch.normal(0, sigma, size=shp).numpy().ravel()
+        off += n
+    return out
+
+
+def dqn_forward(flat, C, n_actions, frame_u8):
+    logits = np.zeros(n_actions, dtype=np.float32)
+    f = np.ascontiguousarray(frame_u8, dtype=np.uint8)
+    a = lib().oracle_dqn_forward(_fp(np.ascontiguousarray(flat, dtype=np.float32)), C, n_actions, f.ctypes.data, _fp(logits))
+    return a, logits

@@ -105,3 +105,26 @@ def test_es_generations(name):
         assert got["sigma_after"] == ref["sigma_after"]
         if ref["diversity"][0] is not None:
             np.testing.assert_allclose(got["diversity"], ref["diversity"], rtol=1e-5)
+
+
+def test_deepqn_forward_vectors():
+    """oracle DeepQN.forward vs the logits the reference's DeepQN produced (train-mode BatchNorm at batch 1 =
+    per-sample spatial statistics).  Tolerance = fp32 summation-order noise of 3136-term dot products."""
+    import hashlib
+    for case in load_golden("deepqn_forward.json")["cases"]:
+        torch.manual_seed(case["torch_seed"])
+        C, n = case["C"], case["n_actions"]
+        flat, shapes = rp.dqn_init(C, n)
+        flat = rp.dqn_mutate_torch(flat, shapes, case["mutate_std"])
+        assert len(flat) == rp.lib().oracle_dqn_param_count(C, n)
+        assert sha(flat) == case["weights_sha256"]  # same parameters as the reference's DeepQN, byte for byte
+        g = np.random.Generator(np.random.PCG64(case["frame_pcg_seed"]))
+        frames = g.integers(0, 256, size=(2, 84, 84, C), dtype=np.uint8)
+        assert hashlib.sha256(frames.tobytes()).hexdigest() == case["frame_sha256"]
+        for r in range(2):
+            a, logits = rp.dqn_forward(flat, C, n, frames[r])
+            ref = np.array(case["logits"][r], dtype=np.float32)
+            np.testing.assert_allclose(logits, ref, rtol=1e-4, atol=2e-5)
+            srt = np.sort(ref)[::-1]
+            if srt[0] - srt[1] > 1e-3:
+                assert a == int(np.argmax(ref))
