@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcoevo.so")
-SOURCES = ["fc_forward.hip", "mpe_env.hip", "offspring.hip", "select.hip", "rollout_api.hip"]
+SOURCES = ["fc_forward.hip", "mpe_env.hip", "offspring.hip", "select.hip", "rollout_api.hip", "deepqn.hip"]
 # -ffp-contract=off: only explicit fmaf fuses (the canonical arithmetic contract with the oracle)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]

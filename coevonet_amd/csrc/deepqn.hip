@@ -1,0 +1,369 @@
+// K2 - DeepQN policy step (reference Atari/deepqn.py:39-48: x/255 -> conv8s4(32) -> BN -> ReLU -> conv4s2(64) -> BN ->
+// ReLU -> conv3s1(64) -> BN -> ReLU -> flatten(CHW) -> fc 3136->512 -> ReLU -> fc 512->n) + first-max action, for many
+// (weight set x frames) tasks.  BatchNorm is in TRAINING mode at batch 1 in the reference (never .eval()ed), i.e.
+// per-sample, per-channel statistics over the spatial positions: batching must not mix samples.
+//
+// Three launches per env step:
+//   dqn_conv_kernel   one workgroup per frame: the uint8 HWC frame is staged in LDS once (coalesced 16-byte loads),
+//                     /255 through a 256-entry LDS table (exact fp32 quotients), the three convolutions run as implicit
+//                     GEMMs on v_mfma_f32_32x32x2_f32 (A = im2col gather out of LDS, B = weights [tap][cout] from L2),
+//                     BN statistics are reduced in the accumulator layout in the canonical tree order, activations stay
+//                     in LDS between layers; conv3's output goes to HBM as act[row][3136].
+//   dqn_fc1_kernel    the 6.4 MB fc1 matrix of each net is streamed exactly once per task (<= 16 rows): a grouped GEMV
+//                     like fc2 of the MPE net, [8][784][64][4] tiling, lane = output, activations as scalar broadcasts.
+//   dqn_out_kernel    512 -> n logits, first-max action.
+// fp32 arithmetic follows the canonical order of oracle/coevo_oracle.c (taps in (ci,ky,kx) order, sequential-k fc
+// chains), so logits equal the oracle's bit for bit.
+#include "coevo_common.hip.h"
+
+namespace coevo {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int DQ_FC1_IN = 3136, DQ_FC1_OUT = 512;
+
+struct DqnLayout {
+    int64_t w1, b1, w2, b2, w3, b3, wf, bf, wo, bo, total, stride;
+};
+
+__host__ __device__ inline DqnLayout dqn_layout(int C, int n)
+{
+    DqnLayout L;
+    L.w1 = 0;
+    L.b1 = (int64_t)C * 64 * 32;          // b1, g1, be1 (32 each)
+    L.w2 = L.b1 + 96;
+    L.b2 = L.w2 + 512 * 64;               // b2, g2, be2 (64 each)
+    L.w3 = L.b2 + 192;
+    L.b3 = L.w3 + 576 * 64;
+    L.wf = L.b3 + 192;                     // [8][784][64][4]
+    L.bf = L.wf + (int64_t)DQ_FC1_OUT * DQ_FC1_IN;
+    L.wo = L.bf + DQ_FC1_OUT;              // [n][512]
+    L.bo = L.wo + (int64_t)n * DQ_FC1_OUT;
+    L.total = L.bo + n;
+    L.stride = (L.total + 63) / 64 * 64;
+    return L;
+}
+
+__host__ __device__ inline int64_t dqn_param_count(int C, int n)
+{
+    return 32LL * C * 64 + 32 + 64LL * 512 + 64 + 64LL * 576 + 64 + 512LL * DQ_FC1_IN + 512 + 512LL * n + n + 320;
+}
+
+// slab position -> canonical flat index (parameters() order: conv1.w conv1.b conv2.w conv2.b conv3.w conv3.b fc1.w
+// fc1.b output.w output.b vbn1.w vbn1.b vbn2.w vbn2.b vbn3.w vbn3.b); -1 for padding
+__host__ __device__ inline int64_t dqn_slab_to_flat(int64_t s, int C, int n)
+{
+    const DqnLayout L = dqn_layout(C, n);
+    const int64_t T1 = (int64_t)C * 64;
+    const int64_t F_w1 = 0, F_b1 = 32 * T1, F_w2 = F_b1 + 32, F_b2 = F_w2 + 64 * 512, F_w3 = F_b2 + 64,
+                  F_b3 = F_w3 + 64 * 576, F_wf = F_b3 + 64, F_bf = F_wf + 512LL * DQ_FC1_IN, F_wo = F_bf + 512,
+                  F_bo = F_wo + 512LL * n, F_g1 = F_bo + n, F_be1 = F_g1 + 32, F_g2 = F_be1 + 32, F_be2 = F_g2 + 64,
+                  F_g3 = F_be2 + 64, F_be3 = F_g3 + 64;
+    if (s >= L.total) return -1;
+    if (s < L.b1) { const int64_t t = s / 32, co = s % 32; return F_w1 + co * T1 + t; }
+    if (s < L.w2) { const int64_t i = s - L.b1; return i < 32 ? F_b1 + i : (i < 64 ? F_g1 + i - 32 : F_be1 + i - 64); }
+    if (s < L.b2) { const int64_t i = s - L.w2, t = i / 64, co = i % 64; return F_w2 + co * 512 + t; }
+    if (s < L.w3) { const int64_t i = s - L.b2; return i < 64 ? F_b2 + i : (i < 128 ? F_g2 + i - 64 : F_be2 + i - 128); }
+    if (s < L.b3) { const int64_t i = s - L.w3, t = i / 64, co = i % 64; return F_w3 + co * 576 + t; }
+    if (s < L.wf) { const int64_t i = s - L.b3; return i < 64 ? F_b3 + i : (i < 128 ? F_g3 + i - 64 : F_be3 + i - 128); }
+    if (s < L.bf) {  // wfq[ob][kq][l][c] = fc1.w[64 ob + l][4 kq + c]
+        const int64_t i = s - L.wf, c = i & 3, l = (i >> 2) & 63, kq = (i >> 8) % 784, ob = (i >> 8) / 784;
+        return F_wf + (ob * 64 + l) * DQ_FC1_IN + kq * 4 + c;
+    }
+    if (s < L.wo) return F_bf + (s - L.bf);
+    if (s < L.bo) return F_wo + (s - L.wo);
+    return F_bo + (s - L.bo);
+}
+
+__global__ __launch_bounds__(256) void dqn_pack_kernel(const float *flat, float *slab, int C, int n)
+{
+    const DqnLayout L = dqn_layout(C, n);
+    const int64_t P = dqn_param_count(C, n);
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= L.stride) return;
+    const int64_t f = dqn_slab_to_flat(s, C, n);
+    slab[(int64_t)blockIdx.y * L.stride + s] = (f >= 0) ? flat[(int64_t)blockIdx.y * P + f] : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// canonical sum over the 64 positions of one block, per output channel, from two 32x32 accumulator tiles.
+// position inside the block: i = 32*mt + (reg&3) + 8*(reg>>2) + 4*(lane>>5); tree = i xor 1, 2, 4, 8, 16, 32.
+__device__ inline float block_tree_from_acc(const f32x16 &t0, const f32x16 &t1)
+{
+    float s[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const f32x16 &v = mt ? t1 : t0;
+        float a[8], b[4];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = v[2 * q] + v[2 * q + 1];            // xor 1: reg bit 0
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] = a[2 * q] + a[2 * q + 1];            // xor 2: reg bit 1
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                                          // xor 4: lane half
+            const u32x2 x = __builtin_amdgcn_permlane32_swap(__float_as_uint(b[q]), __float_as_uint(b[q]), false, false);
+            b[q] = __uint_as_float(x[0]) + __uint_as_float(x[1]);
+        }
+        s[mt] = (b[0] + b[1]) + (b[2] + b[3]);                                  // xor 8, 16: reg bits 2, 3
+    }
+    return s[0] + s[1];                                                         // xor 32: the two row tiles
+}
+
+struct ConvGeom { int cin, ks, stride, hin, hout, cout; };
+
+// One conv + BN(train, batch 1) + ReLU layer of one frame on the matrix cores.
+//   UNITS_PER_WAVE: (position block, column tile) work units a wave owns (conv1: 2, conv2/3: 1); unit u of wave w is
+//   global unit w + 4*u; unit -> (block = unit / NT, nt = unit % NT).
+template <int TAPS_MAX, int KS, int STRIDE, int HIN, int HOUT, int COUT, int UNITS, bool U8IN>
+__device__ inline void conv_bn_relu_mfma(const void *in_lds, const float *lut, int cin, const float *wt,
+                                         const float *bias, const float *gamma, const float *beta, float *out,
+                                         float *red, int w, int l)
+{
+    constexpr int NPOS = HOUT * HOUT, NBLK = (NPOS + 63) / 64, NT = COUT / 32, NUNIT = NBLK * NT;
+    const int lc = l & 31, lh = l >> 5;
+    const int taps = cin * KS * KS;
+    f32x16 acc[UNITS][2];
+    int base[UNITS][2];
+    bool live[UNITS];
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) {
+        const int unit = w + 4 * u;
+        live[u] = unit < NUNIT;
+        const int blk = unit / NT, nt = unit % NT;
+        const float bb = live[u] ? bias[32 * nt + lc] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            int p = 64 * blk + 32 * mt + lc;
+            if (!live[u] || p >= NPOS) p = 0;  // padded rows read position 0 and are masked out of every result
+            const int oy = p / HOUT, ox = p % HOUT;
+            base[u][mt] = U8IN ? ((oy * STRIDE) * HIN + ox * STRIDE) * cin : (oy * STRIDE) * HIN + ox * STRIDE;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][mt][r] = bb;
+        }
+    }
+    // all units of one wave share the column tile when NT == 1 (conv1); otherwise a wave has a single unit
+    const int nt0 = (w % NT);
+    for (int t0 = 0; t0 < taps; t0 += 2) {
+        const int t = t0 + lh;
+        const int ci = t / (KS * KS), rem = t % (KS * KS), ky = rem / KS, kx = rem % KS;
+        const int toff = U8IN ? (ky * HIN + kx) * cin + ci : (ci * HIN + ky) * HIN + kx;
+        const float bv = wt[(size_t)t * COUT + 32 * nt0 + lc];
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            if (!live[u]) continue;  // wave-uniform
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                float av;
+                if constexpr (U8IN) av = lut[static_cast<const unsigned char *>(in_lds)[base[u][mt] + toff]];
+                else av = static_cast<const float *>(in_lds)[base[u][mt] + toff];
+                acc[u][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[u][mt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- BatchNorm statistics: canonical block sums -> LDS -> blocks left to right ------------------------------
+    auto masked = [&](int u, int mt, int r) {
+        const int unit = w + 4 * u, blk = unit / NT;
+        const int p = 64 * blk + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        return p < NPOS;
+    };
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            if (!live[u]) continue;
+            const int unit = w + 4 * u, blk = unit / NT, nt = unit % NT;
+            f32x16 v0, v1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float x0 = acc[u][0][r], x1 = acc[u][1][r];
+                v0[r] = masked(u, 0, r) ? (pass ? x0 * x0 : x0) : 0.0f;
+                v1[r] = masked(u, 1, r) ? (pass ? x1 * x1 : x1) : 0.0f;
+            }
+            const float s = block_tree_from_acc(v0, v1);
+            if (lh == 0) red[(nt * 8 + blk) * 32 + lc] = s;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            if (!live[u]) continue;
+            const int unit = w + 4 * u, nt = unit % NT;
+            float tot = red[(nt * 8 + 0) * 32 + lc];
+            for (int b = 1; b < NBLK; ++b) tot = tot + red[(nt * 8 + b) * 32 + lc];
+            const float stat = tot / (float)NPOS;
+            if (pass == 0) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[u][mt][r] = acc[u][mt][r] - stat;
+            } else {
+                const int blk = unit / NT;
+                const float rstd = 1.0f / __builtin_sqrtf(stat + LN_EPS);
+                const float ga = gamma[32 * nt + lc], be = beta[32 * nt + lc];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int p = 64 * blk + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (p < NPOS) {
+                            const float y = __builtin_fmaf(acc[u][mt][r] * rstd, ga, be);
+                            out[(size_t)(32 * nt + lc) * NPOS + p] = relu_keep_nan(y);
+                        }
+                    }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+struct DqnSmem {
+    float lut[256];
+    float a1[32 * 400];
+    float a2[64 * 81];
+    float red[2 * 8 * 32];
+    unsigned char frame[84 * 84 * 6 + 16];
+};
+
+__global__ __launch_bounds__(256) void dqn_conv_kernel(const float *slab, const coevo_dqn_task *tasks, int C,
+                                                        int n_actions, const uint8_t *frames, float *act)
+{
+    __shared__ __attribute__((aligned(16))) DqnSmem sm;
+    const coevo_dqn_task task = tasks[blockIdx.x];
+    if ((int)blockIdx.y >= task.n_rows) return;
+    const int row = task.row_begin + blockIdx.y;
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    const float *net = slab + task.net_off;
+    const DqnLayout L = dqn_layout(C, n_actions);
+    // stage the frame (84*84*C bytes, a multiple of 16) and the /255 table
+    const int nbytes = 84 * 84 * C;
+    const uint4 *src = reinterpret_cast<const uint4 *>(frames + (size_t)row * nbytes);
+    uint4 *dst = reinterpret_cast<uint4 *>(sm.frame);
+    for (int i = t; i < nbytes / 16; i += 256) dst[i] = src[i];
+    sm.lut[t] = (float)t / 255.0f;
+    __syncthreads();
+    conv_bn_relu_mfma<384, 8, 4, 84, 20, 32, 2, true>(sm.frame, sm.lut, C, net + L.w1, net + L.b1, net + L.b1 + 32,
+                                                      net + L.b1 + 64, sm.a1, sm.red, w, l);
+    conv_bn_relu_mfma<512, 4, 2, 20, 9, 64, 1, false>(sm.a1, nullptr, 32, net + L.w2, net + L.b2, net + L.b2 + 64,
+                                                      net + L.b2 + 128, sm.a2, sm.red, w, l);
+    conv_bn_relu_mfma<576, 3, 1, 9, 7, 64, 1, false>(sm.a2, nullptr, 64, net + L.w3, net + L.b3, net + L.b3 + 64,
+                                                     net + L.b3 + 128, act + (size_t)row * DQ_FC1_IN, sm.red, w, l);
+}
+
+// fc1 + ReLU: grid (task, half); wave w of half h owns outputs [64*(4h+w), +64); <= 16 rows per task.
+constexpr int DQ_RMAX = 16;
+__global__ __launch_bounds__(256) void dqn_fc1_kernel(const float *slab, const coevo_dqn_task *tasks, int C,
+                                                       int n_actions, const float *act, float *hid)
+{
+    const coevo_dqn_task task = tasks[blockIdx.x];
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    const int ob = 4 * blockIdx.y + w;
+    const float *net = slab + task.net_off;
+    const DqnLayout L = dqn_layout(C, n_actions);
+    const int nrows = task.n_rows;
+    const float bb = net[L.bf + 64 * ob + l];
+    float acc[DQ_RMAX];
+#pragma unroll
+    for (int r = 0; r < DQ_RMAX; ++r) acc[r] = bb;
+    const float4 *wp = reinterpret_cast<const float4 *>(net + L.wf) + (size_t)ob * 784 * 64 + l;
+    const float *arow = act + (size_t)task.row_begin * DQ_FC1_IN;
+    constexpr int U = 8;
+    for (int kq = 0; kq < 784; kq += U) {
+        float4 wv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) wv[u] = wp[(size_t)(kq + u) * 64];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int r = 0; r < DQ_RMAX; ++r) {
+                if (r < nrows) {  // wave-uniform
+                    const float4 x = *reinterpret_cast<const float4 *>(arow + (size_t)r * DQ_FC1_IN + 4 * (kq + u));
+                    acc[r] = __builtin_fmaf(wv[u].x, x.x, acc[r]);
+                    acc[r] = __builtin_fmaf(wv[u].y, x.y, acc[r]);
+                    acc[r] = __builtin_fmaf(wv[u].z, x.z, acc[r]);
+                    acc[r] = __builtin_fmaf(wv[u].w, x.w, acc[r]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < DQ_RMAX; ++r)
+        if (r < nrows) hid[(size_t)(task.row_begin + r) * DQ_FC1_OUT + 64 * ob + l] = relu_keep_nan(acc[r]);
+}
+
+// output layer + first-max action: one 64-thread workgroup per (task, row)
+__global__ __launch_bounds__(64) void dqn_out_kernel(const float *slab, const coevo_dqn_task *tasks, int C,
+                                                      int n_actions, const float *hid, int32_t *actions,
+                                                      float *logits, int32_t *status)
+{
+    __shared__ float lg[64];
+    const coevo_dqn_task task = tasks[blockIdx.x];
+    if ((int)blockIdx.y >= task.n_rows) return;
+    const int row = task.row_begin + blockIdx.y, o = threadIdx.x;
+    const float *net = slab + task.net_off;
+    const DqnLayout L = dqn_layout(C, n_actions);
+    if (o < n_actions) {
+        float y = net[L.bo + o];
+        const float *wr = net + L.wo + (size_t)o * DQ_FC1_OUT, *x = hid + (size_t)row * DQ_FC1_OUT;
+        for (int k = 0; k < DQ_FC1_OUT; ++k) y = __builtin_fmaf(wr[k], x[k], y);
+        lg[o] = y;
+        if (logits) logits[(size_t)row * COEVO_DQN_LOGIT_STRIDE + o] = y;
+    }
+    __syncthreads();
+    if (o == 0) {
+        int best = -1;
+        float cur = -__builtin_inff();
+        for (int i = 0; i < n_actions; ++i)
+            if (lg[i] > cur) { cur = lg[i]; best = i; }
+        if (best < 0) { atomicOr(status, COEVO_ST_NO_ACTION); best = 0; }
+        actions[row] = best;
+    }
+}
+
+}  // namespace coevo
+
+using namespace coevo;
+
+static bool dqn_shape_ok(int C, int n) { return C >= 1 && C <= 6 && n >= 1 && n <= COEVO_DQN_LOGIT_STRIDE; }
+
+extern "C" int64_t coevo_dqn_param_count(int C, int n_actions)
+{
+    return dqn_shape_ok(C, n_actions) ? dqn_param_count(C, n_actions) : COEVO_ERR_ARG;
+}
+
+extern "C" int64_t coevo_dqn_slab_stride(int C, int n_actions)
+{
+    return dqn_shape_ok(C, n_actions) ? dqn_layout(C, n_actions).stride : COEVO_ERR_ARG;
+}
+
+extern "C" int64_t coevo_dqn_workspace_bytes(int n_rows_total)
+{
+    return n_rows_total > 0 ? (int64_t)n_rows_total * (DQ_FC1_IN + DQ_FC1_OUT) * 4 : COEVO_ERR_ARG;
+}
+
+extern "C" int coevo_dqn_pack(const float *flat, float *slab, int n, int C, int n_actions, void *stream)
+{
+    if (!flat || !slab || n <= 0 || !dqn_shape_ok(C, n_actions)) return COEVO_ERR_ARG;
+    const dim3 grid((unsigned)((dqn_layout(C, n_actions).stride + 255) / 256), (unsigned)n);
+    hipLaunchKernelGGL(dqn_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, flat, slab, C, n_actions);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_dqn_forward_argmax(const float *slab, const coevo_dqn_task *tasks, int n_tasks,
+                                        int max_rows_per_task, int n_rows_total, int C, int n_actions,
+                                        const uint8_t *frames, int32_t *actions, float *logits, int32_t *status,
+                                        void *workspace, void *stream)
+{
+    if (!slab || !tasks || !frames || !actions || !status || !workspace) return COEVO_ERR_ARG;
+    if (n_tasks <= 0 || n_rows_total <= 0 || !dqn_shape_ok(C, n_actions)) return COEVO_ERR_ARG;
+    if (max_rows_per_task < 1 || max_rows_per_task > DQ_RMAX) return COEVO_ERR_ARG;
+    float *act = static_cast<float *>(workspace);
+    float *hid = act + (size_t)n_rows_total * DQ_FC1_IN;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(dqn_conv_kernel, dim3(n_tasks, max_rows_per_task), dim3(256), 0, s, slab, tasks, C, n_actions,
+                       frames, act);
+    hipLaunchKernelGGL(dqn_fc1_kernel, dim3(n_tasks, 2), dim3(256), 0, s, slab, tasks, C, n_actions, act, hid);
+    hipLaunchKernelGGL(dqn_out_kernel, dim3(n_tasks, max_rows_per_task), dim3(64), 0, s, slab, tasks, C, n_actions, hid,
+                       actions, logits, status);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}

@@ -23,6 +23,10 @@ ST_NAMES = {1: "input contains inf or NaN", 2: "output contains inf or NaN after
             4: "output contains inf or NaN after fc2", 8: "output contains inf or NaN",
             16: "no action selected (current_best_position = -1)"}
 
+DQN_LOGIT_STRIDE = 32
+DQN_MAX_ROWS = 16
+DQN_TASK_DTYPE = np.dtype([("net_off", "<i8"), ("row_begin", "<i4"), ("n_rows", "<i4")])
+
 # numpy view of coevo_fc_task
 TASK_DTYPE = np.dtype([("net_off", "<i8"), ("row_begin", "<i4"), ("n_rows", "<i4"), ("D", "<i4"),
                        ("reserved", "<i4")])
@@ -76,6 +80,12 @@ _SIGS = {
     "coevo_mpe_policy_cycle_stamped": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_void_p]),
+    "coevo_dqn_param_count": (C.c_int64, [C.c_int, C.c_int]),
+    "coevo_dqn_slab_stride": (C.c_int64, [C.c_int, C.c_int]),
+    "coevo_dqn_workspace_bytes": (C.c_int64, [C.c_int]),
+    "coevo_dqn_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "coevo_dqn_forward_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "coevo_fc_perturb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]),
     "coevo_fc_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -149,5 +159,5 @@ def fc_slab_stride(D):
 
 def tasks_to_device(tasks_np, device="cuda"):
     """numpy structured array (TASK_DTYPE) -> device byte tensor usable as coevo_fc_task*"""
-    assert tasks_np.dtype == TASK_DTYPE
+    assert tasks_np.dtype in (TASK_DTYPE, DQN_TASK_DTYPE)
     return torch.from_numpy(tasks_np.view(np.uint8).copy()).to(device)

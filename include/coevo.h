@@ -189,6 +189,30 @@ int coevo_ga_fitness(const double *rewards, int game_first, int pop, int games_p
  * HIGHER index first, quirk Q13).  n <= 4096. */
 int coevo_rank_desc(const float *fitness, int n, int32_t *order, void *stream);
 
+/* ---------------------------------------------------------------- K2: DeepQN policy step -------------------- */
+/* DeepQN.forward (Atari/deepqn.py:39-48) + first-max action (the rule its docstring :51-52 intends; the reference's
+ * own determine_action does not run) for rows of uint8 frames [84][84][C] in HWC order, as the env hands
+ * them over (the permute of preprocess_observation, utils/game_logic_functions.py:78, is folded into the load).
+ * BatchNorm runs in training mode at batch 1: per-sample, per-channel spatial statistics; rows never mix.
+ * Canonical flat order = torch parameters() order: conv1.w conv1.b conv2.w conv2.b conv3.w conv3.b fc1.w fc1.b
+ * output.w output.b vbn1.w vbn1.b vbn2.w vbn2.b vbn3.w vbn3.b. */
+#define COEVO_DQN_LOGIT_STRIDE 32    /* floats per logits row; n_actions <= 32 (6 pong, 18 boxing) */
+#define COEVO_DQN_MAX_ROWS 16        /* frames one task (one weight set) may carry */
+int64_t coevo_dqn_param_count(int C, int n_actions);      /* 1 687 526 for C=4, n=6 */
+int64_t coevo_dqn_slab_stride(int C, int n_actions);
+int64_t coevo_dqn_workspace_bytes(int n_rows_total);      /* conv3 activations + fc1 outputs of every row */
+int coevo_dqn_pack(const float *flat, float *slab, int n, int C, int n_actions, void *stream);
+typedef struct {
+    int64_t net_off;   /* float offset of the net inside the slab */
+    int32_t row_begin;
+    int32_t n_rows;    /* 1 .. COEVO_DQN_MAX_ROWS frames that share this weight set */
+} coevo_dqn_task;
+/* frames [n_rows_total][84][84][C] uint8; actions [n_rows_total]; logits [n_rows_total][COEVO_DQN_LOGIT_STRIDE] or
+ * NULL; workspace of coevo_dqn_workspace_bytes(n_rows_total) bytes.  Three launches on `stream`. */
+int coevo_dqn_forward_argmax(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int max_rows_per_task,
+                             int n_rows_total, int C, int n_actions, const uint8_t *frames, int32_t *actions,
+                             float *logits, int32_t *status, void *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

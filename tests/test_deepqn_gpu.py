@@ -1,0 +1,54 @@
+"""DeepQN policy kernels (K2) through the C ABI: bit-exact vs the oracle, and vs the reference's own logits (fixture)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from coevonet_amd import deepqn as dq
+from oracle import ref_port as rp
+from tests.util import load_golden, sha
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("C,n_actions,rows", [(4, 6, [3, 1, 10]), (6, 18, [16, 2])])
+def test_dqn_forward_bit_exact_vs_oracle(C, n_actions, rows):
+    torch.manual_seed(C * 10 + n_actions)
+    nets = []
+    for _ in rows:
+        flat, shapes = rp.dqn_init(C, n_actions)
+        nets.append(rp.dqn_mutate_torch(flat, shapes, 0.02))
+    g = np.random.Generator(np.random.PCG64(7))
+    frames = [g.integers(0, 256, size=(r, 84, 84, C), dtype=np.uint8) for r in rows]
+    frames[0][0, :, :, :] = 0          # a constant frame: zero variance in conv1's BatchNorm statistics
+    logits, actions = dq.batched_actions(nets, frames, C, n_actions)
+    row = 0
+    for net, fr in zip(nets, frames):
+        for r in range(fr.shape[0]):
+            a, want = rp.dqn_forward(net, C, n_actions, fr[r])
+            assert np.array_equal(logits[row].view(np.uint32), want.view(np.uint32)), (row, logits[row], want)
+            assert actions[row] == a
+            row += 1
+
+
+def test_dqn_matches_reference_logits_fixture():
+    """the product's DeepQN mirror: same parameters as the reference's (sha256) and logits within fp32 summation noise"""
+    for case in load_golden("deepqn_forward.json")["cases"]:
+        torch.manual_seed(case["torch_seed"])
+        C, n = case["C"], case["n_actions"]
+        net = dq.DeepQN(C, n, "float32")
+        for p in net.parameters():
+            p.data += torch.normal(0, case["mutate_std"], size=p.size())
+        assert sha(net.flat()) == case["weights_sha256"]
+        g = np.random.Generator(np.random.PCG64(case["frame_pcg_seed"]))
+        frames = g.integers(0, 256, size=(2, 84, 84, C), dtype=np.uint8)
+        assert hashlib.sha256(frames.tobytes()).hexdigest() == case["frame_sha256"]
+        for r in range(2):
+            x = torch.from_numpy(frames[r]).to(torch.float32).permute(2, 0, 1).unsqueeze(0)  # preprocess_observation
+            out = net.forward(x).numpy()[0]
+            ref = np.array(case["logits"][r], dtype=np.float32)
+            np.testing.assert_allclose(out, ref, rtol=1e-4, atol=2e-5)
+            srt = np.sort(ref)[::-1]
+            if srt[0] - srt[1] > 1e-3:
+                assert net.determine_action(x, None) == int(np.argmax(ref))
