@@ -86,8 +86,9 @@ def main():
     ctx = DistContext()
     if ctx.world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={ctx.world}: launch with torch.distributed.run")
-    torch.cuda.set_device(ctx.local_rank)
-    dev = torch.device("cuda", ctx.local_rank)
+    dev_index = ctx.local_rank % max(torch.cuda.device_count(), 1)  # (rehearsals put several ranks on one GPU)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     L.load()
 
     pop = a.pop_per_gpu * ctx.world  # weak scaling: per-GPU work fixed

@@ -154,6 +154,38 @@ __global__ __launch_bounds__(256) void fc_perturb_kernel(const float *parent_sla
     *reinterpret_cast<float4 *>(ch + s0) = make_float4(out[0], out[1], out[2], out[3]);
 }
 
+// New elites without gathering them from whichever GPU evaluated them: elite e of this generation is individual
+// id = order[e] of the population that was bred from `elite_prev` one generation ago, so any rank can rebuild it:
+//   id == 0      -> last generation's best, elite_prev[0], unchanged
+//   id >= 1      -> elite_prev[(id-1) % E] + sigma_prev * eps(seed, stream (id-1, stream_hi_prev))   (same bits as the
+//                   child the owning rank materialised: same kernel arithmetic, same counters)
+__global__ __launch_bounds__(256) void fc_rebuild_elites_kernel(const float *elite_prev, const int32_t *order,
+                                                                 float *elite_new, int E, int D,
+                                                                 const float *sigma_prev_dev, uint64_t seed,
+                                                                 uint32_t stream_hi_prev)
+{
+    const int e = blockIdx.y;
+    const int64_t stride = fc_stride(D), P = fc_params(D);
+    const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (s0 >= stride) return;
+    const int id = order[e];
+    float *dst = elite_new + (int64_t)e * stride;
+    if (id == 0) {
+        *reinterpret_cast<float4 *>(dst + s0) = *reinterpret_cast<const float4 *>(elite_prev + s0);
+        return;
+    }
+    const int c = id - 1;
+    const float sigma = *sigma_prev_dev;
+    const float4 pv = *reinterpret_cast<const float4 *>(elite_prev + (int64_t)(c % E) * stride + s0);
+    float z[4];
+    slab_quad_normals(seed, (uint32_t)c, stream_hi_prev, s0, D, P, z);
+    const float in[4] = {pv.x, pv.y, pv.z, pv.w};
+    float out[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = (s0 + i >= P) ? in[i] : in[i] + sigma * z[i];
+    *reinterpret_cast<float4 *>(dst + s0) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
 __global__ __launch_bounds__(256) void fc_gather_kernel(const float *src_slab, const int32_t *src_idx,
                                                          float *dst_slab, int dst_first, int64_t stride)
 {
@@ -262,6 +294,20 @@ extern "C" int coevo_fc_perturb(const float *parent_slab, const int32_t *parent_
     const dim3 grid((unsigned)((fc_stride(D) / 4 + 255) / 256), (unsigned)n_children);
     hipLaunchKernelGGL(fc_perturb_kernel, grid, dim3(256), 0, (hipStream_t)stream, parent_slab, parent_idx,
                        child_slab, child_first, D, sigma_dev, seed, stream_lo_first, stream_hi, skip_layernorm);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_fc_rebuild_elites(const float *elite_prev, const int32_t *order, float *elite_new, int E, int D,
+                                       const float *sigma_prev_dev, uint64_t seed, uint32_t stream_hi_prev,
+                                       void *stream)
+{
+    if (!elite_prev || !order || !elite_new || !sigma_prev_dev || !fc_dim_ok(D) || E <= 0 || E > 65535)
+        return COEVO_ERR_ARG;
+    if (elite_prev == elite_new) return COEVO_ERR_ARG;  // elite e reads several previous elites: never in place
+    const dim3 grid((unsigned)((fc_stride(D) / 4 + 255) / 256), (unsigned)E);
+    hipLaunchKernelGGL(fc_rebuild_elites_kernel, grid, dim3(256), 0, (hipStream_t)stream, elite_prev, order, elite_new,
+                       E, D, sigma_prev_dev, seed, stream_hi_prev);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

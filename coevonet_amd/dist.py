@@ -17,14 +17,18 @@ import torch.distributed as dist
 
 def allgather_shards(local: torch.Tensor, world: int) -> torch.Tensor:
     """local [R, n_local, C] (this rank's contiguous index range of every role) -> [R, world*n_local, C], rank-major
-    along the index axis.  One all_gather_into_tensor."""
+    along the index axis.  One all_gather_into_tensor (RCCL on device tensors; gloo moves device tensors through the
+    host, which is how the N>1 path is rehearsed with several ranks on one GPU)."""
     if world == 1:
         return local
     R, n_local, Cc = local.shape
+    dev = local.device
     flat_in = local.contiguous().reshape(-1)
-    out = torch.empty(world * flat_in.numel(), dtype=local.dtype, device=local.device)
+    if dist.get_backend() == "gloo" and flat_in.is_cuda:
+        flat_in = flat_in.cpu()
+    out = torch.empty(world * flat_in.numel(), dtype=local.dtype, device=flat_in.device)
     dist.all_gather_into_tensor(out, flat_in)  # flat in, flat out: the form both RCCL and gloo accept
-    return out.reshape(world, R, n_local, Cc).permute(1, 0, 2, 3).reshape(R, world * n_local, Cc)
+    return out.to(dev).reshape(world, R, n_local, Cc).permute(1, 0, 2, 3).reshape(R, world * n_local, Cc)
 
 
 class DistContext:
@@ -35,9 +39,10 @@ class DistContext:
         if self.world > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+            backend = backend or os.environ.get("COEVO_DIST_BACKEND") or \
+                ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
-                torch.cuda.set_device(self.local_rank)
+                torch.cuda.set_device(self.local_rank % max(torch.cuda.device_count(), 1))
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
 
     def gather_ga(self, eng):
@@ -60,7 +65,7 @@ class DistContext:
     def max_over_ranks(self, seconds: float, device) -> float:
         if self.world == 1:
             return seconds
-        t = torch.tensor([seconds], dtype=torch.float64, device=device)
+        t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 

@@ -92,7 +92,8 @@ class GAEngine:
         self.base, off = {}, 0
         for r in ROLES:
             self.base[r] = {}
-            for region, count in (("pop", pop), ("hof", hof), ("elite", elites), ("stale", 1), ("hof_tmp", hof)):
+            for region, count in (("pop", pop), ("hof", hof), ("elite", elites), ("stale", 1), ("hof_tmp", hof),
+                                  ("elite_prev", elites)):
                 self.base[r][region] = off
                 off += count * self.stride[r]
         self.slab = torch.zeros(off, dtype=torch.float32, device=device)
@@ -134,6 +135,7 @@ class GAEngine:
         self.fitness = {r: torch.zeros(pop, **f32) for r in ROLES}
         self.order = {r: torch.zeros(pop, dtype=torch.int32, device=device) for r in ROLES}
         self.sigma = {r: torch.zeros(1, **f32) for r in ROLES}
+        self.sigma_prev = {r: torch.zeros(1, **f32) for r in ROLES}
         self.last_reward = torch.zeros(3, pop, 3, dtype=torch.float64, device=device)  # [role][i][triple]
         self.parent_idx = torch.tensor([c % elites for c in range(max(pop - 1, 1))], dtype=torch.int32, device=device)
         self.hof_shift_idx = torch.arange(1, max(hof, 2), dtype=torch.int32, device=device)
@@ -247,16 +249,30 @@ class GAEngine:
             L.call("coevo_rank_desc", L._p(self.fitness[r]), self.pop, L._p(self.order[r]))
 
     def breed_device(self, gen, sigmas):
-        """elites -> elite buffer, HoF FIFO, population := [best] + (pop-1) mutated clones, all on the device"""
+        """elites -> elite buffer, HoF FIFO, population := [best] + (pop-1) mutated clones, all on the device.
+
+        One GPU: the elites are gathered out of the population slab.  Several GPUs: a rank holds only its own shard of
+        the population, so (from generation 1 on) every rank REBUILDS the elites from last generation's elites and the
+        counter-based noise (coevo_fc_rebuild_elites) and materialises only the children of its own shard - breeding
+        cost per GPU does not grow with the number of GPUs and no weight crosses xGMI."""
+        sharded = self.world > 1
         for ri, r in enumerate(ROLES):
             D = ROLE_D[r]
+            if sharded and gen > 0:
+                L.call("coevo_fc_gather", self._ptr(r, "elite"), L._p(self.iota), self._ptr(r, "elite_prev"), 0, self.E, D)
+                L.call("coevo_fc_rebuild_elites", self._ptr(r, "elite_prev"), L._p(self.order[r]), self._ptr(r, "elite"),
+                       self.E, D, L._p(self.sigma_prev[r]), self.philox_seed, (gen - 1) * 4 + ri)
+            else:  # generation 0's population is the host-initialised one, present on every rank
+                L.call("coevo_fc_gather", self._ptr(r, "pop"), L._p(self.order[r]), self._ptr(r, "elite"), 0, self.E, D)
             self.sigma[r].fill_(float(sigmas[r]))
-            L.call("coevo_fc_gather", self._ptr(r, "pop"), L._p(self.order[r]), self._ptr(r, "elite"), 0, self.E, D)
+            self.sigma_prev[r].fill_(float(sigmas[r]))
             self._hof_push(r)
             L.call("coevo_fc_gather", self._ptr(r, "elite"), L._p(self.iota), self._ptr(r, "pop"), 0, 1, D)
-            if self.pop > 1:
-                L.call("coevo_fc_perturb", self._ptr(r, "elite"), L._p(self.parent_idx), self._ptr(r, "pop"), 1,
-                       self.pop - 1, D, L._p(self.sigma[r]), self.philox_seed, 0, gen * 4 + ri, 0)
+            c_lo, c_hi = (max(self.lo, 1) - 1, self.hi - 1) if sharded else (0, self.pop - 1)  # child c = individual c+1
+            if c_hi > c_lo:
+                L.call("coevo_fc_perturb", self._ptr(r, "elite"), self.parent_idx.data_ptr() + 4 * c_lo,
+                       self._ptr(r, "pop"), 1 + c_lo, c_hi - c_lo, D, L._p(self.sigma[r]), self.philox_seed, c_lo,
+                       gen * 4 + ri, 0)
 
     def _hof_push(self, r):
         """hof.append(best); hof.pop(0)  (genetic_algorithm.py:270-275)"""

@@ -159,6 +159,12 @@ int coevo_mpe_policy_cycle_stamped(const float *slab, const coevo_fc_task *tasks
 int coevo_fc_perturb(const float *parent_slab, const int32_t *parent_idx, float *child_slab, int child_first,
                      int n_children, int D, const float *sigma_dev, uint64_t seed, uint32_t stream_lo_first,
                      uint32_t stream_hi, int skip_layernorm, void *stream);
+/* Multi-GPU Co-GA: this generation's elites (ids order[0..E-1] on the device) rebuilt from LAST generation's elites
+ * and the counter-based noise their children were bred with (id 0 = last best unchanged, id >= 1 = elite_prev[(id-1)%E]
+ * + sigma_prev*eps(stream (id-1, stream_hi_prev))): no weight crosses xGMI, every rank gets identical bits.
+ * GA mutation touches every parameter (LayerNorm included). elite_new must not alias elite_prev. */
+int coevo_fc_rebuild_elites(const float *elite_prev, const int32_t *order, float *elite_new, int E, int D,
+                            const float *sigma_prev_dev, uint64_t seed, uint32_t stream_hi_prev, void *stream);
 /* net copies inside/between slabs driven by device-resident indices: dst[dst_first+i] = src[src_idx[i]] */
 int coevo_fc_gather(const float *src_slab, const int32_t *src_idx, float *dst_slab, int dst_first, int n, int D,
                     void *stream);
