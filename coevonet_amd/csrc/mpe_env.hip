@@ -53,12 +53,14 @@ __device__ inline u128 pcg_advance(u128 state, u128 inc, uint64_t delta)
 // 64-bit output for even ordinals, the kept high half for odd ones; Lemire range 2 => top bit), then ten
 // uniform(-1,1) doubles.  Two resets consume 21 raw 64-bit outputs.
 __global__ void mpe_reset_kernel(double *st, int n, int game_first, int count, coevo_pcg64 rng,
-                                 uint64_t first_ordinal)
+                                 int64_t first_ordinal, const int32_t *gen_dev, int64_t ordinals_per_gen)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const int g = game_first + i;
-    const uint64_t ordinal = first_ordinal + (uint64_t)i;
+    int64_t first = first_ordinal + (gen_dev ? (int64_t)(*gen_dev) * ordinals_per_gen : 0);
+    if (first < 0) first = 0;  // a batch that is disabled in this generation (e.g. no previous evaluation yet)
+    const uint64_t ordinal = (uint64_t)first + (uint64_t)i;
     const u128 inc = ((u128)rng.pcg_inc_hi << 64) | rng.pcg_inc_lo;
     u128 s = ((u128)rng.pcg_state_hi << 64) | rng.pcg_state_lo;
     s = pcg_advance(s, inc, (ordinal >> 1) * 21);
@@ -166,13 +168,26 @@ __global__ void mpe_rewards_kernel(const double *st, int n, double *rewards)
 
 }  // namespace coevo
 
+extern "C" int coevo_mpe_reset_gen(double *state, int n_games, int game_first, int count, coevo_pcg64 rng,
+                                   int64_t first_ordinal, const int32_t *gen_dev, int64_t ordinals_per_gen,
+                                   void *stream)
+{
+    if (!state || n_games <= 0 || game_first < 0 || count < 0 || game_first + count > n_games) return COEVO_ERR_ARG;
+    if (count == 0) return COEVO_OK;
+    hipLaunchKernelGGL(coevo::mpe_reset_kernel, dim3((count + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                       state, n_games, game_first, count, rng, first_ordinal, gen_dev, ordinals_per_gen);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
 extern "C" int coevo_mpe_reset(double *state, int n_games, int game_first, int count, coevo_pcg64 rng,
                                uint64_t first_ordinal, void *stream)
 {
     if (!state || n_games <= 0 || game_first < 0 || count < 0 || game_first + count > n_games) return COEVO_ERR_ARG;
     if (count == 0) return COEVO_OK;
     hipLaunchKernelGGL(coevo::mpe_reset_kernel, dim3((count + 127) / 128), dim3(128), 0, (hipStream_t)stream,
-                       state, n_games, game_first, count, rng, first_ordinal);
+                       state, n_games, game_first, count, rng, (int64_t)first_ordinal, (const int32_t *)nullptr,
+                       (int64_t)0);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

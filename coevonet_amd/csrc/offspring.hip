@@ -131,8 +131,9 @@ __global__ __launch_bounds__(256) void fc_perturb_kernel(const float *parent_sla
                                                           float *child_slab, int child_first, int D,
                                                           const float *sigma_dev, uint64_t seed,
                                                           uint32_t stream_lo_first, uint32_t stream_hi,
-                                                          int skip_layernorm)
+                                                          int skip_layernorm, const int32_t *gen_dev)
 {
+    if (gen_dev) stream_hi += 4u * (uint32_t)(*gen_dev);  // generation-indexed noise stream without a host argument
     const int c = blockIdx.y;
     const int64_t stride = fc_stride(D), P = fc_params(D);
     const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -162,8 +163,9 @@ __global__ __launch_bounds__(256) void fc_perturb_kernel(const float *parent_sla
 __global__ __launch_bounds__(256) void fc_rebuild_elites_kernel(const float *elite_prev, const int32_t *order,
                                                                  float *elite_new, int E, int D,
                                                                  const float *sigma_prev_dev, uint64_t seed,
-                                                                 uint32_t stream_hi_prev)
+                                                                 uint32_t stream_hi_prev, const int32_t *gen_dev)
 {
+    if (gen_dev) stream_hi_prev += 4u * (uint32_t)(*gen_dev - 1);
     const int e = blockIdx.y;
     const int64_t stride = fc_stride(D), P = fc_params(D);
     const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -284,30 +286,44 @@ extern "C" int coevo_fc_unpack(const float *slab, float *flat, int n, int D, voi
     return COEVO_OK;
 }
 
+extern "C" int coevo_fc_perturb_gen(const float *parent_slab, const int32_t *parent_idx, float *child_slab,
+                                    int child_first, int n_children, int D, const float *sigma_dev, uint64_t seed,
+                                    uint32_t stream_lo_first, uint32_t stream_hi, int skip_layernorm,
+                                    const int32_t *gen_dev, void *stream);
+
 extern "C" int coevo_fc_perturb(const float *parent_slab, const int32_t *parent_idx, float *child_slab,
                                 int child_first, int n_children, int D, const float *sigma_dev, uint64_t seed,
                                 uint32_t stream_lo_first, uint32_t stream_hi, int skip_layernorm, void *stream)
+{
+    return coevo_fc_perturb_gen(parent_slab, parent_idx, child_slab, child_first, n_children, D, sigma_dev, seed,
+                                stream_lo_first, stream_hi, skip_layernorm, nullptr, stream);
+}
+
+extern "C" int coevo_fc_perturb_gen(const float *parent_slab, const int32_t *parent_idx, float *child_slab,
+                                    int child_first, int n_children, int D, const float *sigma_dev, uint64_t seed,
+                                    uint32_t stream_lo_first, uint32_t stream_hi, int skip_layernorm,
+                                    const int32_t *gen_dev, void *stream)
 {
     if (!parent_slab || !parent_idx || !child_slab || !sigma_dev || !fc_dim_ok(D)) return COEVO_ERR_ARG;
     if (n_children < 0 || child_first < 0 || n_children > 65535) return COEVO_ERR_ARG;
     if (n_children == 0) return COEVO_OK;
     const dim3 grid((unsigned)((fc_stride(D) / 4 + 255) / 256), (unsigned)n_children);
     hipLaunchKernelGGL(fc_perturb_kernel, grid, dim3(256), 0, (hipStream_t)stream, parent_slab, parent_idx,
-                       child_slab, child_first, D, sigma_dev, seed, stream_lo_first, stream_hi, skip_layernorm);
+                       child_slab, child_first, D, sigma_dev, seed, stream_lo_first, stream_hi, skip_layernorm, gen_dev);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }
 
 extern "C" int coevo_fc_rebuild_elites(const float *elite_prev, const int32_t *order, float *elite_new, int E, int D,
                                        const float *sigma_prev_dev, uint64_t seed, uint32_t stream_hi_prev,
-                                       void *stream)
+                                       const int32_t *gen_dev, void *stream)
 {
     if (!elite_prev || !order || !elite_new || !sigma_prev_dev || !fc_dim_ok(D) || E <= 0 || E > 65535)
         return COEVO_ERR_ARG;
     if (elite_prev == elite_new) return COEVO_ERR_ARG;  // elite e reads several previous elites: never in place
     const dim3 grid((unsigned)((fc_stride(D) / 4 + 255) / 256), (unsigned)E);
     hipLaunchKernelGGL(fc_rebuild_elites_kernel, grid, dim3(256), 0, (hipStream_t)stream, elite_prev, order, elite_new,
-                       E, D, sigma_prev_dev, seed, stream_hi_prev);
+                       E, D, sigma_prev_dev, seed, stream_hi_prev, gen_dev);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

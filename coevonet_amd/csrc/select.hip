@@ -100,9 +100,86 @@ __global__ __launch_bounds__(256) void rank_desc_kernel(const float *fitness, in
     }
 }
 
+// np.mean of n <= 10 float64 values exactly as numpy computes it (pairwise_sum: n < 8 sequential from 0; otherwise
+// eight running sums combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), remainder added sequentially), then / n
+__device__ inline double np_mean_le10(const double *a, int n)
+{
+    double res;
+    if (n < 8) {
+        res = 0.0;
+        for (int i = 0; i < n; ++i) res += a[i];
+    } else {
+        res = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        for (int i = 8; i < n; ++i) res += a[i];
+    }
+    return res / (double)n;
+}
+
+// evaluate_current_weights' means (genetic_algorithm.py:12-29) of the generation that finished one generation ago +
+// the adaptive mutation power rule (:323-345, quirk Q5: agent_0's increase starts from agent_1's sigma), on the device
+// so that a generation needs no host round trip.  *gen_dev = g: the evaluation games in `rewards` belong to g-1.
+__global__ void ga_adapt_kernel(const double *rewards, int eval_first, const int32_t *gen_dev, double *hist,
+                                double *sig_hist, int cap, double *sigma64, float *sigma32, double sig_min,
+                                double sig_max, int adaptive)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int g = *gen_dev;
+    if (g > 0 && g - 1 < cap) {
+        const int e = g - 1;
+        for (int s = 0; s < 3; ++s) {
+            double tot = 0.0;
+            for (int i = 0; i < 10; ++i) tot += rewards[3 * (size_t)(eval_first + i) + s];
+            hist[(size_t)s * cap + e] = tot / 10;
+        }
+        if (adaptive) {
+            bool worse[3];
+            for (int s = 0; s < 3; ++s) {
+                const double *h = hist + (size_t)s * cap;
+                const int len = e + 1;
+                if (e > 10) {
+                    const int n_old = (len >= 20) ? 10 : len - 10;   // h[-20:-10]
+                    const double m_new = np_mean_le10(h + len - 10, 10);
+                    const double m_old = np_mean_le10(h + (len >= 20 ? len - 20 : 0), n_old);
+                    worse[s] = m_new < m_old;
+                } else {
+                    worse[s] = false;
+                }
+            }
+            const double s1_before = sigma64[1];
+            sigma64[0] = worse[0] ? fmin(s1_before * 1.2, sig_max) : fmax(sigma64[0] * 0.95, sig_min);
+            sigma64[1] = worse[1] ? fmin(sigma64[1] * 1.2, sig_max) : fmax(sigma64[1] * 0.95, sig_min);
+            sigma64[2] = worse[2] ? fmin(sigma64[2] * 1.2, sig_max) : fmax(sigma64[2] * 0.95, sig_min);
+        }
+        for (int s = 0; s < 3; ++s) sig_hist[(size_t)s * cap + e] = sigma64[s];
+    }
+    for (int s = 0; s < 3; ++s) sigma32[s] = (float)sigma64[s];
+}
+
+__global__ void counter_add_kernel(int32_t *p, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += v; }
+
 }  // namespace coevo
 
 using namespace coevo;
+
+extern "C" int coevo_ga_adapt_sigma(const double *rewards, int eval_first_game, const int32_t *gen_dev, double *hist,
+                                    double *sig_hist, int cap, double *sigma64, float *sigma32, double sig_min,
+                                    double sig_max, int adaptive, void *stream)
+{
+    if (!rewards || !gen_dev || !hist || !sig_hist || !sigma64 || !sigma32 || cap <= 0 || eval_first_game < 0)
+        return COEVO_ERR_ARG;
+    hipLaunchKernelGGL(ga_adapt_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rewards, eval_first_game, gen_dev,
+                       hist, sig_hist, cap, sigma64, sigma32, sig_min, sig_max, adaptive);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_counter_add(int32_t *counter, int value, void *stream)
+{
+    if (!counter) return COEVO_ERR_ARG;
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, value);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
 
 extern "C" int coevo_fc_diversity(const float *ref_net, const float *pop_slab, int n, int D, float *dist,
                                   float *score, void *stream)

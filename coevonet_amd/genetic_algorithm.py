@@ -261,7 +261,7 @@ class GAEngine:
             if sharded and gen > 0:
                 L.call("coevo_fc_gather", self._ptr(r, "elite"), L._p(self.iota), self._ptr(r, "elite_prev"), 0, self.E, D)
                 L.call("coevo_fc_rebuild_elites", self._ptr(r, "elite_prev"), L._p(self.order[r]), self._ptr(r, "elite"),
-                       self.E, D, L._p(self.sigma_prev[r]), self.philox_seed, (gen - 1) * 4 + ri)
+                       self.E, D, L._p(self.sigma_prev[r]), self.philox_seed, (gen - 1) * 4 + ri, None)
             else:  # generation 0's population is the host-initialised one, present on every rank
                 L.call("coevo_fc_gather", self._ptr(r, "pop"), L._p(self.order[r]), self._ptr(r, "elite"), 0, self.E, D)
             self.sigma[r].fill_(float(sigmas[r]))
@@ -308,6 +308,77 @@ class GAEngine:
 
     def elite_ids(self):
         return {r: self.order[r][:self.E].cpu().numpy().astype(int).tolist() for r in ROLES}
+
+    # ------------------------------------------------------------------ whole generation on the device, one graph
+    def setup_device_loop(self, args, capacity):
+        """state for the host-free generation loop: generation counter, float64 sigma master copy + float32 copy for
+        the perturb kernel, evaluation-reward and sigma histories (what the reference keeps in python lists)"""
+        dev = self.device
+        self.gen_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.sigma64 = torch.tensor([getattr(args, SIGMA_ATTR[r]) for r in ROLES], dtype=torch.float64, device=dev)
+        self.sigma32 = self.sigma64.to(torch.float32)
+        self.sigma32_prev = self.sigma32.clone()
+        self.cap = int(max(capacity, 1))
+        self.hist = torch.zeros(3, self.cap, dtype=torch.float64, device=dev)
+        self.sig_hist = torch.zeros(3, self.cap, dtype=torch.float64, device=dev)
+        self.loop_args = (float(args.min_mutation_power), float(args.max_mutation_power), 1 if args.adaptive else 0)
+        self._gen_graph = None
+
+    def enqueue_generation(self):
+        """reset -> 25 cycles -> rewards -> sharing/fitness/rank -> evaluation means + adaptive sigma -> HoF push and
+        offspring -> generation counter tick; every launch takes the generation from the device counter, so the
+        captured graph is replayed unchanged generation after generation"""
+        assert self.world == 1 and self.env_mode == "device"
+        ro, M = self.ro, 3 * self.pop * self.hof
+        per_gen, per_phase = M + N_EVAL, self.pop * self.hof
+        g = L._p(self.gen_dev)
+        for ph in range(3):
+            L.call("coevo_mpe_reset_gen", L._p(ro.state), self.plan.n_games, ph * per_phase, per_phase, ro.rng,
+                   self.first_ordinal + ph * per_phase, g, per_gen)
+        L.call("coevo_mpe_reset_gen", L._p(ro.state), self.plan.n_games, self.n_main, N_EVAL, ro.rng,
+               self.first_ordinal - per_gen + M, g, per_gen)
+        ro.enqueue(self.n_cycles)
+        for ph, r in enumerate(ROLES):
+            D = ROLE_D[r]
+            L.call("coevo_fc_diversity", self._ptr(r, "stale"), self._ptr(r, "pop"), self.pop, D, L._p(self.dist[r]),
+                   L._p(self.div[r]))
+            L.call("coevo_ga_fitness", L._p(ro.rewards), ph * per_phase, self.pop, self.hof, self.hof, RET_SLOT[r],
+                   L._p(self.div[r]), L._p(self.fitness[r]))
+            L.call("coevo_rank_desc", L._p(self.fitness[r]), self.pop, L._p(self.order[r]))
+        mn, mx, adaptive = self.loop_args
+        L.call("coevo_ga_adapt_sigma", L._p(ro.rewards), self.n_main, g, L._p(self.hist), L._p(self.sig_hist), self.cap,
+               L._p(self.sigma64), L._p(self.sigma32), mn, mx, adaptive)
+        for ri, r in enumerate(ROLES):
+            D = ROLE_D[r]
+            L.call("coevo_fc_gather", self._ptr(r, "pop"), L._p(self.order[r]), self._ptr(r, "elite"), 0, self.E, D)
+            self._hof_push(r)
+            L.call("coevo_fc_gather", self._ptr(r, "elite"), L._p(self.iota), self._ptr(r, "pop"), 0, 1, D)
+            if self.pop > 1:
+                L.call("coevo_fc_perturb_gen", self._ptr(r, "elite"), L._p(self.parent_idx), self._ptr(r, "pop"), 1,
+                       self.pop - 1, D, self.sigma32.data_ptr() + 4 * ri, self.philox_seed, 0, ri, 0, g)
+        L.call("coevo_counter_add", g, 1)
+
+    def replay_generation(self, gen):
+        if gen <= 1:  # the evaluation games of "generation -1" do not exist: disabled in generation 0 only
+            limits = np.zeros(self.plan.n_games, dtype=np.int32)
+            limits[:self.n_main] = self.T_train
+            if gen == 1:
+                limits[self.n_main:] = self.T_eval
+            self.ro.set_limits(limits)
+        if self.ro.use_graph:
+            key = bool(self.ro.time_light)
+            if self._gen_graph is None:
+                self._gen_graph = {}
+            if key not in self._gen_graph:
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    self.enqueue_generation()
+                self._gen_graph[key] = gr
+                # the capture did not execute anything: the counter still holds `gen`
+            self._gen_graph[key].replay()
+        else:
+            self.enqueue_generation()
 
 
 # --------------------------------------------------------------------------------------------- trainer
@@ -361,11 +432,25 @@ class GATrainer:
         self.res = GAResult()
         self.res.engine = self.eng
         self.gen = 0
+        # the host-free generation loop needs device-built offspring, the device env and a single rank
+        self.device_loop = (self.rng == "device_philox" and env_mode == "device" and shard == (0, 1)
+                            and getattr(args, "coevo_device_loop", True))
+        if self.device_loop:
+            self.eng.setup_device_loop(args, capacity=max(getattr(args, "generations", 0), 1) + 64)
 
     def step(self):
         """generation self.gen: play its games (+ the previous generation's 10 evaluation games), select, breed"""
         eng, args, res, gen = self.eng, self.args, self.res, self.gen
         t0 = time.perf_counter()
+        if self.device_loop:
+            # no host round trip: evaluation means, adaptive sigma, selection and offspring all stay on the device;
+            # the host only enqueues (replays) the generation and may run ahead of the GPU
+            eng.replay_generation(gen)
+            if self.collect:
+                self._collect_device_loop(gen)
+            res.seconds.append(time.perf_counter() - t0)
+            self.gen += 1
+            return
         eng.rollout(gen, with_prev_eval=gen > 0)
         if gen > 0:
             _finish_generation(args, gen - 1, eng.eval_rewards(), res)
@@ -383,9 +468,35 @@ class GATrainer:
         res.seconds.append(time.perf_counter() - t0)
         self.gen += 1
 
+    def _collect_device_loop(self, gen):
+        eng, res, args = self.eng, self.res, self.args
+        eng.ro.check_status()
+        eng.ro.collect_stamps()
+        res.game_rewards.append(eng.rewards_host()[:eng.n_main].copy())
+        res.fitness.append([eng.fitness[r].cpu().numpy().tolist() for r in ROLES])
+        res.diversity.append([float(eng.div[r].item()) for r in ROLES])
+        res.elite_ids.append([eng.elite_ids()[r] for r in ROLES])
+        self._sync_history_from_device(upto=gen)  # evaluation means / sigmas of generations < gen are final
+
+    def _sync_history_from_device(self, upto):
+        """mirror the device-resident histories into the result and the (mutable, reference-style) args bag"""
+        eng, res, args = self.eng, self.res, self.args
+        hist = eng.hist[:, :upto].cpu().numpy()
+        sig = eng.sig_hist[:, :upto].cpu().numpy()
+        for s, r in enumerate(ROLES):
+            res.rewards[r] = [float(x) for x in hist[s]]
+        res.sigma_after = [[float(sig[0, e]), float(sig[1, e]), float(sig[2, e])] for e in range(upto)]
+        cur = eng.sigma64.cpu().numpy()
+        args.mutation_power_agent_0, args.mutation_power_agent_1, args.mutation_power_adversary = (
+            float(cur[0]), float(cur[1]), float(cur[2]))
+
     def finish(self):
         """flush the last generation's evaluation games and leave the env's reset counter where the reference would"""
         if self.gen > 0:
+            if self.device_loop:
+                torch.cuda.synchronize()
+                self.eng.ro.check_status()
+                self._sync_history_from_device(upto=self.gen - 1)
             _finish_generation(self.args, self.gen - 1, self.eng.eval_only(self.gen - 1), self.res)
         if hasattr(self.env, "n_resets"):
             self.env.n_resets = self.first_ordinal + self.gen * (3 * self.args.population * self.args.hof_size + N_EVAL)

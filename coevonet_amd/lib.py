@@ -66,6 +66,8 @@ _SIGS = {
     "coevo_fc_forward_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "coevo_mpe_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, PCG64State, C.c_uint64, C.c_void_p]),
+    "coevo_mpe_reset_gen": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, PCG64State, C.c_int64, C.c_void_p,
+                                      C.c_int64, C.c_void_p]),
     "coevo_mpe_observe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "coevo_mpe_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                  C.c_void_p]),
@@ -89,7 +91,12 @@ _SIGS = {
     "coevo_fc_perturb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]),
     "coevo_fc_rebuild_elites": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64,
-                                          C.c_uint32, C.c_void_p]),
+                                          C.c_uint32, C.c_void_p, C.c_void_p]),
+    "coevo_fc_perturb_gen": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
+    "coevo_ga_adapt_sigma": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p]),
+    "coevo_counter_add": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "coevo_fc_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "coevo_es_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float,
                                   C.c_void_p]),

@@ -185,6 +185,14 @@ class DeviceRollout:
         self.desc.n_cycles = n_cycles
         L.call("coevo_mpe_rollout", L.C.byref(self.desc), ctx, 1 if timed else 0)
 
+    def enqueue(self, n_cycles):
+        """plain enqueue on the current stream (no graph of its own): for callers that capture a larger graph"""
+        self.desc.light_stamps = L._p(self.stamps) if self.time_light else None
+        self.desc.n_cycles = int(n_cycles)
+        L.call("coevo_mpe_rollout", L.C.byref(self.desc), self.ctx if self.overlap else None, 0)
+        if self.time_light:
+            self._pending_stamps = int(n_cycles)
+
     def collect_stamps(self):
         """after the replay has finished (the caller synchronised): fold this replay's clock stamps into the log"""
         n = getattr(self, "_pending_stamps", 0)

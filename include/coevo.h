@@ -96,6 +96,10 @@ typedef struct {
  * utils/game_logic_functions.py:54); each game jumps straight to its ordinal, so shards need no common prefix. */
 int coevo_mpe_reset(double *state, int n_games, int game_first, int count, coevo_pcg64 rng, uint64_t first_ordinal,
                     void *stream);
+/* the same with the generation taken from a device counter: first ordinal = first_ordinal + (*gen_dev) *
+ * ordinals_per_gen (clamped at 0), so a captured hipGraph of a whole generation can be replayed unchanged */
+int coevo_mpe_reset_gen(double *state, int n_games, int game_first, int count, coevo_pcg64 rng, int64_t first_ordinal,
+                        const int32_t *gen_dev, int64_t ordinals_per_gen, void *stream);
 /* obs rows for (game, slot) pairs: row r observes game row_game[r] as slot row_slot[r] (float32 casts of fp64
  * differences, PettingZoo SimpleEnv.observe). */
 int coevo_mpe_observe(const double *state, int n_games, const int32_t *row_game, const int32_t *row_slot,
@@ -159,12 +163,17 @@ int coevo_mpe_policy_cycle_stamped(const float *slab, const coevo_fc_task *tasks
 int coevo_fc_perturb(const float *parent_slab, const int32_t *parent_idx, float *child_slab, int child_first,
                      int n_children, int D, const float *sigma_dev, uint64_t seed, uint32_t stream_lo_first,
                      uint32_t stream_hi, int skip_layernorm, void *stream);
+/* coevo_fc_perturb with the generation taken from a device counter: stream_hi_eff = stream_hi + 4 * (*gen_dev) */
+int coevo_fc_perturb_gen(const float *parent_slab, const int32_t *parent_idx, float *child_slab, int child_first,
+                         int n_children, int D, const float *sigma_dev, uint64_t seed, uint32_t stream_lo_first,
+                         uint32_t stream_hi, int skip_layernorm, const int32_t *gen_dev, void *stream);
 /* Multi-GPU Co-GA: this generation's elites (ids order[0..E-1] on the device) rebuilt from LAST generation's elites
  * and the counter-based noise their children were bred with (id 0 = last best unchanged, id >= 1 = elite_prev[(id-1)%E]
  * + sigma_prev*eps(stream (id-1, stream_hi_prev))): no weight crosses xGMI, every rank gets identical bits.
  * GA mutation touches every parameter (LayerNorm included). elite_new must not alias elite_prev. */
 int coevo_fc_rebuild_elites(const float *elite_prev, const int32_t *order, float *elite_new, int E, int D,
-                            const float *sigma_prev_dev, uint64_t seed, uint32_t stream_hi_prev, void *stream);
+                            const float *sigma_prev_dev, uint64_t seed, uint32_t stream_hi_prev,
+                            const int32_t *gen_dev /* or NULL; adds 4*(*gen_dev - 1) */, void *stream);
 /* net copies inside/between slabs driven by device-resident indices: dst[dst_first+i] = src[src_idx[i]] */
 int coevo_fc_gather(const float *src_slab, const int32_t *src_idx, float *dst_slab, int dst_first, int n, int D,
                     void *stream);
@@ -194,6 +203,16 @@ int coevo_ga_fitness(const double *rewards, int game_first, int pop, int games_p
 /* order = np.argsort(fitness)[::-1] (genetic_algorithm.py:223-225; stable ascending sort reversed, so ties put the
  * HIGHER index first, quirk Q13).  n <= 4096. */
 int coevo_rank_desc(const float *fitness, int n, int32_t *order, void *stream);
+
+/* evaluate_current_weights' 10-game means (genetic_algorithm.py:12-29) + the adaptive mutation power rule (:323-345,
+ * quirk Q5) on the device, arithmetic identical to the reference's numpy/python float64 (np.mean's pairwise order
+ * included).  *gen_dev = g: rewards[eval_first_game .. +9] are generation g-1's evaluation games; their means are
+ * appended to hist[3][cap] at index g-1, sigma64[3] (agent_0, agent_1, adversary) is updated when `adaptive`, logged to
+ * sig_hist[3][cap] and rounded into sigma32[3] for coevo_fc_perturb.  g == 0 only refreshes sigma32. */
+int coevo_ga_adapt_sigma(const double *rewards, int eval_first_game, const int32_t *gen_dev, double *hist,
+                         double *sig_hist, int cap, double *sigma64, float *sigma32, double sig_min, double sig_max,
+                         int adaptive, void *stream);
+int coevo_counter_add(int32_t *counter, int value, void *stream);   /* the device generation counter's tick */
 
 /* ---------------------------------------------------------------- K2: DeepQN policy step -------------------- */
 /* DeepQN.forward (Atari/deepqn.py:39-48) + first-max action (the rule its docstring :51-52 intends; the reference's
