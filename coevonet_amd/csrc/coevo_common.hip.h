@@ -103,6 +103,19 @@ __device__ inline float mpe_obs_element(const double *st, int n, int g, int slot
     return (float)(st[(size_t)(src + c) * n + g] - st[(size_t)(2 * slot + c) * n + g]);
 }
 
+// fixed-order block reduction of one double per thread (256 threads): xor tree inside each wave, waves left to right
+__device__ inline double block_sum_f64(double v, double *scratch)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = v + __shfl_xor(v, m, 64);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) scratch[w] = v;
+    __syncthreads();
+    const double tot = ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3];
+    __syncthreads();
+    return tot;
+}
+
 __device__ inline bool bad_post_relu(float y) { return __builtin_isnan(y) || (__builtin_isinf(y) && y > 0.0f); }
 __device__ inline float relu_keep_nan(float y) { return (y > 0.0f) ? y : (__builtin_isnan(y) ? y : 0.0f); }
 

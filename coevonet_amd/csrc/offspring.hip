@@ -131,28 +131,48 @@ __global__ __launch_bounds__(256) void fc_perturb_kernel(const float *parent_sla
                                                           float *child_slab, int child_first, int D,
                                                           const float *sigma_dev, uint64_t seed,
                                                           uint32_t stream_lo_first, uint32_t stream_hi,
-                                                          int skip_layernorm, const int32_t *gen_dev)
+                                                          int skip_layernorm, const int32_t *gen_dev,
+                                                          const float *dist_ref, double *dist_partial)
 {
+    __shared__ double scratch[4];
     if (gen_dev) stream_hi += 4u * (uint32_t)(*gen_dev);  // generation-indexed noise stream without a host argument
     const int c = blockIdx.y;
     const int64_t stride = fc_stride(D), P = fc_params(D);
     const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (s0 >= stride) return;
-    const float sigma = *sigma_dev;
-    const float *par = parent_slab + (int64_t)parent_idx[c] * stride;
-    float *ch = child_slab + (int64_t)(child_first + c) * stride;
-    const float4 pv = *reinterpret_cast<const float4 *>(par + s0);
-    float z[4];
-    slab_quad_normals(seed, stream_lo_first + (uint32_t)c, stream_hi, s0, D, P, z);
-    float in[4] = {pv.x, pv.y, pv.z, pv.w}, out[4];
+    double d2 = 0.0;
+    if (s0 < stride) {
+        const float sigma = *sigma_dev;
+        const float *par = parent_slab + (int64_t)parent_idx[c] * stride;
+        float *ch = child_slab + (int64_t)(child_first + c) * stride;
+        const float4 pv = *reinterpret_cast<const float4 *>(par + s0);
+        float z[4];
+        slab_quad_normals(seed, stream_lo_first + (uint32_t)c, stream_hi, s0, D, P, z);
+        float in[4] = {pv.x, pv.y, pv.z, pv.w}, out[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t s = s0 + i;
-        const bool keep = (s >= P) || (skip_layernorm && fc_slab_is_layernorm(s, D));
-        const float noise = sigma * z[i];  // rounded first, then added (agent.py:28-29)
-        out[i] = keep ? in[i] : in[i] + noise;
+        for (int i = 0; i < 4; ++i) {
+            const int64_t s = s0 + i;
+            const bool keep = (s >= P) || (skip_layernorm && fc_slab_is_layernorm(s, D));
+            const float noise = sigma * z[i];  // rounded first, then added (agent.py:28-29)
+            out[i] = keep ? in[i] : in[i] + noise;
+        }
+        *reinterpret_cast<float4 *>(ch + s0) = make_float4(out[0], out[1], out[2], out[3]);
+        if (dist_partial) {  // fitness-sharing distance of the new child to a reference net, while it is in registers
+            const float4 rv = *reinterpret_cast<const float4 *>(dist_ref + s0);
+            const float ref[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t s = s0 + i;
+                if (s < P && !fc_slab_is_layernorm(s, D)) {
+                    const float d = out[i] - ref[i];
+                    d2 += (double)d * (double)d;
+                }
+            }
+        }
     }
-    *reinterpret_cast<float4 *>(ch + s0) = make_float4(out[0], out[1], out[2], out[3]);
+    if (dist_partial) {  // wave-uniform
+        const double tot = block_sum_f64(d2, scratch);
+        if (threadIdx.x == 0) dist_partial[(size_t)c * gridDim.x + blockIdx.x] = tot;
+    }
 }
 
 // New elites without gathering them from whichever GPU evaluated them: elite e of this generation is individual
@@ -286,17 +306,17 @@ extern "C" int coevo_fc_unpack(const float *slab, float *flat, int n, int D, voi
     return COEVO_OK;
 }
 
-extern "C" int coevo_fc_perturb_gen(const float *parent_slab, const int32_t *parent_idx, float *child_slab,
-                                    int child_first, int n_children, int D, const float *sigma_dev, uint64_t seed,
-                                    uint32_t stream_lo_first, uint32_t stream_hi, int skip_layernorm,
-                                    const int32_t *gen_dev, void *stream);
+extern "C" int coevo_fc_perturb_dist(const float *parent_slab, const int32_t *parent_idx, float *child_slab,
+                                     int child_first, int n_children, int D, const float *sigma_dev, uint64_t seed,
+                                     uint32_t stream_lo_first, uint32_t stream_hi, int skip_layernorm,
+                                     const int32_t *gen_dev, const float *dist_ref, double *dist_partial, void *stream);
 
 extern "C" int coevo_fc_perturb(const float *parent_slab, const int32_t *parent_idx, float *child_slab,
                                 int child_first, int n_children, int D, const float *sigma_dev, uint64_t seed,
                                 uint32_t stream_lo_first, uint32_t stream_hi, int skip_layernorm, void *stream)
 {
-    return coevo_fc_perturb_gen(parent_slab, parent_idx, child_slab, child_first, n_children, D, sigma_dev, seed,
-                                stream_lo_first, stream_hi, skip_layernorm, nullptr, stream);
+    return coevo_fc_perturb_dist(parent_slab, parent_idx, child_slab, child_first, n_children, D, sigma_dev, seed,
+                                 stream_lo_first, stream_hi, skip_layernorm, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int coevo_fc_perturb_gen(const float *parent_slab, const int32_t *parent_idx, float *child_slab,
@@ -304,12 +324,25 @@ extern "C" int coevo_fc_perturb_gen(const float *parent_slab, const int32_t *par
                                     uint32_t stream_lo_first, uint32_t stream_hi, int skip_layernorm,
                                     const int32_t *gen_dev, void *stream)
 {
+    return coevo_fc_perturb_dist(parent_slab, parent_idx, child_slab, child_first, n_children, D, sigma_dev, seed,
+                                 stream_lo_first, stream_hi, skip_layernorm, gen_dev, nullptr, nullptr, stream);
+}
+
+extern "C" int64_t coevo_fc_perturb_blocks(int D) { return fc_dim_ok(D) ? (fc_stride(D) / 4 + 255) / 256 : COEVO_ERR_ARG; }
+
+extern "C" int coevo_fc_perturb_dist(const float *parent_slab, const int32_t *parent_idx, float *child_slab,
+                                     int child_first, int n_children, int D, const float *sigma_dev, uint64_t seed,
+                                     uint32_t stream_lo_first, uint32_t stream_hi, int skip_layernorm,
+                                     const int32_t *gen_dev, const float *dist_ref, double *dist_partial, void *stream)
+{
+    if ((dist_ref == nullptr) != (dist_partial == nullptr)) return COEVO_ERR_ARG;
     if (!parent_slab || !parent_idx || !child_slab || !sigma_dev || !fc_dim_ok(D)) return COEVO_ERR_ARG;
     if (n_children < 0 || child_first < 0 || n_children > 65535) return COEVO_ERR_ARG;
     if (n_children == 0) return COEVO_OK;
     const dim3 grid((unsigned)((fc_stride(D) / 4 + 255) / 256), (unsigned)n_children);
     hipLaunchKernelGGL(fc_perturb_kernel, grid, dim3(256), 0, (hipStream_t)stream, parent_slab, parent_idx,
-                       child_slab, child_first, D, sigma_dev, seed, stream_lo_first, stream_hi, skip_layernorm, gen_dev);
+                       child_slab, child_first, D, sigma_dev, seed, stream_lo_first, stream_hi, skip_layernorm, gen_dev,
+                       dist_ref, dist_partial);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

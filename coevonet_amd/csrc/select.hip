@@ -7,19 +7,6 @@
 
 namespace coevo {
 
-// fixed-order block reduction of one double per thread (256 threads): xor tree inside each wave, waves left to right
-__device__ inline double block_sum_f64(double v, double *scratch)
-{
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v = v + __shfl_xor(v, m, 64);
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) scratch[w] = v;
-    __syncthreads();
-    const double tot = ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3];
-    __syncthreads();
-    return tot;
-}
-
 // dist[i] = || w_i - w_ref ||_2 over the Linear weights and biases only (get_weights_ES default layers,
 // MPE/fcnetwork.py:161: fc1, fc2, output).  One workgroup per population member; squares accumulate in fp64 so the
 // fp32 result does not depend on the summation order.
@@ -47,6 +34,29 @@ __global__ __launch_bounds__(256) void fc_distance_kernel(const float *ref_net, 
     }
     const double tot = block_sum_f64(acc, scratch);
     if (threadIdx.x == 0) dist[blockIdx.x] = (float)sqrt(tot);
+}
+
+// dist[first + c] = sqrt(sum_b partial[c][b]) - finishes the squared distances the perturb kernel accumulated per
+// block; one wavefront per child (lane-strided partial sums, then the xor tree: a fixed order).  If head is given,
+// dist[first - 1] = *head (the unchanged best individual keeps the distance it had in the previous population).
+__global__ __launch_bounds__(64) void dist_finalize_kernel(const double *partial, int n_blocks, float *dist, int first,
+                                                            const float *head)
+{
+    const int c = blockIdx.x, l = threadIdx.x;
+    double v = 0.0;
+    for (int b = l; b < n_blocks; b += 64) v += partial[(size_t)c * n_blocks + b];
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = v + __shfl_xor(v, m, 64);
+    if (l == 0) {
+        dist[first + c] = (float)sqrt(v);
+        if (c == 0 && head) dist[first - 1] = *head;
+    }
+}
+
+__global__ void gather_f32_kernel(float *dst, const float *src, const int32_t *idx, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
 }
 
 // score = sum_i max(0, 1 - d_i / mean(d)), mean rounded to fp32 as np.mean of an fp32 array is
@@ -195,6 +205,24 @@ extern "C" int coevo_fc_distance(const float *ref_net, const float *pop_slab, in
 {
     if (!ref_net || !pop_slab || !dist || n <= 0 || (D != 8 && D != 10)) return COEVO_ERR_ARG;
     hipLaunchKernelGGL(fc_distance_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, ref_net, pop_slab, D, dist);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_fc_distance_finalize(const double *partial, int n_blocks, int n, float *dist, int first,
+                                          const float *head, void *stream)
+{
+    if (!partial || !dist || n_blocks <= 0 || n <= 0 || first < 0 || (head && first < 1)) return COEVO_ERR_ARG;
+    hipLaunchKernelGGL(dist_finalize_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, partial, n_blocks, dist, first,
+                       head);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_gather_f32(float *dst, const float *src, const int32_t *idx, int n, void *stream)
+{
+    if (!dst || !src || !idx || n <= 0) return COEVO_ERR_ARG;
+    hipLaunchKernelGGL(gather_f32_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, dst, src, idx, n);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

@@ -323,6 +323,15 @@ class GAEngine:
         self.sig_hist = torch.zeros(3, self.cap, dtype=torch.float64, device=dev)
         self.loop_args = (float(args.min_mutation_power), float(args.max_mutation_power), 1 if args.adaptive else 0)
         self._gen_graph = None
+        # distances to the stale agent: computed once for the initial population, then accumulated by the perturb
+        # kernel while it writes each new child (no second pass over the 336 MB population)
+        self.pblocks = {r: int(L.load().coevo_fc_perturb_blocks(ROLE_D[r])) for r in ROLES}
+        self.dist_partial = {r: torch.zeros(max(self.pop - 1, 1) * self.pblocks[r], dtype=torch.float64, device=dev)
+                             for r in ROLES}
+        self.best_dist = {r: torch.zeros(1, dtype=torch.float32, device=dev) for r in ROLES}
+        for r in ROLES:
+            L.call("coevo_fc_distance", self._ptr(r, "stale"), self._ptr(r, "pop"), self.pop, ROLE_D[r],
+                   L._p(self.dist[r]))
 
     def enqueue_generation(self):
         """reset -> 25 cycles -> rewards -> sharing/fitness/rank -> evaluation means + adaptive sigma -> HoF push and
@@ -340,8 +349,7 @@ class GAEngine:
         ro.enqueue(self.n_cycles)
         for ph, r in enumerate(ROLES):
             D = ROLE_D[r]
-            L.call("coevo_fc_diversity", self._ptr(r, "stale"), self._ptr(r, "pop"), self.pop, D, L._p(self.dist[r]),
-                   L._p(self.div[r]))
+            L.call("coevo_sharing_score", L._p(self.dist[r]), self.pop, L._p(self.div[r]))
             L.call("coevo_ga_fitness", L._p(ro.rewards), ph * per_phase, self.pop, self.hof, self.hof, RET_SLOT[r],
                    L._p(self.div[r]), L._p(self.fitness[r]))
             L.call("coevo_rank_desc", L._p(self.fitness[r]), self.pop, L._p(self.order[r]))
@@ -353,9 +361,13 @@ class GAEngine:
             L.call("coevo_fc_gather", self._ptr(r, "pop"), L._p(self.order[r]), self._ptr(r, "elite"), 0, self.E, D)
             self._hof_push(r)
             L.call("coevo_fc_gather", self._ptr(r, "elite"), L._p(self.iota), self._ptr(r, "pop"), 0, 1, D)
+            L.call("coevo_gather_f32", L._p(self.best_dist[r]), L._p(self.dist[r]), L._p(self.order[r]), 1)  # the best
             if self.pop > 1:
-                L.call("coevo_fc_perturb_gen", self._ptr(r, "elite"), L._p(self.parent_idx), self._ptr(r, "pop"), 1,
-                       self.pop - 1, D, self.sigma32.data_ptr() + 4 * ri, self.philox_seed, 0, ri, 0, g)
+                L.call("coevo_fc_perturb_dist", self._ptr(r, "elite"), L._p(self.parent_idx), self._ptr(r, "pop"), 1,
+                       self.pop - 1, D, self.sigma32.data_ptr() + 4 * ri, self.philox_seed, 0, ri, 0, g,
+                       self._ptr(r, "stale"), L._p(self.dist_partial[r]))
+                L.call("coevo_fc_distance_finalize", L._p(self.dist_partial[r]), self.pblocks[r], self.pop - 1,
+                       L._p(self.dist[r]), 1, L._p(self.best_dist[r]))
         L.call("coevo_counter_add", g, 1)
 
     def replay_generation(self, gen):

@@ -94,6 +94,13 @@ _SIGS = {
                                           C.c_uint32, C.c_void_p, C.c_void_p]),
     "coevo_fc_perturb_gen": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                        C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
+    "coevo_fc_perturb_blocks": (C.c_int64, [C.c_int]),
+    "coevo_fc_perturb_dist": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
+    "coevo_fc_distance_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                             C.c_void_p]),
+    "coevo_gather_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "coevo_ga_adapt_sigma": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "coevo_counter_add": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

@@ -167,6 +167,20 @@ int coevo_fc_perturb(const float *parent_slab, const int32_t *parent_idx, float 
 int coevo_fc_perturb_gen(const float *parent_slab, const int32_t *parent_idx, float *child_slab, int child_first,
                          int n_children, int D, const float *sigma_dev, uint64_t seed, uint32_t stream_lo_first,
                          uint32_t stream_hi, int skip_layernorm, const int32_t *gen_dev, void *stream);
+/* ... and, while each child is in registers, its squared L2 distance (Linear weights/biases only) to the net
+ * `dist_ref` (one net, slab layout): per-block partial sums go to dist_partial[n_children][coevo_fc_perturb_blocks(D)]
+ * (fp64); coevo_fc_distance_finalize turns them into the distances diversity_penalty needs next generation, saving a
+ * second pass over the population.  dist_ref and dist_partial are both NULL or both set. */
+int64_t coevo_fc_perturb_blocks(int D);
+int coevo_fc_perturb_dist(const float *parent_slab, const int32_t *parent_idx, float *child_slab, int child_first,
+                          int n_children, int D, const float *sigma_dev, uint64_t seed, uint32_t stream_lo_first,
+                          uint32_t stream_hi, int skip_layernorm, const int32_t *gen_dev, const float *dist_ref,
+                          double *dist_partial, void *stream);
+/* dist[first + c] = sqrt(sum of child c's partials); head != NULL: also dist[first-1] = *head (the unchanged best
+ * individual keeps the distance it had in the previous population, stashed with coevo_gather_f32 before breeding) */
+int coevo_fc_distance_finalize(const double *dist_partial, int n_blocks, int n, float *dist, int first,
+                               const float *head, void *stream);
+int coevo_gather_f32(float *dst, const float *src, const int32_t *idx, int n, void *stream);  /* dst[i]=src[idx[i]] */
 /* Multi-GPU Co-GA: this generation's elites (ids order[0..E-1] on the device) rebuilt from LAST generation's elites
  * and the counter-based noise their children were bred with (id 0 = last best unchanged, id >= 1 = elite_prev[(id-1)%E]
  * + sigma_prev*eps(stream (id-1, stream_hi_prev))): no weight crosses xGMI, every rank gets identical bits.
