@@ -103,6 +103,132 @@ __device__ inline float mpe_obs_element(const double *st, int n, int g, int slot
     return (float)(st[(size_t)(src + c) * n + g] - st[(size_t)(2 * slot + c) * n + g]);
 }
 
+// ---- one game in registers: the world step and the observation, same operation order as everywhere else ---------
+// Named scalars, not arrays: hipcc turns a select over array elements back into a runtime-indexed load from a scratch
+// copy of the array.
+struct MpeGame {
+    double ax, ay, bx, by, cx, cy;        // positions of adversary_0 (a), agent_0 (b), agent_1 (c)
+    double avx, avy, bvx, bvy, cvx, cvy;  // velocities
+    double l0x, l0y, l1x, l1y;            // landmarks
+    double gx, gy;                        // goal landmark
+};
+
+__device__ __forceinline__ void mpe_load_game(const double *st, int n, int g, MpeGame &s)
+{
+    const size_t N = (size_t)n;
+    s.ax = st[0 * N + g]; s.ay = st[1 * N + g]; s.bx = st[2 * N + g]; s.by = st[3 * N + g];
+    s.cx = st[4 * N + g]; s.cy = st[5 * N + g];
+    s.avx = st[6 * N + g]; s.avy = st[7 * N + g]; s.bvx = st[8 * N + g]; s.bvy = st[9 * N + g];
+    s.cvx = st[10 * N + g]; s.cvy = st[11 * N + g];
+    s.l0x = st[12 * N + g]; s.l0y = st[13 * N + g]; s.l1x = st[14 * N + g]; s.l1y = st[15 * N + g];
+    s.gx = st[16 * N + g]; s.gy = st[17 * N + g];
+}
+
+__device__ __forceinline__ void mpe_store_game(double *st, int n, int g, const MpeGame &s)
+{
+    const size_t N = (size_t)n;
+    st[0 * N + g] = s.ax; st[1 * N + g] = s.ay; st[2 * N + g] = s.bx; st[3 * N + g] = s.by;
+    st[4 * N + g] = s.cx; st[5 * N + g] = s.cy;
+    st[6 * N + g] = s.avx; st[7 * N + g] = s.avy; st[8 * N + g] = s.bvx; st[9 * N + g] = s.bvy;
+    st[10 * N + g] = s.cvx; st[11 * N + g] = s.cvy;
+    st[12 * N + g] = s.l0x; st[13 * N + g] = s.l0y; st[14 * N + g] = s.l1x; st[15 * N + g] = s.l1y;
+    st[16 * N + g] = s.gx; st[17 * N + g] = s.gy;
+}
+
+// one agent's integration step for one coordinate (discrete action -> force 5*u, dt 0.1, damping 0.25)
+__device__ __forceinline__ void mpe_move(double &pos, double &vel, double u, int pos_first)
+{
+    const double f = (((u * 5.0) + 0.0) / 1.0) * 0.1;
+    if (pos_first) pos = pos + vel * 0.1;
+    vel = vel * 0.75;
+    vel = vel + f;
+    if (!pos_first) pos = pos + vel * 0.1;
+}
+
+__device__ __forceinline__ double mpe_ux(int act) { return act == 1 ? -1.0 : (act == 2 ? 1.0 : 0.0); }
+__device__ __forceinline__ double mpe_uy(int act) { return act == 3 ? -1.0 : (act == 4 ? 1.0 : 0.0); }
+
+// PettingZoo World.step for three discrete actions (no collisions, no noise) + the two reward values
+__device__ __forceinline__ void mpe_world_step(MpeGame &s, int act_a, int act_b, int act_c, int pos_first,
+                                               double &r_good, double &r_adv)
+{
+    mpe_move(s.ax, s.avx, mpe_ux(act_a), pos_first);
+    mpe_move(s.ay, s.avy, mpe_uy(act_a), pos_first);
+    mpe_move(s.bx, s.bvx, mpe_ux(act_b), pos_first);
+    mpe_move(s.by, s.bvy, mpe_uy(act_b), pos_first);
+    mpe_move(s.cx, s.cvx, mpe_ux(act_c), pos_first);
+    mpe_move(s.cy, s.cvy, mpe_uy(act_c), pos_first);
+    double dx = s.ax - s.gx, dy = s.ay - s.gy;
+    const double da = sqrt(dx * dx + dy * dy);
+    dx = s.bx - s.gx; dy = s.by - s.gy;
+    const double db = sqrt(dx * dx + dy * dy);
+    dx = s.cx - s.gx; dy = s.cy - s.gy;
+    const double dc = sqrt(dx * dx + dy * dy);
+    r_adv = -da;
+    const double m = (dc < db) ? dc : db;
+    r_good = -m + da;
+}
+
+// the whole observation of env slot `slot` (float32 casts of fp64 differences, as SimpleEnv.observe does):
+//   adversary: [lm0-p, lm1-p, agent_0-p, agent_1-p]           good: [goal-p, lm0-p, lm1-p, adversary-p, other good-p]
+// Three branches with fixed fields rather than selects on `slot`: hipcc turns a select chain over the position values
+// into a runtime-indexed load from a scratch copy.  Rows of one task almost always share a slot (wave-uniform branch).
+__device__ __forceinline__ void mpe_obs_good(const MpeGame &s, double mex, double mey, double ox, double oy, float o[10])
+{
+    o[0] = (float)(s.gx - mex);  o[1] = (float)(s.gy - mey);
+    o[2] = (float)(s.l0x - mex); o[3] = (float)(s.l0y - mey);
+    o[4] = (float)(s.l1x - mex); o[5] = (float)(s.l1y - mey);
+    o[6] = (float)(s.ax - mex);  o[7] = (float)(s.ay - mey);
+    o[8] = (float)(ox - mex);    o[9] = (float)(oy - mey);
+}
+
+__device__ __forceinline__ void mpe_obs_from_game(const MpeGame &s, int slot, float o[10])
+{
+    if (slot == COEVO_SLOT_ADVERSARY) {
+        o[0] = (float)(s.l0x - s.ax); o[1] = (float)(s.l0y - s.ay);
+        o[2] = (float)(s.l1x - s.ax); o[3] = (float)(s.l1y - s.ay);
+        o[4] = (float)(s.bx - s.ax);  o[5] = (float)(s.by - s.ay);
+        o[6] = (float)(s.cx - s.ax);  o[7] = (float)(s.cy - s.ay);
+        o[8] = 0.0f;                  o[9] = 0.0f;
+    } else if (slot == COEVO_SLOT_AGENT_0) {
+        mpe_obs_good(s, s.bx, s.by, s.cx, s.cy, o);
+    } else {
+        mpe_obs_good(s, s.cx, s.cy, s.bx, s.by, o);
+    }
+}
+
+// Fused env step (coevo_mpe_rollout): the state a policy launch of cycle `cycle` observes is derived in registers
+// from the previous cycle's state buffer and the previous cycle's actions; only the row in the adversary's seat (one
+// per game) writes the new state and credits the rewards (quirk Q1), into the OTHER buffer.  obs_out[0..D) filled.
+__device__ __forceinline__ void mpe_fused_observe(const double *st_prev, double *st_next, const int32_t *act_prev,
+                                         const int32_t *game_limit, int n, int g, int slot, int cycle, int pos_first,
+                                         float *obs_out)
+{
+    const size_t N = (size_t)n;
+    MpeGame s;
+    mpe_load_game(st_prev, n, g, s);
+    if (cycle > 0) {
+        const int limit = game_limit ? game_limit[g] : 0x7fffffff;
+        const int t0 = 3 * (cycle - 1);
+        const bool stepped = t0 + 2 < limit;  // agent_1 acted in the previous cycle: the world moved
+        double r_good = 0.0, r_adv = 0.0;
+        if (stepped) mpe_world_step(s, act_prev[3 * g], act_prev[3 * g + 1], act_prev[3 * g + 2], pos_first, r_good, r_adv);
+        if (slot == COEVO_SLOT_ADVERSARY) {  // the game's owner row: carry the bookkeeping into the new buffer
+            double rg_prev = st_prev[18 * N + g], a_adv = st_prev[19 * N + g], a_a0 = st_prev[20 * N + g],
+                   a_a1 = st_prev[21 * N + g];
+            if (t0 < limit) a_adv = a_adv + rg_prev;
+            if (t0 + 1 < limit) a_a0 = a_a0 + rg_prev;
+            if (stepped) { a_a1 = a_a1 + r_adv; rg_prev = r_good; }
+            mpe_store_game(st_next, n, g, s);
+            st_next[18 * N + g] = rg_prev;
+            st_next[19 * N + g] = a_adv;
+            st_next[20 * N + g] = a_a0;
+            st_next[21 * N + g] = a_a1;
+        }
+    }
+    mpe_obs_from_game(s, slot, obs_out);
+}
+
 // fixed-order block reduction of one double per thread (256 threads): xor tree inside each wave, waves left to right
 __device__ inline double block_sum_f64(double v, double *scratch)
 {

@@ -36,8 +36,9 @@ struct FcSmem {
 struct FcArgs {
     const float *slab;
     const coevo_fc_task *tasks;
-    const float *obs;          // FROM_STATE == false
-    const double *state;       // FROM_STATE == true: [COEVO_MPE_STATE_DOUBLES][n_games]
+    const float *obs;          // MODE 0: observations given
+    const double *state;       // MODE 1: read from the game state [COEVO_MPE_STATE_DOUBLES][n_games];
+                               // MODE 2 (fused env step): the PREVIOUS cycle's state buffer
     const int32_t *row_game;
     const int32_t *row_slot;
     int n_games;
@@ -45,7 +46,14 @@ struct FcArgs {
     float *logits;  // may be null
     int32_t *status;
     unsigned long long *stamps;  // may be null: [COEVO_STAMP_SLOTS][2] = {min workgroup start, max workgroup end}
+    // MODE 2 only
+    double *state_next;          // the buffer this cycle's state is written to (by each game's owner row)
+    const int32_t *act_prev;     // [n_games][3] actions of the previous cycle, by env slot
+    int32_t *act_cur;            // [n_games][3] this cycle's actions
+    const int32_t *game_limit;
+    int cycle, pos_first;
 };
+constexpr int MODE_OBS = 0, MODE_STATE = 1, MODE_FUSED = 2;
 
 // 100 MHz wall clock; the first/last workgroup of a launch bracket its duration (used where HIP events cannot be:
 // inside hipGraph replays)
@@ -63,11 +71,28 @@ __device__ inline void stamp_end(unsigned long long *stamps)
                   (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
-template <int R, bool FROM_STATE>
+#ifdef COEVO_PHASE_STAMPS
+// diagnostic build only (tools/phase_stamps.py): per-workgroup shader-clock stamps at the phase boundaries of the
+// streaming kernel, written to a buffer nothing else reads
+__device__ unsigned long long g_phase_stamps[4096 * 8];
+#define COEVO_STAMP(i)                                                                          \
+    do {                                                                                        \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {                                            \
+            unsigned long long _t;                                                              \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");          \
+            g_phase_stamps[blockIdx.x * 8 + (i)] = _t;                                          \
+        }                                                                                       \
+    } while (0)
+#else
+#define COEVO_STAMP(i) do { } while (0)
+#endif
+
+template <int R, int MODE>
 __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
 {
     __shared__ FcSmem<R> sm;
     stamp_begin(a.stamps);
+    COEVO_STAMP(0);
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
     const coevo_fc_task task = a.tasks[blockIdx.x];
     const int D = task.D, nrows = task.n_rows, row0 = task.row_begin;
@@ -91,25 +116,44 @@ __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
     const float p_b3 = (t < R * NACT) ? net[fc_off_b3(D) + t % NACT] : 0.0f;
 
     // ---- stage observations (zero padded) and the output layer -------------------------------------------
-    for (int i = t; i < R * COEVO_OBS_STRIDE; i += 256) {
-        const int r = i / COEVO_OBS_STRIDE, k = i % COEVO_OBS_STRIDE;
-        float v = 0.0f;
-        if (r < nrows && k < D) {
-            if constexpr (FROM_STATE) {
-                const int row = row0 + r;
-                v = mpe_obs_element(a.state, a.n_games, a.row_game[row], a.row_slot[row], k);
-            } else {
-                v = a.obs[(size_t)(row0 + r) * COEVO_OBS_STRIDE + k];
+    if constexpr (MODE == MODE_FUSED) {
+        if (t < R) {  // one lane per row: advance its game in registers, observe, (owner row) publish the new state
+            float o[COEVO_OBS_STRIDE];
+#pragma unroll
+            for (int k = 0; k < COEVO_OBS_STRIDE; ++k) o[k] = 0.0f;
+            if (t < nrows) {
+                const int row = row0 + t;
+                mpe_fused_observe(a.state, a.state_next, a.act_prev, a.game_limit, a.n_games, a.row_game[row],
+                                  a.row_slot[row], a.cycle, a.pos_first, o);
+#pragma unroll
+                for (int k = 0; k < 10; ++k)
+                    if (!__builtin_isfinite(o[k])) st |= COEVO_ST_BAD_INPUT;
             }
-            if (!__builtin_isfinite(v)) st |= COEVO_ST_BAD_INPUT;
+#pragma unroll
+            for (int k = 0; k < COEVO_OBS_STRIDE; ++k) sm.xs0[t][k] = o[k];
         }
-        sm.xs0[r][k] = v;
+    } else {
+        for (int i = t; i < R * COEVO_OBS_STRIDE; i += 256) {
+            const int r = i / COEVO_OBS_STRIDE, k = i % COEVO_OBS_STRIDE;
+            float v = 0.0f;
+            if (r < nrows && k < D) {
+                if constexpr (MODE == MODE_STATE) {
+                    const int row = row0 + r;
+                    v = mpe_obs_element(a.state, a.n_games, a.row_game[row], a.row_slot[row], k);
+                } else {
+                    v = a.obs[(size_t)(row0 + r) * COEVO_OBS_STRIDE + k];
+                }
+                if (!__builtin_isfinite(v)) st |= COEVO_ST_BAD_INPUT;
+            }
+            sm.xs0[r][k] = v;
+        }
     }
     {
         const float *W3 = net + fc_off_w3(D);
         for (int i = t; i < NACT * H2; i += 256) sm.w3s[i >> 8][i & 255] = W3[i];
     }
     __syncthreads();
+    COEVO_STAMP(1);
 
     // ---- fc1: outputs j0 = t, j1 = t + 256; sequential-k chains from the bias -----------------------------
     float a0[R], a1[R];
@@ -168,6 +212,7 @@ __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
         }
     }
     __syncthreads();
+    COEVO_STAMP(2);
 
     // ---- fc2: lane owns output 64w + l; 128 k-quads streamed as 16-byte pieces, 8 loads in flight ----------
     float acc[R];
@@ -197,6 +242,7 @@ __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
             }
         }
     }
+    COEVO_STAMP(3);
     // ---- LayerNorm(256) + ReLU: block b = wave b ------------------------------------------------------------
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -228,6 +274,7 @@ __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
         }
     }
     __syncthreads();
+    COEVO_STAMP(4);
 
     // ---- output layer: one lane per (row, action), 256-long sequential chain out of LDS --------------------
     if (t < R * NACT) {
@@ -246,6 +293,7 @@ __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
         sm.logit[r][o] = y;
     }
     __syncthreads();
+    COEVO_STAMP(5);
 
     // ---- first-max action (strict '>' scan from -inf), status --------------------------------------------
     if (t < nrows) {
@@ -258,13 +306,19 @@ __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
             if (v > cur) { cur = v; best = o; }
         }
         if (best < 0) { st |= COEVO_ST_NO_ACTION; best = 0; }
-        a.actions[row0 + t] = best;
+        if constexpr (MODE == MODE_FUSED) {
+            const int row = row0 + t;
+            a.act_cur[3 * a.row_game[row] + a.row_slot[row]] = best;  // by (game, slot): next cycle's step reads it
+        } else {
+            a.actions[row0 + t] = best;
+        }
         if (a.logits) {
 #pragma unroll
             for (int o = 0; o < NACT; ++o) a.logits[(size_t)(row0 + t) * COEVO_LOGIT_STRIDE + o] = sm.logit[t][o];
         }
     }
     if (st) atomicOr(a.status, st);
+    COEVO_STAMP(6);
     stamp_end(a.stamps);
 }
 
@@ -295,7 +349,7 @@ struct FcMfmaSmem {
 
 __device__ inline int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-template <bool FROM_STATE>
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void fc_policy_mfma_kernel(FcArgs a)
 {
     __shared__ FcMfmaSmem sm;
@@ -331,19 +385,37 @@ __global__ __launch_bounds__(256, 2) void fc_policy_mfma_kernel(FcArgs a)
     }
     const float p_b3 = (t < 32 * NACT) ? net[fc_off_b3(D) + t % NACT] : 0.0f;
 
-    for (int i = t; i < 32 * COEVO_OBS_STRIDE; i += 256) {
-        const int r = i / COEVO_OBS_STRIDE, k = i % COEVO_OBS_STRIDE;
-        float v = 0.0f;
-        if (r < nrows && k < D) {
-            if constexpr (FROM_STATE) {
-                const int row = row0 + r;
-                v = mpe_obs_element(a.state, a.n_games, a.row_game[row], a.row_slot[row], k);
-            } else {
-                v = a.obs[(size_t)(row0 + r) * COEVO_OBS_STRIDE + k];
+    if constexpr (MODE == MODE_FUSED) {
+        if (t < 32) {
+            float o[COEVO_OBS_STRIDE];
+#pragma unroll
+            for (int k = 0; k < COEVO_OBS_STRIDE; ++k) o[k] = 0.0f;
+            if (t < nrows) {
+                const int row = row0 + t;
+                mpe_fused_observe(a.state, a.state_next, a.act_prev, a.game_limit, a.n_games, a.row_game[row],
+                                  a.row_slot[row], a.cycle, a.pos_first, o);
+#pragma unroll
+                for (int k = 0; k < 10; ++k)
+                    if (!__builtin_isfinite(o[k])) st |= COEVO_ST_BAD_INPUT;
             }
-            if (!__builtin_isfinite(v)) st |= COEVO_ST_BAD_INPUT;
+#pragma unroll
+            for (int k = 0; k < COEVO_OBS_STRIDE; ++k) sm.xst[k][t] = o[k];
         }
-        sm.xst[k][r] = v;
+    } else {
+        for (int i = t; i < 32 * COEVO_OBS_STRIDE; i += 256) {
+            const int r = i / COEVO_OBS_STRIDE, k = i % COEVO_OBS_STRIDE;
+            float v = 0.0f;
+            if (r < nrows && k < D) {
+                if constexpr (MODE == MODE_STATE) {
+                    const int row = row0 + r;
+                    v = mpe_obs_element(a.state, a.n_games, a.row_game[row], a.row_slot[row], k);
+                } else {
+                    v = a.obs[(size_t)(row0 + r) * COEVO_OBS_STRIDE + k];
+                }
+                if (!__builtin_isfinite(v)) st |= COEVO_ST_BAD_INPUT;
+            }
+            sm.xst[k][r] = v;
+        }
     }
     {
         const float *W3 = net + fc_off_w3(D);
@@ -532,7 +604,12 @@ __global__ __launch_bounds__(256, 2) void fc_policy_mfma_kernel(FcArgs a)
             if (v > cur) { cur = v; best = o; }
         }
         if (best < 0) { st |= COEVO_ST_NO_ACTION; best = 0; }
-        a.actions[row0 + t] = best;
+        if constexpr (MODE == MODE_FUSED) {
+            const int row = row0 + t;
+            a.act_cur[3 * a.row_game[row] + a.row_slot[row]] = best;  // by (game, slot): next cycle's step reads it
+        } else {
+            a.actions[row0 + t] = best;
+        }
         if (a.logits) {
 #pragma unroll
             for (int o = 0; o < NACT; ++o) a.logits[(size_t)(row0 + t) * COEVO_LOGIT_STRIDE + o] = sm.logit[t][o];
@@ -541,25 +618,33 @@ __global__ __launch_bounds__(256, 2) void fc_policy_mfma_kernel(FcArgs a)
     if (st) atomicOr(a.status, st);
 }
 
-template <bool FROM_STATE>
+template <int MODE>
 static int launch_fc(const FcArgs &a, int n_tasks, int max_rows, hipStream_t s)
 {
     if (n_tasks <= 0) return COEVO_OK;
     if (max_rows <= 1)
-        hipLaunchKernelGGL((fc_policy_kernel<1, FROM_STATE>), dim3(n_tasks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((fc_policy_kernel<1, MODE>), dim3(n_tasks), dim3(256), 0, s, a);
     else if (max_rows <= 2)
-        hipLaunchKernelGGL((fc_policy_kernel<2, FROM_STATE>), dim3(n_tasks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((fc_policy_kernel<2, MODE>), dim3(n_tasks), dim3(256), 0, s, a);
     else if (max_rows <= 5)
-        hipLaunchKernelGGL((fc_policy_kernel<5, FROM_STATE>), dim3(n_tasks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((fc_policy_kernel<5, MODE>), dim3(n_tasks), dim3(256), 0, s, a);
     else if (max_rows <= 8)
-        hipLaunchKernelGGL((fc_policy_kernel<8, FROM_STATE>), dim3(n_tasks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((fc_policy_kernel<8, MODE>), dim3(n_tasks), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((fc_policy_mfma_kernel<FROM_STATE>), dim3(n_tasks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((fc_policy_mfma_kernel<MODE>), dim3(n_tasks), dim3(256), 0, s, a);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }
 
 }  // namespace coevo
+
+#ifdef COEVO_PHASE_STAMPS
+extern "C" int coevo_debug_read_phase_stamps(unsigned long long *host_out, int n_words)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(coevo::g_phase_stamps), sizeof(unsigned long long) * n_words) ==
+                   hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" int coevo_fc_forward_argmax(const float *slab, const coevo_fc_task *tasks, int n_tasks,
                                        int max_rows_per_task, const float *obs, int32_t *actions, float *logits,
@@ -567,8 +652,9 @@ extern "C" int coevo_fc_forward_argmax(const float *slab, const coevo_fc_task *t
 {
     if (!slab || !tasks || !obs || !actions || !status || n_tasks < 0) return COEVO_ERR_ARG;
     if (max_rows_per_task < 1 || max_rows_per_task > COEVO_FC_MAX_ROWS) return COEVO_ERR_ARG;
-    coevo::FcArgs a{slab, tasks, obs, nullptr, nullptr, nullptr, 0, actions, logits, status, nullptr};
-    return coevo::launch_fc<false>(a, n_tasks, max_rows_per_task, (hipStream_t)stream);
+    coevo::FcArgs a{slab, tasks, obs, nullptr, nullptr, nullptr, 0, actions, logits, status, nullptr,
+                    nullptr, nullptr, nullptr, nullptr, 0, 0};
+    return coevo::launch_fc<coevo::MODE_OBS>(a, n_tasks, max_rows_per_task, (hipStream_t)stream);
 }
 
 extern "C" int coevo_mpe_policy_cycle_stamped(const float *slab, const coevo_fc_task *tasks, int n_tasks,
@@ -594,6 +680,23 @@ extern "C" int coevo_mpe_policy_cycle_stamped(const float *slab, const coevo_fc_
     if (n_tasks < 0 || n_games <= 0) return COEVO_ERR_ARG;
     if (max_rows_per_task < 1 || max_rows_per_task > COEVO_FC_MAX_ROWS) return COEVO_ERR_ARG;
     coevo::FcArgs a{slab, tasks, nullptr, state, row_game, row_slot, n_games, actions, nullptr, status,
-                    reinterpret_cast<unsigned long long *>(stamps)};
-    return coevo::launch_fc<true>(a, n_tasks, max_rows_per_task, (hipStream_t)stream);
+                    reinterpret_cast<unsigned long long *>(stamps), nullptr, nullptr, nullptr, nullptr, 0, 0};
+    return coevo::launch_fc<coevo::MODE_STATE>(a, n_tasks, max_rows_per_task, (hipStream_t)stream);
+}
+
+extern "C" int coevo_mpe_policy_cycle_fused(const float *slab, const coevo_fc_task *tasks, int n_tasks,
+                                            int max_rows_per_task, const double *state_prev, double *state_next,
+                                            int n_games, const int32_t *row_game, const int32_t *row_slot,
+                                            const int32_t *act_prev, int32_t *act_cur, const int32_t *game_limit,
+                                            int cycle, int pos_first, int32_t *status, uint64_t *stamps, void *stream)
+{
+    if (!slab || !tasks || !state_prev || !state_next || !row_game || !row_slot || !act_prev || !act_cur || !status)
+        return COEVO_ERR_ARG;
+    if (n_tasks < 0 || n_games <= 0 || cycle < 0 || state_prev == state_next || act_prev == act_cur)
+        return COEVO_ERR_ARG;
+    if (max_rows_per_task < 1 || max_rows_per_task > COEVO_FC_MAX_ROWS) return COEVO_ERR_ARG;
+    coevo::FcArgs a{slab, tasks, nullptr, state_prev, row_game, row_slot, n_games, nullptr, nullptr, status,
+                    reinterpret_cast<unsigned long long *>(stamps), state_next, act_prev, act_cur, game_limit, cycle,
+                    pos_first};
+    return coevo::launch_fc<coevo::MODE_FUSED>(a, n_tasks, max_rows_per_task, (hipStream_t)stream);
 }

@@ -156,6 +156,34 @@ __global__ void mpe_step_kernel(double *st, int n, const int32_t *game_rows, con
     st[18 * N + g] = r_good;
 }
 
+// The last cycle's step in the fused scheme: its actions are applied only to close the books (credits of cycle
+// `cycle`), the play_game triples go straight to rewards[n][3]; no state is written.
+__global__ void mpe_final_step_kernel(const double *st, int n, const int32_t *act, int cycle,
+                                      const int32_t *game_limit, int pos_first, double *rewards)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const size_t N = (size_t)n;
+    double a_adv = st[19 * N + g], a_a0 = st[20 * N + g], a_a1 = st[21 * N + g];
+    if (cycle >= 0) {
+        const int limit = game_limit ? game_limit[g] : 0x7fffffff;
+        const int t0 = 3 * cycle;
+        const double rg_prev = st[18 * N + g];
+        if (t0 < limit) a_adv = a_adv + rg_prev;
+        if (t0 + 1 < limit) a_a0 = a_a0 + rg_prev;
+        if (t0 + 2 < limit) {
+            MpeGame s;
+            mpe_load_game(st, n, g, s);
+            double r_good, r_adv;
+            mpe_world_step(s, act[3 * g], act[3 * g + 1], act[3 * g + 2], pos_first, r_good, r_adv);
+            a_a1 = a_a1 + r_adv;
+        }
+    }
+    rewards[3 * (size_t)g + 0] = a_a0;
+    rewards[3 * (size_t)g + 1] = a_a1;
+    rewards[3 * (size_t)g + 2] = a_adv;
+}
+
 __global__ void mpe_rewards_kernel(const double *st, int n, double *rewards)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -209,6 +237,16 @@ extern "C" int coevo_mpe_step(double *state, int n_games, const int32_t *game_ro
     if (!state || !game_rows || !actions || n_games <= 0 || cycle < 0) return COEVO_ERR_ARG;
     hipLaunchKernelGGL(coevo::mpe_step_kernel, dim3((n_games + 127) / 128), dim3(128), 0, (hipStream_t)stream,
                        state, n_games, game_rows, actions, cycle, game_limit, pos_first);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_mpe_final_step(const double *state, int n_games, const int32_t *actions_by_game, int cycle,
+                                    const int32_t *game_limit, int pos_first, double *rewards, void *stream)
+{
+    if (!state || !rewards || n_games <= 0 || (cycle >= 0 && !actions_by_game)) return COEVO_ERR_ARG;
+    hipLaunchKernelGGL(coevo::mpe_final_step_kernel, dim3((n_games + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                       state, n_games, actions_by_game, cycle, game_limit, pos_first, rewards);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

@@ -76,8 +76,9 @@ extern "C" int coevo_rollout_ctx_light_times(void *ctx, float *ms_out, int max_o
 
 extern "C" int coevo_mpe_rollout(const coevo_rollout_desc *d, void *ctx, int time_light, void *stream)
 {
-    if (!d || !d->slab || !d->state || !d->row_game || !d->row_slot || !d->game_rows || !d->actions || !d->status)
-        return COEVO_ERR_ARG;
+    if (!d || !d->slab || !d->state || !d->row_game || !d->row_slot || !d->status) return COEVO_ERR_ARG;
+    if ((d->state_alt == nullptr) != (d->actions_by_game == nullptr)) return COEVO_ERR_ARG;
+    if (!d->state_alt && (!d->game_rows || !d->actions)) return COEVO_ERR_ARG;
     if (d->n_games <= 0 || d->n_cycles < 0 || d->n_heavy < 0 || d->n_light < 0) return COEVO_ERR_ARG;
     if ((d->n_heavy > 0 && !d->heavy) || (d->n_light > 0 && !d->light)) return COEVO_ERR_ARG;
     auto *c = static_cast<coevo_rollout_ctx *>(ctx);
@@ -91,24 +92,39 @@ extern "C" int coevo_mpe_rollout(const coevo_rollout_desc *d, void *ctx, int tim
                            d->n_cycles * COEVO_STAMP_SLOTS);
         COEVO_HIP_CHECK(hipGetLastError());
     }
+    const bool fused = d->state_alt != nullptr && d->actions_by_game != nullptr;
+    const size_t act_stride = 3 * (size_t)d->n_games;
     for (int cyc = 0; cyc < d->n_cycles; ++cyc) {
         int rc;
+        // fused env step: cycle c reads the state of cycle c-1 (buffer (c-1)&1; buffer 0 holds the reset state) and
+        // the actions of cycle c-1, derives its own state in registers, the owner rows write it to buffer c&1
+        const double *st_prev = (cyc == 0) ? d->state : (((cyc - 1) & 1) ? d->state_alt : d->state);
+        double *st_next = (cyc & 1) ? d->state_alt : d->state;
+        if (cyc == 0) st_next = d->state_alt;  // never written in cycle 0; only has to differ from st_prev
+        const int32_t *act_prev = fused ? d->actions_by_game + (size_t)((cyc + 1) & 1) * act_stride : nullptr;
+        int32_t *act_cur = fused ? d->actions_by_game + (size_t)(cyc & 1) * act_stride : nullptr;
+        auto policy = [&](const coevo_fc_task *tasks, int n_tasks, int max_rows, uint64_t *stamps, hipStream_t s) {
+            if (fused)
+                return coevo_mpe_policy_cycle_fused(d->slab, tasks, n_tasks, max_rows, st_prev, st_next, d->n_games,
+                                                    d->row_game, d->row_slot, act_prev, act_cur, d->game_limit, cyc,
+                                                    d->pos_first, d->status, stamps, s);
+            return coevo_mpe_policy_cycle_stamped(d->slab, tasks, n_tasks, max_rows, d->state, d->n_games, d->row_game,
+                                                  d->row_slot, d->actions, d->status, stamps, s);
+        };
         if (two) {
             COEVO_HIP_CHECK(hipEventRecord(c->fork, main_s));
             COEVO_HIP_CHECK(hipStreamWaitEvent(c->side, c->fork, 0));
         }
         if (d->n_heavy > 0) {
-            rc = coevo_mpe_policy_cycle(d->slab, d->heavy, d->n_heavy, d->heavy_max_rows, d->state, d->n_games,
-                                        d->row_game, d->row_slot, d->actions, d->status, two ? c->side : main_s);
+            rc = policy(d->heavy, d->n_heavy, d->heavy_max_rows, nullptr, two ? c->side : main_s);
             if (rc) return rc;
             if (two) COEVO_HIP_CHECK(hipEventRecord(c->join, c->side));
         }
         if (d->n_light > 0) {
             const bool timed = time_light && c && (size_t)(2 * c->pairs_used + 1) < c->timing.size();
             if (timed) COEVO_HIP_CHECK(record_timing(c->timing[2 * c->pairs_used]));
-            rc = coevo_mpe_policy_cycle_stamped(d->slab, d->light, d->n_light, d->light_max_rows, d->state,
-                                                d->n_games, d->row_game, d->row_slot, d->actions, d->status,
-                                                d->light_stamps ? d->light_stamps + 2 * COEVO_STAMP_SLOTS * cyc : nullptr, main_s);
+            rc = policy(d->light, d->n_light, d->light_max_rows,
+                        d->light_stamps ? d->light_stamps + 2 * COEVO_STAMP_SLOTS * cyc : nullptr, main_s);
             if (rc) return rc;
             if (timed) {
                 COEVO_HIP_CHECK(record_timing(c->timing[2 * c->pairs_used + 1]));
@@ -116,8 +132,17 @@ extern "C" int coevo_mpe_rollout(const coevo_rollout_desc *d, void *ctx, int tim
             }
         }
         if (two) COEVO_HIP_CHECK(hipStreamWaitEvent(main_s, c->join, 0));
-        rc = coevo_mpe_step(d->state, d->n_games, d->game_rows, d->actions, cyc, d->game_limit, d->pos_first, main_s);
-        if (rc) return rc;
+        if (!fused) {
+            rc = coevo_mpe_step(d->state, d->n_games, d->game_rows, d->actions, cyc, d->game_limit, d->pos_first, main_s);
+            if (rc) return rc;
+        }
+    }
+    if (fused) {
+        if (!d->rewards) return COEVO_ERR_ARG;
+        const int last = d->n_cycles - 1;  // -1: no cycle ran, the books are the reset state's zeros
+        const double *st_last = (last <= 0) ? d->state : ((last & 1) ? d->state_alt : d->state);
+        return coevo_mpe_final_step(st_last, d->n_games, d->actions_by_game + (size_t)((last < 0 ? 0 : last) & 1) * act_stride,
+                                    last, d->game_limit, d->pos_first, d->rewards, main_s);
     }
     if (d->rewards) return coevo_mpe_rewards(d->state, d->n_games, d->rewards, main_s);
     return COEVO_OK;

@@ -49,7 +49,7 @@ class RolloutDesc(C.Structure):
                 ("row_game", C.c_void_p), ("row_slot", C.c_void_p), ("game_rows", C.c_void_p),
                 ("actions", C.c_void_p), ("status", C.c_void_p), ("game_limit", C.c_void_p),
                 ("rewards", C.c_void_p), ("pos_first", C.c_int32), ("reserved", C.c_int32),
-                ("light_stamps", C.c_void_p)]
+                ("state_alt", C.c_void_p), ("actions_by_game", C.c_void_p), ("light_stamps", C.c_void_p)]
 
 
 class CoevoError(RuntimeError):
@@ -88,6 +88,11 @@ _SIGS = {
     "coevo_dqn_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "coevo_dqn_forward_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "coevo_mpe_policy_cycle_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "coevo_mpe_final_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.c_void_p]),
     "coevo_fc_perturb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]),
     "coevo_fc_rebuild_elites": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64,

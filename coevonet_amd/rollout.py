@@ -111,12 +111,15 @@ class DeviceRollout:
     """Env copies resident on the GPU.  One C-ABI call (coevo_mpe_rollout) enqueues every cycle: the shared-opponent
     (MFMA) launch on a side HIP stream concurrently with the per-individual (streaming) launch, then the env step."""
 
-    def __init__(self, plan: RolloutPlan, slab: torch.Tensor, env_seed=sa.ENV_SEED, timing_pairs=0):
+    def __init__(self, plan: RolloutPlan, slab: torch.Tensor, env_seed=sa.ENV_SEED, timing_pairs=0, fused_step=True):
         self.plan = plan
         self.slab = slab
         dev = plan.device
         n = plan.n_games
-        self.state = torch.zeros(L.MPE_STATE_DOUBLES, n, dtype=torch.float64, device=dev)
+        # two state buffers + actions by (game, slot), double buffered: the env step is fused into the policy launches
+        self.state2 = torch.zeros(2, L.MPE_STATE_DOUBLES, n, dtype=torch.float64, device=dev)
+        self.state = self.state2[0]
+        self.actions_by_game = torch.zeros(2, n, 3, dtype=torch.int32, device=dev)
         self.actions = torch.zeros(plan.n_rows, dtype=torch.int32, device=dev)
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self.limits = torch.zeros(n, dtype=torch.int32, device=dev)
@@ -138,7 +141,8 @@ class DeviceRollout:
             state=L._p(self.state), n_games=n, n_cycles=0, row_game=L._p(p.row_game), row_slot=L._p(p.row_slot),
             game_rows=L._p(p.game_rows), actions=L._p(self.actions), status=L._p(self.status),
             game_limit=L._p(self.limits), rewards=L._p(self.rewards), pos_first=self.pos_first, reserved=0,
-            light_stamps=None)
+            state_alt=self.state2[1].data_ptr() if fused_step else None,
+            actions_by_game=L._p(self.actions_by_game) if fused_step else None, light_stamps=None)
         self.stamps = torch.zeros(256, L.STAMP_SLOTS, 2, dtype=torch.int64, device=dev)  # per cycle, per slot
 
     def __del__(self):

@@ -134,6 +134,12 @@ typedef struct {
     const int32_t *game_limit;   /* per game agent-step limit, or NULL */
     double *rewards;             /* [n_games][3] or NULL */
     int32_t pos_first; int32_t reserved;
+    /* fused env step (both set, or both NULL for the separate coevo_mpe_step launch per cycle): a second state buffer
+     * and the actions by (game, slot), double buffered [2][n_games][3].  The policy launches of cycle c then derive
+     * the state of cycle c in registers from cycle c-1's buffer + actions (bit-identical arithmetic), each game's
+     * adversary-seat row publishes it to the other buffer, and one coevo_mpe_final_step closes the books: one launch
+     * less and one dependency less per cycle.  `rewards` is required; `actions` / `game_rows` are not used. */
+    double *state_alt; int32_t *actions_by_game;
     uint64_t *light_stamps;      /* [n_cycles][COEVO_STAMP_SLOTS][2] or NULL: per light launch and slot {earliest
                                     workgroup start, latest workgroup end} in 100 MHz s_memrealtime ticks (min / max
                                     over the slots = the launch) - kernel timing that survives graph replay */
@@ -151,6 +157,15 @@ int coevo_mpe_policy_cycle_stamped(const float *slab, const coevo_fc_task *tasks
                                    const double *state, int n_games, const int32_t *row_game,
                                    const int32_t *row_slot, int32_t *actions, int32_t *status, uint64_t *stamps,
                                    void *stream);
+
+/* the policy launch of the fused scheme (see coevo_rollout_desc) and the closing step */
+int coevo_mpe_policy_cycle_fused(const float *slab, const coevo_fc_task *tasks, int n_tasks, int max_rows_per_task,
+                                 const double *state_prev, double *state_next, int n_games, const int32_t *row_game,
+                                 const int32_t *row_slot, const int32_t *act_prev, int32_t *act_cur,
+                                 const int32_t *game_limit, int cycle, int pos_first, int32_t *status, uint64_t *stamps,
+                                 void *stream);
+int coevo_mpe_final_step(const double *state, int n_games, const int32_t *actions_by_game, int cycle,
+                         const int32_t *game_limit, int pos_first, double *rewards, void *stream);
 
 /* ---------------------------------------------------------------- K3/K4/K8: offspring on device ------------- */
 /* child = parent + sigma * eps(seed, stream, p), p = canonical flat index; Philox4x32-10 + Box-Muller with
