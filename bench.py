@@ -150,13 +150,21 @@ def main():
             rows = int(sum(int(t["n_rows"]) for t in eng.plan.light_np))
             alg_bytes = sum(nets.values()) + rows * (4 * 10 + 4)
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+            traffic, traffic_note = None, None
+            pmc = os.path.join(REPO, "profiles", "r01_pmc_hbm_traffic.json")
+            if a.pop_per_gpu == 200 and a.hof == 5 and os.path.exists(pmc):
+                # HBM bytes per launch of this kernel from the PMC counters (FETCH_SIZE/WRITE_SIZE, separate rocprofv3
+                # passes of this same command, gfx950 correction applied) - collected offline, see the file
+                with open(pmc) as f:
+                    traffic = json.load(f)["dominant_kernel_hbm_bytes_per_launch"]
+                traffic_note = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc passes of this command)"
             out["roofline"] = {"bound": "hbm", "kernel": "fc_policy_kernel<5,true> (per-individual weight sets)",
                                "timing": ("HIP events around each launch on its stream" if a.no_graph else
                                           "in-kernel 100 MHz clock stamps, first workgroup start to last workgroup "
                                           "end (HIP events cannot be read back from replayed hipGraphs; "
                                           "--no-graph uses events)"),
                                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
                                "launches_timed": len(d)}
         if not a.no_cpu_baseline and ctx.world == 1:
