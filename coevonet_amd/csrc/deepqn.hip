@@ -144,20 +144,27 @@ __device__ inline void conv_bn_relu_mfma(const void *in_lds, const float *lut, i
     }
     // all units of one wave share the column tile when NT == 1 (conv1); otherwise a wave has a single unit
     const int nt0 = (w % NT);
-    for (int t0 = 0; t0 < taps; t0 += 2) {
-        const int t = t0 + lh;
-        const int ci = t / (KS * KS), rem = t % (KS * KS), ky = rem / KS, kx = rem % KS;
-        const int toff = U8IN ? (ky * HIN + kx) * cin + ci : (ci * HIN + ky) * HIN + kx;
-        const float bv = wt[(size_t)t * COUT + 32 * nt0 + lc];
+    // taps in chunks of 8 k-pairs (all tap counts are multiples of 16): the chunk's 8 weight operands are requested
+    // first (8 independent L2 loads in flight), then 8 x (im2col gather out of LDS, MFMAs)
+    for (int t0 = 0; t0 < taps; t0 += 16) {
+        float bv[8];
 #pragma unroll
-        for (int u = 0; u < UNITS; ++u) {
-            if (!live[u]) continue;  // wave-uniform
+        for (int j = 0; j < 8; ++j) bv[j] = wt[(size_t)(t0 + 2 * j + lh) * COUT + 32 * nt0 + lc];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                float av;
-                if constexpr (U8IN) av = lut[static_cast<const unsigned char *>(in_lds)[base[u][mt] + toff]];
-                else av = static_cast<const float *>(in_lds)[base[u][mt] + toff];
-                acc[u][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[u][mt], 0, 0, 0);
+        for (int j = 0; j < 8; ++j) {
+            const int t = t0 + 2 * j + lh;
+            const int ci = t / (KS * KS), rem = t % (KS * KS), ky = rem / KS, kx = rem % KS;
+            const int toff = U8IN ? (ky * HIN + kx) * cin + ci : (ci * HIN + ky) * HIN + kx;
+#pragma unroll
+            for (int u = 0; u < UNITS; ++u) {
+                if (!live[u]) continue;  // wave-uniform
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    float av;
+                    if constexpr (U8IN) av = lut[static_cast<const unsigned char *>(in_lds)[base[u][mt] + toff]];
+                    else av = static_cast<const float *>(in_lds)[base[u][mt] + toff];
+                    acc[u][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[u][mt], 0, 0, 0);
+                }
             }
         }
     }
@@ -248,14 +255,19 @@ __global__ __launch_bounds__(256) void dqn_conv_kernel(const float *slab, const 
                                                      net + L.b3 + 128, act + (size_t)row * DQ_FC1_IN, sm.red, w, l);
 }
 
-// fc1 + ReLU: grid (task, half); wave w of half h owns outputs [64*(4h+w), +64); <= 16 rows per task.
+// fc1 + ReLU: grid (task, 8), ONE wavefront per workgroup: it owns outputs [64*ob, +64) and streams their 802 KB
+// ([784][64][4] tile) exactly once for the task's <= 16 rows, 28 KiB in flight (only 8 wavefronts exist per net, so the
+// memory-level parallelism has to come from depth).  The activations of a chunk (rows x 28 k-quads) are staged in LDS
+// with coalesced loads and read back as broadcasts (scalar loads of them serialise: 12 500 dependent s_loads per wave).
 constexpr int DQ_RMAX = 16;
-__global__ __launch_bounds__(256) void dqn_fc1_kernel(const float *slab, const coevo_dqn_task *tasks, int C,
-                                                       int n_actions, const float *act, float *hid)
+__global__ __launch_bounds__(64) void dqn_fc1_kernel(const float *slab, const coevo_dqn_task *tasks, int C,
+                                                      int n_actions, const float *act, float *hid)
 {
+    constexpr int U = 28;  // k-quads per chunk; 784 = 28 * 28
+    __shared__ __attribute__((aligned(16))) float xs[DQ_RMAX][U * 4];
     const coevo_dqn_task task = tasks[blockIdx.x];
-    const int t = threadIdx.x, w = t >> 6, l = t & 63;
-    const int ob = 4 * blockIdx.y + w;
+    const int l = threadIdx.x;
+    const int ob = blockIdx.y;
     const float *net = slab + task.net_off;
     const DqnLayout L = dqn_layout(C, n_actions);
     const int nrows = task.n_rows;
@@ -265,17 +277,23 @@ __global__ __launch_bounds__(256) void dqn_fc1_kernel(const float *slab, const c
     for (int r = 0; r < DQ_RMAX; ++r) acc[r] = bb;
     const float4 *wp = reinterpret_cast<const float4 *>(net + L.wf) + (size_t)ob * 784 * 64 + l;
     const float *arow = act + (size_t)task.row_begin * DQ_FC1_IN;
-    constexpr int U = 8;
     for (int kq = 0; kq < 784; kq += U) {
         float4 wv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) wv[u] = wp[(size_t)(kq + u) * 64];
+        __syncthreads();  // the previous chunk's activations have been consumed
+        for (int i = l; i < nrows * U; i += 64) {  // rows x 28 float4 pieces, coalesced per row
+            const int r = i / U, q = i % U;
+            *reinterpret_cast<float4 *>(&xs[r][4 * q]) =
+                *reinterpret_cast<const float4 *>(arow + (size_t)r * DQ_FC1_IN + 4 * (kq + q));
+        }
+        __syncthreads();
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int r = 0; r < DQ_RMAX; ++r) {
                 if (r < nrows) {  // wave-uniform
-                    const float4 x = *reinterpret_cast<const float4 *>(arow + (size_t)r * DQ_FC1_IN + 4 * (kq + u));
+                    const float4 x = *reinterpret_cast<const float4 *>(&xs[r][4 * u]);
                     acc[r] = __builtin_fmaf(wv[u].x, x.x, acc[r]);
                     acc[r] = __builtin_fmaf(wv[u].y, x.y, acc[r]);
                     acc[r] = __builtin_fmaf(wv[u].z, x.z, acc[r]);
@@ -361,7 +379,7 @@ extern "C" int coevo_dqn_forward_argmax(const float *slab, const coevo_dqn_task 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(dqn_conv_kernel, dim3(n_tasks, max_rows_per_task), dim3(256), 0, s, slab, tasks, C, n_actions,
                        frames, act);
-    hipLaunchKernelGGL(dqn_fc1_kernel, dim3(n_tasks, 2), dim3(256), 0, s, slab, tasks, C, n_actions, act, hid);
+    hipLaunchKernelGGL(dqn_fc1_kernel, dim3(n_tasks, 8), dim3(64), 0, s, slab, tasks, C, n_actions, act, hid);
     hipLaunchKernelGGL(dqn_out_kernel, dim3(n_tasks, max_rows_per_task), dim3(64), 0, s, slab, tasks, C, n_actions, hid,
                        actions, logits, status);
     COEVO_HIP_CHECK(hipGetLastError());
