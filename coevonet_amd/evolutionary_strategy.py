@@ -274,21 +274,35 @@ class ESTrainer:
     def base_agents(self):
         """the three trained agents, as the reference returns them (evolutionary_strategy.py:393)"""
         out = []
+        state = torch.random.get_rng_state()  # building the agent objects must not advance the reference's RNG stream
         for r in ROLES:
             a = create_agent(self.env, self.args, role=r)
             a.model.set_flat(self.eng.download(r, "base", 0, 1)[0])
             out.append(a)
+        torch.random.set_rng_state(state)
         return tuple(out)
 
 
 def evolution_strategy_train(env, args, output_dir, rng=None, env_mode=None, collect=True, return_result=False):
     """Drop-in for evolutionary_strategy.py:151: returns (agent_0, agent_1, adversary) like the reference; with
     return_result=True also the ESResult history (what the reference only plots)."""
+    import os
+    from .io_utils import ES_FILES, MetricsWriter, save_model
     tr = ESTrainer(env, args, rng=rng, env_mode=env_mode, collect=collect)
+    save = bool(getattr(args, "save", False)) and output_dir is not None
     for _ in range(args.generations):
-        if not tr.step():
+        go_on = tr.step()
+        if save:  # evolutionary_strategy.py:357-360
+            for a, r in zip(tr.base_agents(), ROLES):
+                save_model(a, os.path.join(output_dir, ES_FILES[r]))
+        if not go_on:
             break
     res = tr.finish()
     res.engine = tr.eng
     agents = tr.base_agents()
+    mw = MetricsWriter(output_dir)
+    for g in range(len(res.rewards["agent_0"])):
+        mw.write(generation=g, eval_rewards={r: res.rewards[r][g] for r in ROLES}, mutation_power=res.sigma_after[g],
+                 diversity=res.diversity[g] if g < len(res.diversity) else None,
+                 seconds=res.seconds[g] if g < len(res.seconds) else None)
     return (agents, res) if return_result else agents

@@ -521,10 +521,27 @@ def genetic_algorithm_train(env, agent, args, output_dir, rng=None, env_mode=Non
 
     rng: "host_reference" (default) reproduces the reference's torch RNG stream bit for bit;
          "device_philox" builds offspring on the device (args.coevo_rng may select it as well)."""
+    from .io_utils import GA_FILES, MetricsWriter, agents_from_flat, save_model
     tr = GATrainer(env, args, rng=rng, env_mode=env_mode, collect=collect, dist_ctx=dist_ctx)
+    save = bool(getattr(args, "save", False)) and output_dir is not None
     for _ in range(args.generations):
         tr.step()
-    return tr.finish()
+        if save:  # genetic_algorithm.py:293-299: HoF and elites of the three roles, every generation
+            for r in ROLES:
+                hof_file, elite_file = GA_FILES[r]
+                save_model(agents_from_flat(env, args, r, tr.eng.download(r, "hof", 0, args.hof_size)),
+                           os.path.join(output_dir, hof_file))
+                save_model(agents_from_flat(env, args, r, tr.eng.download(r, "elite", 0, args.elites_number)),
+                           os.path.join(output_dir, elite_file))
+    res = tr.finish()
+    mw = MetricsWriter(output_dir)
+    for g in range(len(res.rewards["agent_0"])):
+        mw.write(generation=g, eval_rewards={r: res.rewards[r][g] for r in ROLES},
+                 mutation_power=res.sigma_after[g] if g < len(res.sigma_after) else None,
+                 diversity=res.diversity[g] if g < len(res.diversity) else None,
+                 elite_ids=res.elite_ids[g] if g < len(res.elite_ids) else None,
+                 seconds=res.seconds[g] if g < len(res.seconds) else None)
+    return res
 
 
 def _finish_generation(args, gen, eval_triple, res):

@@ -1,0 +1,56 @@
+"""Checkpoint export and metrics.
+
+* ``save_model(obj, path)`` = utils/utils_pth_and_plots.py:78-80 (``torch.save`` of python objects).  The trainers call it
+  with lists of ``Agent`` objects under the reference's file names (genetic_algorithm.py:53-61, 293-299;
+  evolutionary_strategy.py:154-156, 357-360), so ``load_agent_for_testing`` (utils/utils_pth_and_plots.py:8-74) +
+  ``main.py --test`` keep working on what this package writes (the pickles reference ``coevonet_amd.agent.MPEAgent``;
+  pass ``weights_only=False`` to ``torch.load`` on torch >= 2.6, which the reference does not).
+* ``MetricsWriter`` replaces the three matplotlib savefigs per generation (utils/utils_pth_and_plots.py:153-262, 2.6 s per
+  generation in the reference, and a crash without --adaptive at :235) with one JSON line per generation.
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import torch
+
+GA_FILES = {"agent_0": ("hall_of_fame_agent_0.pth", "elite_weights_agent_0.pth"),
+            "agent_1": ("hall_of_fame_agent_1.pth", "elite_weights_agent_1.pth"),
+            "adversary_0": ("hall_of_fame_adversary.pth", "elite_weights_adversary.pth")}
+ES_FILES = {"agent_0": "agent_0.pth", "agent_1": "agent_1.pth", "adversary_0": "adversary.pth"}
+
+
+def save_model(obj, file_path):
+    torch.save(obj, file_path)
+
+
+def load_agents(file_path):
+    return torch.load(file_path, weights_only=False)
+
+
+def agents_from_flat(env, args, role, flats):
+    """[n][P] flat parameter rows -> list of MPEAgent (the objects the reference pickles)"""
+    from .game_logic import create_agent
+    state = torch.random.get_rng_state()  # constructing agents draws from the generator: leave the stream untouched
+    out = []
+    for w in flats:
+        a = create_agent(env, args, role)
+        a.model.set_flat(w)
+        out.append(a)
+    torch.random.set_rng_state(state)
+    return out
+
+
+class MetricsWriter:
+    def __init__(self, output_dir, name="metrics.jsonl"):
+        self.path = None
+        if output_dir:
+            os.makedirs(output_dir, exist_ok=True)
+            self.path = os.path.join(output_dir, name)
+            open(self.path, "w").close()
+
+    def write(self, **rec):
+        if self.path:
+            with open(self.path, "a") as f:
+                f.write(json.dumps(rec) + "\n")

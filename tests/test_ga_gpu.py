@@ -113,3 +113,28 @@ def test_aec_loop_with_device_forward():
     env.reset()
     got = _play_mpe_aec(env, a0.model, a1.model, adv.model, args, False)
     assert list(got) == case["games"][0]["rewards"]
+
+
+def test_save_and_metrics_roundtrip(tmp_path):
+    """--save writes the reference's file names with lists of Agent objects that load back (what
+    load_agent_for_testing + main.py --test consume), and one metrics line per generation"""
+    import json
+    import os
+    from coevonet_amd.io_utils import GA_FILES, load_agents
+    cfg = {"seed": 3, "args": dict(generations=2, population=5, hof_size=2, elites_number=2, save=True,
+                                   max_timesteps_per_episode=20, max_evaluation_steps=20)}
+    torch.manual_seed(cfg["seed"])
+    args = Bag(algorithm="GA", **cfg["args"])
+    env = initialize_env(args)
+    res = ga.genetic_algorithm_train(env, env.agents[0], args, str(tmp_path), rng="device_philox")
+    for role, (hof_file, elite_file) in GA_FILES.items():
+        hof = load_agents(os.path.join(tmp_path, hof_file))
+        assert len(hof) == 2 and hasattr(hof[-1], "model") and hasattr(hof[-1].model, "determine_action")
+        assert [sha(a.model.flat()) for a in hof] == [sha(w) for w in res.engine.download(role, "hof", 0, 2)]
+        assert len(load_agents(os.path.join(tmp_path, elite_file))) == 2
+    lines = [json.loads(x) for x in open(os.path.join(tmp_path, "metrics.jsonl"))]
+    assert len(lines) == 2 and lines[1]["generation"] == 1 and set(lines[0]["eval_rewards"]) == set(ga.ROLES)
+    # a reloaded trio plays through the drop-in play_game like main.py --test does
+    trio = [load_agents(os.path.join(tmp_path, GA_FILES[r][0]))[-1] for r in ("agent_0", "agent_1", "adversary_0")]
+    out = play_game(env=env, player1=trio[0].model, player2=trio[1].model, adversary=trio[2].model, args=args, eval=True)
+    assert len(out) == 3 and all(np.isfinite(out))
