@@ -146,6 +146,8 @@ def main():
     ctx.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    if timed and not a.no_graph:
+        tr.stamp_every = 4  # reading a generation's 25 launch durations back needs a host sync: every 4th generation
     for i in range(a.steps):
         tr.step()
     torch.cuda.synchronize()
@@ -191,7 +193,7 @@ def main():
                 with open(pmc) as f:
                     traffic = json.load(f)["dominant_kernel_hbm_bytes_per_launch"]
                 traffic_note = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc passes of this command)"
-            out["roofline"] = {"bound": "hbm", "kernel": "fc_policy_kernel<5,true> (per-individual weight sets)",
+            out["roofline"] = {"bound": "hbm", "kernel": "fc_policy_kernel<5, 2> (per-individual weight sets, fused env step)",
                                "timing": ("HIP events around each launch on its stream" if a.no_graph else
                                           "in-kernel 100 MHz clock stamps, first workgroup start to last workgroup "
                                           "end (HIP events cannot be read back from replayed hipGraphs; "

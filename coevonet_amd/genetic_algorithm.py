@@ -389,6 +389,8 @@ class GAEngine:
                 self._gen_graph[key] = gr
                 # the capture did not execute anything: the counter still holds `gen`
             self._gen_graph[key].replay()
+            if self.ro.time_light:
+                self.ro._pending_stamps = self.n_cycles  # this replay re-armed and re-wrote the clock stamps
         else:
             self.enqueue_generation()
 
@@ -444,6 +446,7 @@ class GATrainer:
         self.res = GAResult()
         self.res.engine = self.eng
         self.gen = 0
+        self.stamp_every = 1
         # the host-free generation loop needs device-built offspring, the device env and a single rank
         self.device_loop = (self.rng == "device_philox" and env_mode == "device" and shard == (0, 1)
                             and getattr(args, "coevo_device_loop", True))
@@ -460,6 +463,11 @@ class GATrainer:
             eng.replay_generation(gen)
             if self.collect:
                 self._collect_device_loop(gen)
+            elif eng.ro.time_light and gen % self.stamp_every == 0:
+                # kernel-timing sample: the stamps are written by every replay (switching between a stamped and a plain
+                # graph costs more than the stamps), but reading them back needs a host sync: sampled generations only
+                torch.cuda.current_stream().synchronize()
+                eng.ro.collect_stamps()
             res.seconds.append(time.perf_counter() - t0)
             self.gen += 1
             return
