@@ -20,6 +20,21 @@ namespace coevo {
 #define COEVO_LIGHT_U 16
 #endif
 
+// A per-individual weight set is read exactly once per launch by exactly one CU.  Non-temporal loads (which would
+// keep that stream from evicting the shared-opponent nets out of L2, MI355X_MICROARCH.md row nt-weights) were measured
+// here and change nothing (350 vs 349 generations/s, 85 vs 81 us in situ): plain loads ship, -DCOEVO_NT builds the
+// other variant for A/B runs.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ inline float4 load_stream16(const float4 *p)
+{
+#ifndef COEVO_NT
+    return *p;
+#else
+    const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+#endif
+}
+
 template <int R>
 struct FcSmem {
     static constexpr int RP = R | 1;  // odd row pitch: conflict-free scatter of h1 into the k-quad image
@@ -231,7 +246,7 @@ __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
         for (int kq = 0; kq < 128; kq += U) {
             float4 wv[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) wv[u] = wp[(size_t)(kq + u) * 64];
+            for (int u = 0; u < U; ++u) wv[u] = load_stream16(wp + (size_t)(kq + u) * 64);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
 #pragma unroll
