@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="enqueue every launch eagerly instead of replaying the "
                     "captured hipGraph of a generation's rollout")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--cohorts", type=int, default=None, help="independent game cohorts per rollout (default: the "
+                    "engine's DEFAULT_COHORTS)")
     a = ap.parse_args()
 
     from coevonet_amd import lib as L
@@ -128,6 +130,9 @@ def main():
     torch.manual_seed(0)
     np.random.seed(0)
     args = make_args(pop, a.hof, a.elites, a.limit)
+    args.generations = a.steps + a.warmup  # sizes the device-resident evaluation / sigma histories
+    if a.cohorts is not None:
+        args.coevo_cohorts = a.cohorts
     env = initialize_env(args)
     tr = GATrainer(env, args, rng="device_philox", env_mode=a.env, collect=False, dist_ctx=ctx)
     eng = tr.eng
@@ -179,11 +184,13 @@ def main():
             avg_ms = float(np.mean(d))
             # algorithmic bytes of one launch of the dominant kernel: every distinct weight set among its tasks once
             # + observations in / actions out; state reads are the observations' fp64 sources
-            nets = {}
-            for t in eng.plan.light_np:
-                nets[int(t["net_off"])] = L.fc_param_count(int(t["D"])) * 4
-            rows = int(sum(int(t["n_rows"]) for t in eng.plan.light_np))
-            alg_bytes = sum(nets.values()) + rows * (4 * 10 + 4)
+            merged = bool(eng.ro.desc.merged) and len(eng.plan.heavy_np) > 0
+            nets, rows = {}, 0
+            for arr in ((eng.plan.heavy_np, eng.plan.light_np) if merged else (eng.plan.light_np,)):
+                for t in arr:
+                    nets[int(t["net_off"])] = L.fc_param_count(int(t["D"])) * 4
+                    rows += int(t["n_rows"])
+            alg_bytes = (sum(nets.values()) + rows * (4 * 10 + 4)) / max(eng.ro.n_cohorts, 1)
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
             traffic, traffic_note = None, None
             pmc = os.path.join(REPO, "profiles", "r01_pmc_hbm_traffic.json")
@@ -191,9 +198,15 @@ def main():
                 # HBM bytes per launch of this kernel from the PMC counters (FETCH_SIZE/WRITE_SIZE, separate rocprofv3
                 # passes of this same command, gfx950 correction applied) - collected offline, see the file
                 with open(pmc) as f:
-                    traffic = json.load(f)["dominant_kernel_hbm_bytes_per_launch"]
-                traffic_note = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc passes of this command)"
-            out["roofline"] = {"bound": "hbm", "kernel": "fc_policy_kernel<5, 2> (per-individual weight sets, fused env step)",
+                    j = json.load(f)
+                want = "fc_cycle_kernel<5>" if merged else "fc_policy_kernel<5, 2>"
+                if want in j.get("dominant_kernel", ""):
+                    traffic = j["dominant_kernel_hbm_bytes_per_launch"]
+                    traffic_note = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc passes of this command)"
+            kname = ("fc_cycle_kernel<5> (one env-cycle: per-individual weight sets streamed once + shared-opponent "
+                     "tasks on the matrix cores, fused env step)" if merged else
+                     "fc_policy_kernel<5, 2> (per-individual weight sets, fused env step)")
+            out["roofline"] = {"bound": "hbm", "kernel": kname,
                                "timing": ("HIP events around each launch on its stream" if a.no_graph else
                                           "in-kernel 100 MHz clock stamps, first workgroup start to last workgroup "
                                           "end (HIP events cannot be read back from replayed hipGraphs; "

@@ -73,8 +73,11 @@ __device__ inline float half_tree_sum(float v)
     v = v + dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
     v = v + dpp_move<0x141>(v);  // row_half_mirror
     v = v + dpp_move<0x140>(v);  // row_mirror
-    v = v + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));  // xor 16 within 32 lanes
-    return v;
+    // xor 16: v_permlane16_swap(v, v) leaves {row0,row0,row2,row2} and {row1,row1,row3,row3} (rows of 16 lanes); their
+    // sum is the pairwise sum in every lane (fp add commutes, so the bits equal v + v[lane ^ 16]) - no LDS round trip
+    typedef unsigned u32x2_h __attribute__((ext_vector_type(2)));
+    const u32x2_h s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
 }
 
 // all six levels: every lane returns the block (64-lane) sum

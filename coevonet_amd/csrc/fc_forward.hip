@@ -67,6 +67,10 @@ struct FcArgs {
     int32_t *act_cur;            // [n_games][3] this cycle's actions
     const int32_t *game_limit;
     int cycle, pos_first;
+    // merged launch only (fc_cycle_kernel): workgroups [0, n_heavy) run `tasks` on the matrix cores, the rest run
+    // `light_tasks[blockIdx.x - n_heavy]` through the streaming path
+    const coevo_fc_task *light_tasks;
+    int n_heavy;
 };
 constexpr int MODE_OBS = 0, MODE_STATE = 1, MODE_FUSED = 2;
 
@@ -93,9 +97,8 @@ __device__ unsigned long long g_phase_stamps[4096 * 8];
 #define COEVO_STAMP(i)                                                                          \
     do {                                                                                        \
         if (threadIdx.x == 0 && blockIdx.x < 4096) {                                            \
-            unsigned long long _t;                                                              \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");          \
-            g_phase_stamps[blockIdx.x * 8 + (i)] = _t;                                          \
+            /* 100 MHz constant clock: comparable across XCDs (s_memtime is per XCD) */          \
+            g_phase_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime();            \
         }                                                                                       \
     } while (0)
 #else
@@ -106,13 +109,10 @@ __device__ unsigned long long g_phase_stamps[4096 * 8];
 // streaming wave would need <= 88 registers; capping this kernel at 80 spills 39 registers and is slower overall,
 // 290 vs 346 generations/s - measured, not pursued.)
 template <int R, int MODE>
-__global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
+__device__ __forceinline__ void fc_policy_body(const FcArgs &a, FcSmem<R> &sm, const coevo_fc_task &task)
 {
-    __shared__ FcSmem<R> sm;
-    stamp_begin(a.stamps);
     COEVO_STAMP(0);
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
-    const coevo_fc_task task = a.tasks[blockIdx.x];
     const int D = task.D, nrows = task.n_rows, row0 = task.row_begin;
     const float *net = a.slab + task.net_off;
     int st = 0;
@@ -242,6 +242,9 @@ __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
         // 128/U memory latencies, hidden by the other workgroups resident on the CU.  (Deeper software pipelining was
         // tried three ways - C++ double buffer, ping-pong buffers with sched_barrier, inline-asm loads with counted
         // vmcnt - and hipcc either sinks the prefetch below its consumer or spills hundreds of registers.)
+        // (Also measured: activations in SGPRs instead of LDS broadcasts - h1 through a global scratch and s_load,
+        // v_pk_fma_f32 with an SGPR-pair operand.  Bit-exact, 22.7 vs 27 us for a lone workgroup's stream, but the 16 KiB
+        // scalar cache thrashes with several workgroups per CU: 326 vs 347 generations/s in situ.  Not shipped.)
         constexpr int U = COEVO_LIGHT_U;
         for (int kq = 0; kq < 128; kq += U) {
             float4 wv[U];
@@ -337,6 +340,14 @@ __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
     }
     if (st) atomicOr(a.status, st);
     COEVO_STAMP(6);
+}
+
+template <int R, int MODE>
+__global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
+{
+    __shared__ FcSmem<R> sm;
+    stamp_begin(a.stamps);
+    fc_policy_body<R, MODE>(a, sm, a.tasks[blockIdx.x]);
     stamp_end(a.stamps);
 }
 
@@ -368,14 +379,13 @@ struct FcMfmaSmem {
 __device__ inline int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void fc_policy_mfma_kernel(FcArgs a)
+__device__ __forceinline__ void fc_policy_mfma_body(const FcArgs &a, FcMfmaSmem &sm, const coevo_fc_task &task)
 {
-    __shared__ FcMfmaSmem sm;
     // these workgroups are the long pole of a cycle when they share CUs with the streaming kernel's waves: let their
     // (few) waves win issue arbitration; the streaming waves are waiting on HBM most of the time anyway
     __builtin_amdgcn_s_setprio(3);
+    COEVO_STAMP(0);
     const int t = threadIdx.x, w = t >> 6, l = t & 63, lc = l & 31, lh = l >> 5;
-    const coevo_fc_task task = a.tasks[blockIdx.x];
     const int D = task.D, nrows = task.n_rows, row0 = task.row_begin;
     const float *net = a.slab + task.net_off;
     int st = 0;
@@ -440,6 +450,7 @@ __global__ __launch_bounds__(256, 2) void fc_policy_mfma_kernel(FcArgs a)
         for (int i = t; i < NACT * H2; i += 256) sm.w3s[i >> 8][i & 255] = W3[i];
     }
     __syncthreads();
+    COEVO_STAMP(1);
 
     // ---- fc1 on the matrix cores: 4 column tiles per wave, D/2 k-pairs ---------------------------------------
     f32x16 c1[4];
@@ -506,6 +517,7 @@ __global__ __launch_bounds__(256, 2) void fc_policy_mfma_kernel(FcArgs a)
         }
     }
     __syncthreads();
+    COEVO_STAMP(2);
 
     // ---- fc2 on the matrix cores: 2 column tiles per wave, 256 k-pairs ---------------------------------------
     f32x16 c2[2];
@@ -556,6 +568,7 @@ __global__ __launch_bounds__(256, 2) void fc_policy_mfma_kernel(FcArgs a)
         consume(bufA, ko);
         consume(bufB, ko + U);
     }
+    COEVO_STAMP(3);
     // ---- LayerNorm(256): canonical block w = this wave's two tiles -------------------------------------------
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -594,6 +607,7 @@ __global__ __launch_bounds__(256, 2) void fc_policy_mfma_kernel(FcArgs a)
         }
     }
     __syncthreads();
+    COEVO_STAMP(4);
 
     // ---- output layer (N = 5: not worth a tile), argmax, status - as in the VALU kernel ----------------------
     if (t < 32 * NACT) {
@@ -612,6 +626,7 @@ __global__ __launch_bounds__(256, 2) void fc_policy_mfma_kernel(FcArgs a)
         sm.logit[r][o] = y;
     }
     __syncthreads();
+    COEVO_STAMP(5);
     if (t < nrows) {
         int best = -1;
         float cur = -__builtin_inff();
@@ -634,6 +649,34 @@ __global__ __launch_bounds__(256, 2) void fc_policy_mfma_kernel(FcArgs a)
         }
     }
     if (st) atomicOr(a.status, st);
+    COEVO_STAMP(6);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void fc_policy_mfma_kernel(FcArgs a)
+{
+    __shared__ FcMfmaSmem sm;
+    fc_policy_mfma_body<MODE>(a, sm, a.tasks[blockIdx.x]);
+}
+
+// One launch = one env-cycle of one cohort of games (fused env step): the shared-opponent tasks first (lowest block
+// indices: they are dispatched first and are the longer workgroups), then the per-individual tasks.  Both kinds of
+// workgroup get the MFMA path's footprint (<= 256 registers, ~73 KiB LDS: two workgroups per CU), so a launch of a
+// few hundred workgroups occupies the CUs in waves - together with a second cohort's launch on another stream the
+// CUs' weight streams run out of phase and HBM stays busy through the non-streaming phases of any one workgroup.
+template <int R>
+__global__ __launch_bounds__(256, 2) void fc_cycle_kernel(FcArgs a)
+{
+    __shared__ union CycleSmem {
+        FcMfmaSmem heavy;
+        FcSmem<R> light;
+    } sm;
+    stamp_begin(a.stamps);
+    if ((int)blockIdx.x < a.n_heavy)  // workgroup-uniform
+        fc_policy_mfma_body<MODE_FUSED>(a, sm.heavy, a.tasks[blockIdx.x]);
+    else
+        fc_policy_body<R, MODE_FUSED>(a, sm.light, a.light_tasks[blockIdx.x - a.n_heavy]);
+    stamp_end(a.stamps);
 }
 
 template <int MODE>
@@ -671,7 +714,7 @@ extern "C" int coevo_fc_forward_argmax(const float *slab, const coevo_fc_task *t
     if (!slab || !tasks || !obs || !actions || !status || n_tasks < 0) return COEVO_ERR_ARG;
     if (max_rows_per_task < 1 || max_rows_per_task > COEVO_FC_MAX_ROWS) return COEVO_ERR_ARG;
     coevo::FcArgs a{slab, tasks, obs, nullptr, nullptr, nullptr, 0, actions, logits, status, nullptr,
-                    nullptr, nullptr, nullptr, nullptr, 0, 0};
+                    nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0};
     return coevo::launch_fc<coevo::MODE_OBS>(a, n_tasks, max_rows_per_task, (hipStream_t)stream);
 }
 
@@ -698,7 +741,7 @@ extern "C" int coevo_mpe_policy_cycle_stamped(const float *slab, const coevo_fc_
     if (n_tasks < 0 || n_games <= 0) return COEVO_ERR_ARG;
     if (max_rows_per_task < 1 || max_rows_per_task > COEVO_FC_MAX_ROWS) return COEVO_ERR_ARG;
     coevo::FcArgs a{slab, tasks, nullptr, state, row_game, row_slot, n_games, actions, nullptr, status,
-                    reinterpret_cast<unsigned long long *>(stamps), nullptr, nullptr, nullptr, nullptr, 0, 0};
+                    reinterpret_cast<unsigned long long *>(stamps), nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0};
     return coevo::launch_fc<coevo::MODE_STATE>(a, n_tasks, max_rows_per_task, (hipStream_t)stream);
 }
 
@@ -715,6 +758,32 @@ extern "C" int coevo_mpe_policy_cycle_fused(const float *slab, const coevo_fc_ta
     if (max_rows_per_task < 1 || max_rows_per_task > COEVO_FC_MAX_ROWS) return COEVO_ERR_ARG;
     coevo::FcArgs a{slab, tasks, nullptr, state_prev, row_game, row_slot, n_games, nullptr, nullptr, status,
                     reinterpret_cast<unsigned long long *>(stamps), state_next, act_prev, act_cur, game_limit, cycle,
-                    pos_first};
+                    pos_first, nullptr, 0};
     return coevo::launch_fc<coevo::MODE_FUSED>(a, n_tasks, max_rows_per_task, (hipStream_t)stream);
+}
+
+extern "C" int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_task *heavy_tasks, int n_heavy,
+                                             const coevo_fc_task *light_tasks, int n_light, int light_max_rows,
+                                             const double *state_prev, double *state_next, int n_games,
+                                             const int32_t *row_game, const int32_t *row_slot, const int32_t *act_prev,
+                                             int32_t *act_cur, const int32_t *game_limit, int cycle, int pos_first,
+                                             int32_t *status, uint64_t *stamps, void *stream)
+{
+    if (!slab || !heavy_tasks || !light_tasks || !state_prev || !state_next || !row_game || !row_slot || !act_prev ||
+        !act_cur || !status)
+        return COEVO_ERR_ARG;
+    if (n_heavy <= 0 || n_light <= 0 || n_games <= 0 || cycle < 0 || state_prev == state_next || act_prev == act_cur)
+        return COEVO_ERR_ARG;
+    if (light_max_rows < 1 || light_max_rows > 8) return COEVO_ERR_ARG;
+    coevo::FcArgs a{slab, heavy_tasks, nullptr, state_prev, row_game, row_slot, n_games, nullptr, nullptr, status,
+                    reinterpret_cast<unsigned long long *>(stamps), state_next, act_prev, act_cur, game_limit, cycle,
+                    pos_first, light_tasks, n_heavy};
+    const dim3 grid(n_heavy + n_light), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (light_max_rows <= 1) hipLaunchKernelGGL((coevo::fc_cycle_kernel<1>), grid, block, 0, s, a);
+    else if (light_max_rows <= 2) hipLaunchKernelGGL((coevo::fc_cycle_kernel<2>), grid, block, 0, s, a);
+    else if (light_max_rows <= 5) hipLaunchKernelGGL((coevo::fc_cycle_kernel<5>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((coevo::fc_cycle_kernel<8>), grid, block, 0, s, a);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
 }

@@ -18,9 +18,16 @@ __global__ void stamps_init_kernel(uint64_t *stamps, int n)
     }
 }
 
+// stream of one cohort beyond the first (the first cohort uses the caller's stream)
+struct cohort_lane {
+    hipStream_t s = nullptr;
+    hipEvent_t done = nullptr;
+};
+
 struct coevo_rollout_ctx {
     hipStream_t side = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, start = nullptr;
+    std::vector<cohort_lane> lanes;  // created on first use
     std::vector<hipEvent_t> timing;  // pairs (start, end) around the light launch of each cycle
     int pairs_used = 0;
 };
@@ -32,7 +39,8 @@ extern "C" void *coevo_rollout_ctx_create(int n_timing_pairs)
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->start, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return nullptr;
     }
@@ -47,10 +55,30 @@ extern "C" void coevo_rollout_ctx_destroy(void *ctx)
     auto *c = static_cast<coevo_rollout_ctx *>(ctx);
     if (!c) return;
     for (auto e : c->timing) (void)hipEventDestroy(e);
+    for (auto &ln : c->lanes) {
+        if (ln.done) (void)hipEventDestroy(ln.done);
+        if (ln.s) (void)hipStreamDestroy(ln.s);
+    }
+    if (c->start) (void)hipEventDestroy(c->start);
     if (c->fork) (void)hipEventDestroy(c->fork);
     if (c->join) (void)hipEventDestroy(c->join);
     if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
+}
+
+// streams for up to n_cohorts independent cohorts (coevo_rollout_desc.n_cohorts); call outside graph capture
+extern "C" int coevo_rollout_ctx_reserve_cohorts(void *ctx, int n_cohorts)
+{
+    auto *c = static_cast<coevo_rollout_ctx *>(ctx);
+    if (!c || n_cohorts < 1 || n_cohorts > COEVO_MAX_COHORTS) return COEVO_ERR_ARG;
+    while ((int)c->lanes.size() < n_cohorts - 1) {
+        cohort_lane ln;
+        if (hipStreamCreateWithFlags(&ln.s, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ln.done, hipEventDisableTiming) != hipSuccess)
+            return COEVO_ERR_HIP;
+        c->lanes.push_back(ln);
+    }
+    return COEVO_OK;
 }
 
 extern "C" int coevo_rollout_ctx_reset_timing(void *ctx)
@@ -83,58 +111,111 @@ extern "C" int coevo_mpe_rollout(const coevo_rollout_desc *d, void *ctx, int tim
     if ((d->n_heavy > 0 && !d->heavy) || (d->n_light > 0 && !d->light)) return COEVO_ERR_ARG;
     auto *c = static_cast<coevo_rollout_ctx *>(ctx);
     hipStream_t main_s = (hipStream_t)stream;
-    const bool two = c && d->n_heavy > 0 && d->n_light > 0;
     // HIP events cannot be read back from inside a captured graph (external event-record nodes are rejected by this
     // runtime), so event timing is for eager enqueues only; graph replays use the kernels' own clock stamps instead
     auto record_timing = [&](hipEvent_t e) { return hipEventRecord(e, main_s); };
     if (d->light_stamps && d->n_cycles > 0) {  // [cycle][2] = {UINT64_MAX, 0}, re-armed by every enqueue / replay
         hipLaunchKernelGGL(stamps_init_kernel, dim3(1), dim3(256), 0, main_s, d->light_stamps,
-                           d->n_cycles * COEVO_STAMP_SLOTS);
+                           (d->n_cohorts > 1 ? d->n_cohorts : 1) * d->n_cycles * COEVO_STAMP_SLOTS);
         COEVO_HIP_CHECK(hipGetLastError());
     }
     const bool fused = d->state_alt != nullptr && d->actions_by_game != nullptr;
     const size_t act_stride = 3 * (size_t)d->n_games;
-    for (int cyc = 0; cyc < d->n_cycles; ++cyc) {
-        int rc;
-        // fused env step: cycle c reads the state of cycle c-1 (buffer (c-1)&1; buffer 0 holds the reset state) and
-        // the actions of cycle c-1, derives its own state in registers, the owner rows write it to buffer c&1
-        const double *st_prev = (cyc == 0) ? d->state : (((cyc - 1) & 1) ? d->state_alt : d->state);
-        double *st_next = (cyc & 1) ? d->state_alt : d->state;
-        if (cyc == 0) st_next = d->state_alt;  // never written in cycle 0; only has to differ from st_prev
-        const int32_t *act_prev = fused ? d->actions_by_game + (size_t)((cyc + 1) & 1) * act_stride : nullptr;
-        int32_t *act_cur = fused ? d->actions_by_game + (size_t)(cyc & 1) * act_stride : nullptr;
-        auto policy = [&](const coevo_fc_task *tasks, int n_tasks, int max_rows, uint64_t *stamps, hipStream_t s) {
-            if (fused)
-                return coevo_mpe_policy_cycle_fused(d->slab, tasks, n_tasks, max_rows, st_prev, st_next, d->n_games,
-                                                    d->row_game, d->row_slot, act_prev, act_cur, d->game_limit, cyc,
-                                                    d->pos_first, d->status, stamps, s);
-            return coevo_mpe_policy_cycle_stamped(d->slab, tasks, n_tasks, max_rows, d->state, d->n_games, d->row_game,
-                                                  d->row_slot, d->actions, d->status, stamps, s);
-        };
-        if (two) {
-            COEVO_HIP_CHECK(hipEventRecord(c->fork, main_s));
-            COEVO_HIP_CHECK(hipStreamWaitEvent(c->side, c->fork, 0));
-        }
-        if (d->n_heavy > 0) {
-            rc = policy(d->heavy, d->n_heavy, d->heavy_max_rows, nullptr, two ? c->side : main_s);
-            if (rc) return rc;
-            if (two) COEVO_HIP_CHECK(hipEventRecord(c->join, c->side));
-        }
-        if (d->n_light > 0) {
-            const bool timed = time_light && c && (size_t)(2 * c->pairs_used + 1) < c->timing.size();
-            if (timed) COEVO_HIP_CHECK(record_timing(c->timing[2 * c->pairs_used]));
-            rc = policy(d->light, d->n_light, d->light_max_rows,
-                        d->light_stamps ? d->light_stamps + 2 * COEVO_STAMP_SLOTS * cyc : nullptr, main_s);
-            if (rc) return rc;
-            if (timed) {
-                COEVO_HIP_CHECK(record_timing(c->timing[2 * c->pairs_used + 1]));
-                ++c->pairs_used;
+    const int K = d->n_cohorts > 1 ? d->n_cohorts : 1;
+    if (K > 1) {
+        if (!c || !fused || !d->heavy_begin || !d->light_begin || K > COEVO_MAX_COHORTS) return COEVO_ERR_ARG;
+        if (d->heavy_begin[0] != 0 || d->light_begin[0] != 0 || d->heavy_begin[K] != d->n_heavy ||
+            d->light_begin[K] != d->n_light)
+            return COEVO_ERR_ARG;
+        for (int k = 0; k < K; ++k)
+            if (d->heavy_begin[k + 1] < d->heavy_begin[k] || d->light_begin[k + 1] < d->light_begin[k]) return COEVO_ERR_ARG;
+        // the lanes must exist already: streams cannot be created while the caller is capturing a graph
+        if ((int)c->lanes.size() < K - 1) return COEVO_ERR_ARG;
+        COEVO_HIP_CHECK(hipEventRecord(c->start, main_s));
+        // One stream per cohort, forked from / joined to the caller's stream only.  (Under graph capture this runtime
+        // tolerates mutual waits between the origin stream and a forked stream - the K = 1 pair below - but two forked
+        // streams that wait on each other send hip::Stream::EndCapture into endless recursion.)  Inside a cohort the
+        // shared-opponent launch and the per-individual launch of a cycle therefore run back to back; the overlap of
+        // matrix-core work with weight streaming now comes from the other cohorts' launches.
+        for (int k = 1; k < K; ++k) COEVO_HIP_CHECK(hipStreamWaitEvent(c->lanes[k - 1].s, c->start, 0));
+    }
+    // one cohort's chain of cycles: per cycle the shared-opponent launch on `hs` || the per-individual launch on `ls`
+    // (hs == ls: back to back)
+    auto chain = [&](int k, const coevo_fc_task *heavy, int n_heavy, const coevo_fc_task *light, int n_light,
+                     hipStream_t ls, hipStream_t hs, hipEvent_t fork, hipEvent_t join) -> int {
+        const bool two = c && hs != ls && n_heavy > 0 && n_light > 0;
+        for (int cyc = 0; cyc < d->n_cycles; ++cyc) {
+            int rc;
+            // fused env step: cycle c reads the state of cycle c-1 (buffer (c-1)&1; buffer 0 holds the reset state)
+            // and the actions of cycle c-1, derives its own state in registers, the owner rows write it to buffer c&1
+            const double *st_prev = (cyc == 0) ? d->state : (((cyc - 1) & 1) ? d->state_alt : d->state);
+            double *st_next = (cyc & 1) ? d->state_alt : d->state;
+            if (cyc == 0) st_next = d->state_alt;  // never written in cycle 0; only has to differ from st_prev
+            const int32_t *act_prev = fused ? d->actions_by_game + (size_t)((cyc + 1) & 1) * act_stride : nullptr;
+            int32_t *act_cur = fused ? d->actions_by_game + (size_t)(cyc & 1) * act_stride : nullptr;
+            auto policy = [&](const coevo_fc_task *tasks, int n_tasks, int max_rows, uint64_t *stamps, hipStream_t s) {
+                if (fused)
+                    return coevo_mpe_policy_cycle_fused(d->slab, tasks, n_tasks, max_rows, st_prev, st_next, d->n_games,
+                                                        d->row_game, d->row_slot, act_prev, act_cur, d->game_limit,
+                                                        cyc, d->pos_first, d->status, stamps, s);
+                return coevo_mpe_policy_cycle_stamped(d->slab, tasks, n_tasks, max_rows, d->state, d->n_games,
+                                                      d->row_game, d->row_slot, d->actions, d->status, stamps, s);
+            };
+            if (fused && d->merged && n_heavy > 0 && n_light > 0 && d->light_max_rows <= 8) {
+                rc = coevo_mpe_policy_cycle_merged(
+                    d->slab, heavy, n_heavy, light, n_light, d->light_max_rows, st_prev, st_next, d->n_games, d->row_game,
+                    d->row_slot, act_prev, act_cur, d->game_limit, cyc, d->pos_first, d->status,
+                    d->light_stamps ? d->light_stamps + 2 * COEVO_STAMP_SLOTS * ((size_t)k * d->n_cycles + cyc) : nullptr,
+                    ls);
+                if (rc) return rc;
+                continue;
+            }
+            hipStream_t heavy_s = two ? hs : ls;
+            if (two) {
+                COEVO_HIP_CHECK(hipEventRecord(fork, ls));
+                COEVO_HIP_CHECK(hipStreamWaitEvent(hs, fork, 0));
+            }
+            if (n_heavy > 0) {
+                rc = policy(heavy, n_heavy, d->heavy_max_rows, nullptr, heavy_s);
+                if (rc) return rc;
+                if (two) COEVO_HIP_CHECK(hipEventRecord(join, hs));
+            }
+            if (n_light > 0) {
+                const bool timed = K == 1 && time_light && c && (size_t)(2 * c->pairs_used + 1) < c->timing.size();
+                if (timed) COEVO_HIP_CHECK(record_timing(c->timing[2 * c->pairs_used]));
+                rc = policy(light, n_light, d->light_max_rows,
+                            d->light_stamps ? d->light_stamps + 2 * COEVO_STAMP_SLOTS * ((size_t)k * d->n_cycles + cyc)
+                                            : nullptr, ls);
+                if (rc) return rc;
+                if (timed) {
+                    COEVO_HIP_CHECK(record_timing(c->timing[2 * c->pairs_used + 1]));
+                    ++c->pairs_used;
+                }
+            }
+            if (two) COEVO_HIP_CHECK(hipStreamWaitEvent(ls, join, 0));
+            if (!fused) {
+                rc = coevo_mpe_step(d->state, d->n_games, d->game_rows, d->actions, cyc, d->game_limit, d->pos_first, ls);
+                if (rc) return rc;
             }
         }
-        if (two) COEVO_HIP_CHECK(hipStreamWaitEvent(main_s, c->join, 0));
-        if (!fused) {
-            rc = coevo_mpe_step(d->state, d->n_games, d->game_rows, d->actions, cyc, d->game_limit, d->pos_first, main_s);
+        return COEVO_OK;
+    };
+    if (K == 1) {
+        const int rc = chain(0, d->heavy, d->n_heavy, d->light, d->n_light, main_s, c ? c->side : main_s,
+                             c ? c->fork : nullptr, c ? c->join : nullptr);
+        if (rc) return rc;
+    } else {
+        // enqueue order = cohort by cohort; the chains only meet again at the `done` events below
+        for (int k = 0; k < K; ++k) {
+            const int hb = d->heavy_begin[k], lb = d->light_begin[k];
+            hipStream_t ks = k ? c->lanes[k - 1].s : main_s;
+            const int rc = chain(k, d->heavy ? d->heavy + hb : nullptr, d->heavy_begin[k + 1] - hb,
+                                 d->light ? d->light + lb : nullptr, d->light_begin[k + 1] - lb, ks, ks, nullptr, nullptr);
             if (rc) return rc;
+        }
+        for (int k = 1; k < K; ++k) {
+            COEVO_HIP_CHECK(hipEventRecord(c->lanes[k - 1].done, c->lanes[k - 1].s));
+            COEVO_HIP_CHECK(hipStreamWaitEvent(main_s, c->lanes[k - 1].done, 0));
         }
     }
     if (fused) {

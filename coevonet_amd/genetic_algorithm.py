@@ -63,6 +63,9 @@ def adapt_mutation_power(args, gen, hist):
         args.mutation_power_adversary = max(args.mutation_power_adversary * 0.95, args.min_mutation_power)
 
 
+DEFAULT_COHORTS = 1   # independent game cohorts per rollout (rollout.RolloutPlan._assign_cohorts); see DESIGN.md
+
+
 class GAEngine:
     """Device-resident population / HoF / elites of the three roles and the per-generation pipeline.
 
@@ -71,7 +74,7 @@ class GAEngine:
 
     def __init__(self, pop, hof, elites, limit_train=None, limit_eval=None, max_cycles=25, device="cuda",
                  env_seed=ENV_SEED, rng="device_philox", philox_seed=0, env="device", first_ordinal=1,
-                 shard=(0, 1), gather=None, timing_pairs=4096):
+                 shard=(0, 1), gather=None, timing_pairs=4096, cohorts=1):
         assert 1 <= elites <= pop and hof >= 1
         self.pop, self.hof, self.E = pop, hof, elites
         self.rng_mode, self.philox_seed, self.env_mode = rng, int(philox_seed), env
@@ -123,7 +126,8 @@ class GAEngine:
         self.n_main = len(games)
         for _ in range(N_EVAL):  # evaluate_current_weights(best trio) = newest HoF members (:12-29, :301)
             games.append((net("hof", "adversary_0", h - 1), net("hof", "agent_0", h - 1), net("hof", "agent_1", h - 1)))
-        self.plan = RolloutPlan(np.array(games), net_off, net_D, device=device)
+        self.plan = RolloutPlan(np.array(games), net_off, net_D, device=device,
+                                n_cohorts=cohorts if env == "device" else 1)
         if env == "device":
             self.ro = DeviceRollout(self.plan, self.slab, env_seed=env_seed, timing_pairs=timing_pairs)
         else:
@@ -441,7 +445,8 @@ class GATrainer:
                             args.max_evaluation_steps, max_cycles=getattr(env, "max_cycles", 25), rng=self.rng,
                             philox_seed=getattr(args, "coevo_seed", 0), env=env_mode,
                             first_ordinal=self.first_ordinal,
-                            env_seed=getattr(env, "seed_value", ENV_SEED) or ENV_SEED, shard=shard, gather=gather)
+                            env_seed=getattr(env, "seed_value", ENV_SEED) or ENV_SEED, shard=shard, gather=gather,
+                            cohorts=int(getattr(args, "coevo_cohorts", DEFAULT_COHORTS)))
         self.eng.load_initial(pop_flat, hof_flat)
         self.res = GAResult()
         self.res.engine = self.eng
@@ -458,6 +463,10 @@ class GATrainer:
         eng, args, res, gen = self.eng, self.args, self.res, self.gen
         t0 = time.perf_counter()
         if self.device_loop:
+            if gen > eng.cap:
+                raise RuntimeError(f"generation {gen} exceeds the device history capacity ({eng.cap}) this trainer was "
+                                   f"set up with (args.generations + 64): the adaptive mutation power could no longer "
+                                   f"be updated on the device")
             # no host round trip: evaluation means, adaptive sigma, selection and offspring all stay on the device;
             # the host only enqueues (replays) the generation and may run ahead of the GPU
             eng.replay_generation(gen)

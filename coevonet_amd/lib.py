@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcoevo.so")
+LIB_PATH = os.environ.get("COEVO_LIB") or os.path.join(HERE, "libcoevo.so")  # COEVO_LIB: A/B builds
 
 OBS_STRIDE = 12
 LOGIT_STRIDE = 8
@@ -48,8 +48,10 @@ class RolloutDesc(C.Structure):
                 ("state", C.c_void_p), ("n_games", C.c_int32), ("n_cycles", C.c_int32),
                 ("row_game", C.c_void_p), ("row_slot", C.c_void_p), ("game_rows", C.c_void_p),
                 ("actions", C.c_void_p), ("status", C.c_void_p), ("game_limit", C.c_void_p),
-                ("rewards", C.c_void_p), ("pos_first", C.c_int32), ("reserved", C.c_int32),
-                ("state_alt", C.c_void_p), ("actions_by_game", C.c_void_p), ("light_stamps", C.c_void_p)]
+                ("rewards", C.c_void_p), ("pos_first", C.c_int32), ("n_cohorts", C.c_int32),
+                ("state_alt", C.c_void_p), ("actions_by_game", C.c_void_p), ("light_stamps", C.c_void_p),
+                ("heavy_begin", C.c_void_p), ("light_begin", C.c_void_p),
+                ("merged", C.c_int32), ("reserved", C.c_int32)]
 
 
 class CoevoError(RuntimeError):
@@ -76,6 +78,7 @@ _SIGS = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "coevo_rollout_ctx_create": (C.c_void_p, [C.c_int]),
     "coevo_rollout_ctx_destroy": (None, [C.c_void_p]),
+    "coevo_rollout_ctx_reserve_cohorts": (C.c_int, [C.c_void_p, C.c_int]),
     "coevo_rollout_ctx_reset_timing": (C.c_int, [C.c_void_p]),
     "coevo_rollout_ctx_light_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "coevo_mpe_rollout": (C.c_int, [C.POINTER(RolloutDesc), C.c_void_p, C.c_int, C.c_void_p]),
@@ -91,6 +94,10 @@ _SIGS = {
     "coevo_mpe_policy_cycle_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "coevo_mpe_policy_cycle_merged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p]),
     "coevo_mpe_final_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                        C.c_void_p]),
     "coevo_fc_perturb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,

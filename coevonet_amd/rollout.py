@@ -12,6 +12,8 @@ share it), all three agents of a cycle observe the same world state, then one st
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -26,24 +28,35 @@ class RolloutPlan:
     """game_nets: int array [n_games][3] of net ids for env slots (adversary_0, agent_0, agent_1);
     net_off / net_D: per net id, float offset inside the slab and observation width."""
 
-    def __init__(self, game_nets, net_off, net_D, device="cuda", heavy_rows=HEAVY_ROWS):
+    def __init__(self, game_nets, net_off, net_D, device="cuda", heavy_rows=HEAVY_ROWS, n_cohorts=1):
         game_nets = np.asarray(game_nets, dtype=np.int64)
         self.n_games = int(game_nets.shape[0])
         by_net = {}
         for g in range(self.n_games):
             for slot in range(3):
                 by_net.setdefault(int(game_nets[g, slot]), []).append((g, slot))
-        light, heavy = [], []
         for net, rows in by_net.items():
             d = int(net_D[net])
             for g, slot in rows:
                 assert d == (8 if slot == 0 else 10), "net width does not match the env slot it plays"
+        cohort = self._assign_cohorts(by_net, self.n_games, max(1, int(n_cohorts)))
+        self.n_cohorts = int(cohort.max()) + 1 if self.n_games else 1
+        self.game_cohort_np = cohort
+        light = [[] for _ in range(self.n_cohorts)]
+        heavy = [[] for _ in range(self.n_cohorts)]
+        for net, rows in by_net.items():
             if len(rows) <= LIGHT_ROWS:
-                light.append((net, rows))
+                light[int(cohort[rows[0][0]])].append((net, rows))   # all its games share one cohort by construction
             else:
-                for i in range(0, len(rows), heavy_rows):
-                    heavy.append((net, rows[i:i + heavy_rows]))
-        heavy = self._xcd_order(heavy)
+                for k in range(self.n_cohorts):
+                    mine = [(g, slot) for g, slot in rows if cohort[g] == k]
+                    for i in range(0, len(mine), heavy_rows):
+                        heavy[k].append((net, mine[i:i + heavy_rows]))
+        heavy = [self._xcd_order(h) for h in heavy]
+        self.heavy_begin_np = np.cumsum([0] + [len(h) for h in heavy]).astype(np.int32)
+        self.light_begin_np = np.cumsum([0] + [len(x) for x in light]).astype(np.int32)
+        heavy = [t for h in heavy for t in h]
+        light = [t for x in light for t in x]
         # heavy tasks first in row space; inside each class keep first-game order (locality of the state reads)
         row_game, row_slot = [], []
         tasks = {"heavy": [], "light": []}
@@ -72,6 +85,39 @@ class RolloutPlan:
             self.game_rows = torch.from_numpy(game_rows.reshape(-1).copy()).to(device)
             self.heavy = L.tasks_to_device(self.heavy_np, device) if len(self.heavy_np) else None
             self.light = L.tasks_to_device(self.light_np, device) if len(self.light_np) else None
+
+    @staticmethod
+    def _assign_cohorts(by_net, n_games, n_cohorts):
+        """game -> cohort.  Games that share a per-individual (light) net must advance together (one task reads that
+        net once for all of them), so cohorts are unions of the connected components of "shares a light net"; the
+        components are dealt round-robin over the cohorts.  Shared-opponent (heavy) nets
+        do not tie games together: their rows are simply cut per cohort.  Speed only - results do not depend on it."""
+        cohort = np.zeros(n_games, dtype=np.int32)
+        if n_cohorts <= 1 or n_games == 0:
+            return cohort
+        parent = list(range(n_games))
+
+        def find(x):
+            while parent[x] != x:
+                parent[x] = parent[parent[x]]
+                x = parent[x]
+            return x
+
+        for rows in by_net.values():
+            if len(rows) <= LIGHT_ROWS:
+                r0 = find(rows[0][0])
+                for g, _ in rows[1:]:
+                    parent[find(g)] = r0
+        comps = {}
+        for g in range(n_games):
+            comps.setdefault(find(g), []).append(g)
+        # dealt round-robin in first-game order: every cohort gets the same share of each role's individuals
+        for c, games in enumerate(sorted(comps.values(), key=lambda c: c[0])):
+            cohort[games] = c % n_cohorts
+        # drop empty cohorts (fewer components than cohorts)
+        used = np.unique(cohort)
+        remap = {int(u): i for i, u in enumerate(used)}
+        return np.array([remap[int(c)] for c in cohort], dtype=np.int32)
 
     @staticmethod
     def _xcd_order(heavy):
@@ -111,7 +157,12 @@ class DeviceRollout:
     """Env copies resident on the GPU.  One C-ABI call (coevo_mpe_rollout) enqueues every cycle: the shared-opponent
     (MFMA) launch on a side HIP stream concurrently with the per-individual (streaming) launch, then the env step."""
 
-    def __init__(self, plan: RolloutPlan, slab: torch.Tensor, env_seed=sa.ENV_SEED, timing_pairs=0, fused_step=True):
+    def __init__(self, plan: RolloutPlan, slab: torch.Tensor, env_seed=sa.ENV_SEED, timing_pairs=0, fused_step=True,
+                 merged=None):
+        if merged is None:
+            # one launch per env-cycle (shared-opponent + per-individual workgroups together): 385 vs 347 generations/s
+            # on cfg2; COEVO_MERGED=0 keeps the two launches on two streams for A/B runs
+            merged = os.environ.get("COEVO_MERGED", "1") != "0"
         self.plan = plan
         self.slab = slab
         dev = plan.device
@@ -140,10 +191,23 @@ class DeviceRollout:
             light=L._p(p.light), n_light=len(p.light_np), light_max_rows=p.light_max,
             state=L._p(self.state), n_games=n, n_cycles=0, row_game=L._p(p.row_game), row_slot=L._p(p.row_slot),
             game_rows=L._p(p.game_rows), actions=L._p(self.actions), status=L._p(self.status),
-            game_limit=L._p(self.limits), rewards=L._p(self.rewards), pos_first=self.pos_first, reserved=0,
+            game_limit=L._p(self.limits), rewards=L._p(self.rewards), pos_first=self.pos_first, n_cohorts=0,
             state_alt=self.state2[1].data_ptr() if fused_step else None,
             actions_by_game=L._p(self.actions_by_game) if fused_step else None, light_stamps=None)
-        self.stamps = torch.zeros(256, L.STAMP_SLOTS, 2, dtype=torch.int64, device=dev)  # per cycle, per slot
+        self.n_cohorts = p.n_cohorts if fused_step else 1
+        self.desc.merged = 1 if (fused_step and merged) else 0
+        if self.n_cohorts > 1:
+            self._hb = np.ascontiguousarray(p.heavy_begin_np)   # host arrays the C side reads at enqueue time
+            self._lb = np.ascontiguousarray(p.light_begin_np)
+            self.desc.n_cohorts = self.n_cohorts
+            rc = L.load().coevo_rollout_ctx_reserve_cohorts(self.ctx, self.n_cohorts)
+            if rc:
+                raise L.CoevoError(f"coevo_rollout_ctx_reserve_cohorts failed with code {rc}")
+            self.desc.heavy_begin = self._hb.ctypes.data
+            self.desc.light_begin = self._lb.ctypes.data
+        self.stamp_cycles = 256
+        self.stamps = torch.zeros(self.n_cohorts * self.stamp_cycles, L.STAMP_SLOTS, 2, dtype=torch.int64,
+                                  device=dev)  # per (cohort, cycle), per slot
 
     def __del__(self):
         try:
@@ -166,8 +230,8 @@ class DeviceRollout:
         (cycle count, timed?) into a hipGraph and replayed: the fork/join between the two policy launches then costs a
         graph edge instead of a cross-stream event round trip (316 vs 266 generations/s on cfg2)."""
         n_cycles = int(n_cycles)
-        assert n_cycles <= self.stamps.shape[0]
-        ctx = self.ctx if self.overlap else None
+        assert n_cycles <= self.stamp_cycles
+        ctx = self.ctx if (self.overlap or self.n_cohorts > 1) else None
         timed = bool(self.time_light)
         if self.use_graph:
             # kernel timing inside a replayed graph comes from the kernel's own 100 MHz clock stamps
@@ -193,7 +257,7 @@ class DeviceRollout:
         """plain enqueue on the current stream (no graph of its own): for callers that capture a larger graph"""
         self.desc.light_stamps = L._p(self.stamps) if self.time_light else None
         self.desc.n_cycles = int(n_cycles)
-        L.call("coevo_mpe_rollout", L.C.byref(self.desc), self.ctx if self.overlap else None, 0)
+        L.call("coevo_mpe_rollout", L.C.byref(self.desc), self.ctx if (self.overlap or self.n_cohorts > 1) else None, 0)
         if self.time_light:
             self._pending_stamps = int(n_cycles)
 
@@ -201,7 +265,7 @@ class DeviceRollout:
         """after the replay has finished (the caller synchronised): fold this replay's clock stamps into the log"""
         n = getattr(self, "_pending_stamps", 0)
         if n:
-            st = self.stamps[:n].cpu().numpy()  # [n][slots][2]
+            st = self.stamps[:n * self.n_cohorts].cpu().numpy()  # [cohort * n + cycle][slots][2]
             dur = st[:, :, 1].max(axis=1) - st[:, :, 0].min(axis=1)  # first workgroup start .. last workgroup end
             self._timed_ms.extend((dur * 1e-5).tolist())  # 100 MHz ticks -> ms
             self._pending_stamps = 0

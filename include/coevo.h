@@ -133,7 +133,12 @@ typedef struct {
     int32_t *actions; int32_t *status;
     const int32_t *game_limit;   /* per game agent-step limit, or NULL */
     double *rewards;             /* [n_games][3] or NULL */
-    int32_t pos_first; int32_t reserved;
+    int32_t pos_first;
+    int32_t n_cohorts;           /* 0/1: one lock-step chain.  K > 1: the games are partitioned into K cohorts whose
+                                    cycle chains are independent (no task of one cohort touches a game of another);
+                                    cohort k runs tasks [heavy_begin[k], heavy_begin[k+1]) and [light_begin[k], ...) on
+                                    its own stream, so the cohorts drift out of phase and one cohort's weight
+                                    streaming fills the HBM idle time of another's non-streaming phases */
     /* fused env step (both set, or both NULL for the separate coevo_mpe_step launch per cycle): a second state buffer
      * and the actions by (game, slot), double buffered [2][n_games][3].  The policy launches of cycle c then derive
      * the state of cycle c in registers from cycle c-1's buffer + actions (bit-identical arithmetic), each game's
@@ -142,10 +147,19 @@ typedef struct {
     double *state_alt; int32_t *actions_by_game;
     uint64_t *light_stamps;      /* [n_cycles][COEVO_STAMP_SLOTS][2] or NULL: per light launch and slot {earliest
                                     workgroup start, latest workgroup end} in 100 MHz s_memrealtime ticks (min / max
-                                    over the slots = the launch) - kernel timing that survives graph replay */
+                                    over the slots = the launch) - kernel timing that survives graph replay.
+                                    With cohorts: [n_cohorts][n_cycles][COEVO_STAMP_SLOTS][2] */
+    const int32_t *heavy_begin;  /* HOST arrays of n_cohorts + 1 task indices (used when n_cohorts > 1) */
+    const int32_t *light_begin;
+    int32_t merged;              /* fused env step only: a cohort's cycle is ONE launch (coevo_mpe_policy_cycle_merged)
+                                    instead of the shared-opponent launch beside / before the per-individual one */
+    int32_t reserved;
 } coevo_rollout_desc;
+#define COEVO_MAX_COHORTS 8
 void *coevo_rollout_ctx_create(int n_timing_pairs);
 void coevo_rollout_ctx_destroy(void *ctx);
+/* create the streams for rollouts with up to n_cohorts cohorts; must not be called during graph capture */
+int coevo_rollout_ctx_reserve_cohorts(void *ctx, int n_cohorts);
 int coevo_rollout_ctx_reset_timing(void *ctx);
 int coevo_rollout_ctx_light_times(void *ctx, float *host_ms_out, int max_out);  /* returns the count; blocks */
 int coevo_mpe_rollout(const coevo_rollout_desc *desc, void *ctx, int time_light, void *stream);
@@ -164,6 +178,16 @@ int coevo_mpe_policy_cycle_fused(const float *slab, const coevo_fc_task *tasks, 
                                  const int32_t *row_slot, const int32_t *act_prev, int32_t *act_cur,
                                  const int32_t *game_limit, int cycle, int pos_first, int32_t *status, uint64_t *stamps,
                                  void *stream);
+/* one env-cycle of one cohort in ONE launch: workgroups [0, n_heavy) run the shared-opponent tasks on the matrix
+ * cores, the other n_light run the per-individual tasks (<= 8 rows each); same results as the two separate
+ * coevo_mpe_policy_cycle_fused launches (replaces the per-agent-step forward of utils/game_logic_functions.py:152-163
+ * for every row of the cohort at once) */
+int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_task *heavy_tasks, int n_heavy,
+                                  const coevo_fc_task *light_tasks, int n_light, int light_max_rows,
+                                  const double *state_prev, double *state_next, int n_games,
+                                  const int32_t *row_game, const int32_t *row_slot, const int32_t *act_prev,
+                                  int32_t *act_cur, const int32_t *game_limit, int cycle, int pos_first,
+                                  int32_t *status, uint64_t *stamps, void *stream);
 int coevo_mpe_final_step(const double *state, int n_games, const int32_t *actions_by_game, int cycle,
                          const int32_t *game_limit, int pos_first, double *rewards, void *stream);
 

@@ -139,3 +139,32 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         L.load()
     with pytest.raises(L.CoevoError):
         L.fc_param_count(10)
+
+
+def test_rollout_plan_cohorts_partition_games():
+    """cohorts never split a per-individual net's games, cover every game once, and cut the shared-opponent rows per
+    cohort; task lists are laid out cohort by cohort (coevo_rollout_desc.heavy_begin / light_begin)"""
+    from coevonet_amd.rollout import RolloutPlan
+    npop, nh = 30, 3
+    off = {i: i * 10 for i in range(npop + 2 * nh)}
+    D = {**{i: 10 for i in range(npop + nh)}, **{npop + nh + k: 8 for k in range(nh)}}
+    games = [(npop + nh + k, i, npop + k) for i in range(npop) for k in range(nh)]
+    for K in (1, 2, 3, 4):
+        plan = RolloutPlan(np.array(games), off, D, device=None, n_cohorts=K)
+        assert plan.n_cohorts == K
+        co = plan.game_cohort_np
+        for i in range(npop):                                   # an individual's games share a cohort
+            assert len({int(co[g]) for g in range(i * nh, (i + 1) * nh)}) == 1
+        assert sorted(np.bincount(co).tolist())[0] >= (npop // K) * nh
+        assert plan.heavy_begin_np[0] == 0 and plan.heavy_begin_np[-1] == len(plan.heavy_np)
+        assert plan.light_begin_np[0] == 0 and plan.light_begin_np[-1] == len(plan.light_np) == npop
+        for k in range(K):
+            for arr, begin in ((plan.heavy_np, plan.heavy_begin_np), (plan.light_np, plan.light_begin_np)):
+                for t in arr[begin[k]:begin[k + 1]]:
+                    rows = range(int(t["row_begin"]), int(t["row_begin"]) + int(t["n_rows"]))
+                    assert all(co[plan.row_game_np[r]] == k for r in rows)
+        assert sorted(plan.row_game_np.tolist()) == sorted(list(range(len(games))) * 3)
+    # one net shared by every game as a per-individual net would tie all games together: a single cohort remains
+    tied = RolloutPlan(np.array([(40, i, 41) for i in range(6)]), {**{i: i for i in range(6)}, 40: 100, 41: 200},
+                       {**{i: 10 for i in range(6)}, 40: 8, 41: 10}, device=None, n_cohorts=3)
+    assert tied.n_cohorts == 1

@@ -239,6 +239,38 @@ def test_device_rollout_matches_oracle_play_game(limit, max_cycles):
         assert list(r[g]) == want["rewards"], (g, r[g], want["rewards"])
 
 
+@pytest.mark.parametrize("mode", ["two_launches", "merged", "cohorts2", "cohorts3_eager"])
+def test_rollout_variants_match_oracle(mode):
+    """A GA-shaped batch (per-individual nets against shared opponents) through DeviceRollout: the two-launch cycle,
+    the merged one-launch cycle and the cohort chains all give the oracle's rewards bit for bit."""
+    from coevonet_amd.rollout import RolloutPlan, DeviceRollout
+    npop, nh, limit, max_cycles = 20, 2, 40, 25
+    nets10 = make_nets(npop + nh, 10, seed=91, mutate=False)      # individuals (agent_0) + opponents for agent_1
+    nets8 = make_nets(nh, 8, seed=92, mutate=False)               # opponent adversaries
+    s10, s8 = L.fc_slab_stride(10), L.fc_slab_stride(8)
+    slab = torch.cat([to_slab(nets10, 10).reshape(-1), to_slab(nets8, 8).reshape(-1)]).contiguous()
+    off = [i * s10 for i in range(npop + nh)] + [(npop + nh) * s10 + k * s8 for k in range(nh)]
+    D = [10] * (npop + nh) + [8] * nh
+    games = [(npop + nh + k, i, npop + k) for i in range(npop) for k in range(nh)]   # (adversary, agent_0, agent_1)
+    K = {"two_launches": 1, "merged": 1, "cohorts2": 2, "cohorts3_eager": 3}[mode]
+    plan = RolloutPlan(np.array(games), off, D, device=DEV, n_cohorts=K)
+    assert plan.n_cohorts == K and len(plan.heavy_np) > 0 and len(plan.light_np) == npop
+    ro = DeviceRollout(plan, slab, merged=(mode != "two_launches"))
+    ro.use_graph = mode != "cohorts3_eager"
+    T = min(limit, 3 * max_cycles)
+    ro.set_limits(np.full(plan.n_games, T))
+    first = 3
+    ro.reset(0, plan.n_games, first)
+    ro.run((T + 2) // 3)
+    torch.cuda.synchronize()
+    ro.check_status()
+    r = ro.rewards.cpu().numpy()
+    stream = rp.Stream()
+    for g, (adv, a0, a1) in enumerate(games):
+        want = rp.play_game(stream, nets10[a0], nets10[a1], nets8[adv - npop - nh], limit, max_cycles, ordinal=first + g)
+        assert list(r[g]) == want["rewards"], (mode, g, r[g], want["rewards"])
+
+
 # ----------------------------------------------------------------------------------- offspring
 @pytest.mark.parametrize("D,skip_ln", [(10, 0), (8, 1)])
 def test_perturb_bit_exact_vs_oracle(D, skip_ln):

@@ -1,0 +1,47 @@
+"""diagnostic (COEVO_PHASE_STAMPS build): begin/end of every workgroup of one merged cycle launch"""
+import ctypes as C, sys, os
+import numpy as np, torch
+sys.path.insert(0, ".")
+os.environ["COEVO_MERGED"] = "1"
+import bench
+from coevonet_amd import lib as L
+from coevonet_amd.game_logic import initialize_env
+from coevonet_amd.genetic_algorithm import GATrainer
+
+dll = L.load()
+torch.manual_seed(0); np.random.seed(0)
+args = bench.make_args(200, 5, 2, 200)
+args.coevo_cohorts = 1
+args.coevo_device_loop = False
+env = initialize_env(args)
+tr = GATrainer(env, args, rng="device_philox", env_mode="device", collect=False)
+eng, ro = tr.eng, tr.eng.ro
+tr.step()
+ro.use_graph = False
+for i in range(2):
+    ro.run(eng.n_cycles)
+torch.cuda.synchronize()
+nh, nl = len(eng.plan.heavy_np), len(eng.plan.light_np)
+n = nh + nl
+dll.coevo_debug_read_phase_stamps.argtypes = [C.c_void_p, C.c_int]
+buf = (C.c_ulonglong * (n * 8))()
+assert dll.coevo_debug_read_phase_stamps(buf, n * 8) == 0
+st = np.frombuffer(buf, dtype=np.uint64).reshape(n, 8).astype(np.int64)
+t0 = st[:, 0].min()
+b, e = (st[:, 0] - t0) / 100.0, (st[:, 6] - t0) / 100.0   # us (100 MHz ticks)
+def desc(name, idx):
+    print(f"{name:24s} n={len(idx):4d} begin {b[idx].min():7.1f}..{b[idx].max():7.1f}  end {e[idx].min():7.1f}..{e[idx].max():7.1f}  life {np.mean(e[idx]-b[idx]):6.1f} us")
+heavy = np.arange(nh); light = np.arange(nh, n)
+desc("heavy", heavy)
+first = light[b[light] < 5]; later = light[b[light] >= 5]
+desc("light, first round", first)
+desc("light, later", later)
+ph = np.diff(st[:, :7], axis=1) / 100.0
+for nm, idx in (("heavy", heavy), ("light first", first), ("light later", later)):
+    print(nm, "phases us:", np.round(ph[idx].mean(axis=0), 1))
+print("launch span us:", e.max())
+
+order = np.argsort(e)
+print("last 10 to finish:", [(int(i), "H" if i < nh else "L", round(float(b[i]), 1), round(float(e[i]), 1)) for i in order[-10:]])
+hist, edges = np.histogram(b[light], bins=12)
+print("light begin histogram (us):", list(zip(np.round(edges[:-1], 0).tolist(), hist.tolist())))

@@ -18,6 +18,20 @@ tr.step()
 ro, p = tr.eng.ro, tr.eng.plan
 dll = L.load()
 names = ["entry->obs staged", "fc1+LN1 (to h1 in LDS)", "fc2 stream", "LN2", "output chain", "argmax/store"]
+print("=== MFMA (shared-opponent) kernel, fused mode not used here: state-read variant")
+nh = len(p.heavy_np)
+for rep in range(3):
+    L.call("coevo_mpe_policy_cycle", L._p(ro.slab), L._p(p.heavy), nh, p.heavy_max, L._p(ro.state), p.n_games,
+           L._p(p.row_game), L._p(p.row_slot), L._p(ro.actions), L._p(ro.status))
+torch.cuda.synchronize()
+buf = (C.c_ulonglong * (nh * 8))()
+assert dll.coevo_debug_read_phase_stamps(buf, nh * 8) == 0
+st = np.frombuffer(buf, dtype=np.uint64).reshape(nh, 8).astype(np.int64)
+d = np.diff(st[:, :7], axis=1)
+for i, nm in enumerate(["entry->obs staged", "fc1 (MFMA) + LN1 + h1 image", "fc2 (MFMA) stream", "LN2", "output chain", "argmax/store"]):
+    print(f"  {nm:28s} {d[:, i].mean():9.0f}  (min {d[:, i].min():7d} max {d[:, i].max():7d})")
+print(f"  {'whole workgroup':28s} {(st[:, 6] - st[:, 0]).mean():9.0f}")
+print("=== streaming (per-individual) kernel")
 for n in (128, 256, 600):
     for rep in range(3):
         L.call("coevo_mpe_policy_cycle", L._p(ro.slab), L._p(p.light), n, p.light_max, L._p(ro.state), p.n_games,
