@@ -152,7 +152,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if timed and not a.no_graph:
-        tr.stamp_every = 4  # reading a generation's 25 launch durations back needs a host sync: every 4th generation
+        tr.stamp_every = 8  # reading a generation's launch durations back needs a host sync: every 8th generation
     for i in range(a.steps):
         tr.step()
     torch.cuda.synchronize()
@@ -192,6 +192,18 @@ def main():
                     rows += int(t["n_rows"])
             alg_bytes = (sum(nets.values()) + rows * (4 * 10 + 4)) / max(eng.ro.n_cohorts, 1)
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+            K = max(eng.ro.n_cohorts, 1)
+            aggregate = None
+            if getattr(eng.ro, "_span_ms", None):
+                # all policy launches of a rollout together: bytes of every launch / (first start .. last end); with one
+                # cohort this is the per-launch figure minus the inter-launch gaps, with K cohorts it accounts for the
+                # launches that run side by side
+                span_ms = float(np.mean(eng.ro._span_ms))
+                tot = alg_bytes * K * eng.ro._span_cycles
+                aggregate = {"achieved": tot / (span_ms * 1e-3) / 1e9, "frac": tot / (span_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "rollout_span_ms": span_ms, "launches": K * eng.ro._span_cycles,
+                             "note": "algorithmic bytes of every policy launch of one rollout / (first workgroup start "
+                                     ".. last workgroup end of the rollout)"}
             traffic, traffic_note = None, None
             pmc = os.path.join(REPO, "profiles", "r01_pmc_hbm_traffic.json")
             if a.pop_per_gpu == 200 and a.hof == 5 and os.path.exists(pmc):
@@ -214,7 +226,7 @@ def main():
                                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
-                               "launches_timed": len(d)}
+                               "launches_timed": len(d), "concurrent_launches": K, "rollout_aggregate": aggregate}
         if not a.no_cpu_baseline and ctx.world == 1:
             out["cpu_baseline"] = cpu_baseline(a.pop_per_gpu, a.hof, a.limit)
             try:

@@ -67,6 +67,16 @@ __device__ inline float dpp_move(float v)
 }
 
 // levels 1..16: every lane ends with the tree sum of its 32-lane half
+// the first four levels only: every lane returns the sum over its 16-lane row (DPP row operations, no cross-row step)
+__device__ inline float row16_tree_sum(float v)
+{
+    v = v + dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = v + dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = v + dpp_move<0x141>(v);  // row_half_mirror
+    v = v + dpp_move<0x140>(v);  // row_mirror
+    return v;
+}
+
 __device__ inline float half_tree_sum(float v)
 {
     v = v + dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]

@@ -7,17 +7,21 @@
 // HBM traffic per task is the weight set itself, read exactly once, fully coalesced:
 //   fc1  W1t[k][512]           each lane owns outputs t and t+256, wave reads 256 B rows (20 KB total)
 //   fc2  W2q[4][128][64][4]    wave w streams its 128 KiB block as 1 KiB wave-instructions (global_load_dwordx4),
-//                              8 in flight per lane; the R activations of each k-quad are LDS broadcast reads
+//                              8-16 in flight per lane; each 16-byte piece is 4 k of the lane's own output column and
+//                              feeds v_mfma_f32_4x4x1_16B_f32 directly (16 blocks x 4 columns = the wave's 64 columns,
+//                              4 rows, one k per instruction); the A operands of a row group are one ds_read_b128
 //   out  W3[5][256]            staged through LDS once
-// Arithmetic per weight byte is tiny (R FMAs per 4 bytes): the kernel is bound by HBM / Infinity-Cache
-// bandwidth, not by the VALU, so no MFMA here (per-individual weights make this a grouped GEMV).
+// Arithmetic per weight byte is tiny (R FMAs per 4 bytes), but as VALU FMAs fed by LDS broadcasts it still cost a lone
+// workgroup 27 us per net against ~5 us of HBM time (tools/stream_probe.hip): the matrix pipe, otherwise idle here,
+// does the same sequential-k fma chains (tools/mfma4_chain_probe.hip: bit-identical) in far fewer issue slots and LDS
+// reads.  (v_mfma_f32_16x16x4_f32, tools/mfma16_chain_probe.hip, is exact as well but spends 16 tile rows on <= 8.)
 // All fp32 math follows the canonical order in coevo_common.hip.h, so logits equal the oracle's bit for bit.
 #include "coevo_common.hip.h"
 
 namespace coevo {
 
 #ifndef COEVO_LIGHT_U
-#define COEVO_LIGHT_U 16
+#define COEVO_LIGHT_U 8   // 16-byte pieces per lane and buffer (two buffers in ping-pong)
 #endif
 
 // A per-individual weight set is read exactly once per launch by exactly one CU.  Non-temporal loads (which would
@@ -35,17 +39,21 @@ __device__ inline float4 load_stream16(const float4 *p)
 #endif
 }
 
-template <int R>
+template <int R, int P>
 struct FcSmem {
-    static constexpr int RP = R | 1;  // odd row pitch: conflict-free scatter of h1 into the k-quad image
+    static constexpr int NG = (R + 3) / 4;   // row groups of four = v_mfma_f32_4x4x1 issues per k
+    static constexpr int RP = 4 * NG + 1;    // odd row pitch: conflict-free scatter of h1 into the k-quad image
     union {
-        float h1q[128][RP][4];  // [k/4][row][k%4]: one ds_read_b128 hands a k-quad of one row to every lane
-        float h2[R][260];       // fc2 activations, row pitch 260 keeps 16-byte alignment, shifts banks by 4
+        // fc1 activations of ONE net at a time, [k/4][row][k%4]: one ds_read_b128 hands lane l the A operands
+        // x[4g + l%4][4q .. 4q+3] of row group g.  Rows >= R of the last group are never written: a tile row only
+        // feeds its own output row, and nothing reads those.
+        float h1q[128][RP][4];
+        float h2[P][R][260];  // fc2 activations, row pitch 260 keeps 16-byte alignment, shifts banks by 4
     };
-    float xs0[R][COEVO_OBS_STRIDE];
-    float w3s[NACT][260];
-    float red[R][8];
-    float logit[R][COEVO_LOGIT_STRIDE];
+    float xs0[P][R][COEVO_OBS_STRIDE];
+    float w3s[P][NACT][260];
+    float red[P][R][8];       // LayerNorm partials per (row, 64-feature block)
+    float logit[P][R][COEVO_LOGIT_STRIDE];
 };
 
 struct FcArgs {
@@ -70,7 +78,7 @@ struct FcArgs {
     // merged launch only (fc_cycle_kernel): workgroups [0, n_heavy) run `tasks` on the matrix cores, the rest run
     // `light_tasks[blockIdx.x - n_heavy]` through the streaming path
     const coevo_fc_task *light_tasks;
-    int n_heavy;
+    int n_heavy, n_light;
 };
 constexpr int MODE_OBS = 0, MODE_STATE = 1, MODE_FUSED = 2;
 
@@ -105,42 +113,63 @@ __device__ unsigned long long g_phase_stamps[4096 * 8];
 #define COEVO_STAMP(i) do { } while (0)
 #endif
 
-// (Register budget note: beside a resident MFMA workgroup, 248 registers allocated, a SIMD has 264 left, so a third
-// streaming wave would need <= 88 registers; capping this kernel at 80 spills 39 registers and is slower overall,
-// 290 vs 346 generations/s - measured, not pursued.)
-template <int R, int MODE>
-__device__ __forceinline__ void fc_policy_body(const FcArgs &a, FcSmem<R> &sm, const coevo_fc_task &task)
+// One workgroup carries P nets (tasks first .. first+P-1).  P = 1 is the plain kernel.  P = 2 is used by the merged
+// cycle launch when one net per workgroup would not fit the CUs in a single round: the entry chains (env step,
+// observation) and both LayerNorm(512) of the two nets share their latency, the two 512 KiB weight streams run back to
+// back, then both LayerNorm(256) / output layers share theirs.  Results do not depend on P.
+template <int R, int MODE, int P>
+__device__ __forceinline__ void fc_policy_body(const FcArgs &a, FcSmem<R, P> &sm, const coevo_fc_task *tasks, int first,
+                                               int n_tasks)
 {
+#ifdef COEVO_LIGHT_PRIO
+    __builtin_amdgcn_s_setprio(COEVO_LIGHT_PRIO);
+#endif
     COEVO_STAMP(0);
+    static_assert(P >= 1 && P <= 4 && R * NACT <= 64, "one wave per net in the per-row phases");
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
-    const int D = task.D, nrows = task.n_rows, row0 = task.row_begin;
-    const float *net = a.slab + task.net_off;
+    int D[P], nrows[P], row0[P];
+    const float *net[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const bool active = first + p < n_tasks;  // a missing net repeats the last one with no rows: nothing is written
+        const coevo_fc_task task = tasks[active ? first + p : n_tasks - 1];
+        D[p] = task.D; nrows[p] = active ? task.n_rows : 0; row0[p] = task.row_begin;
+        net[p] = a.slab + task.net_off;
+    }
     int st = 0;
 
     // ---- every small parameter this thread will need, requested up front: one HBM round trip instead of one
     //      per layer (they would otherwise be loaded at first use, behind a barrier, with nothing else in flight)
     constexpr int DMAX = 10;
-    float w1a[DMAX], w1b[DMAX];
+    float w1a[P][DMAX], w1b[P][DMAX];
+    float p_b1a[P], p_b1b[P], p_g1a[P], p_g1b[P], p_be1a[P], p_be1b[P];
+    float p_b2[P], p_g2[P], p_be2[P];  // fc2 column of this lane: t
 #pragma unroll
-    for (int k = 0; k < DMAX; ++k) {
-        w1a[k] = (k < D) ? net[(size_t)k * H1 + t] : 0.0f;
-        w1b[k] = (k < D) ? net[(size_t)k * H1 + 256 + t] : 0.0f;
+    for (int p = 0; p < P; ++p) {
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) {
+            w1a[p][k] = (k < D[p]) ? net[p][(size_t)k * H1 + t] : 0.0f;
+            w1b[p][k] = (k < D[p]) ? net[p][(size_t)k * H1 + 256 + t] : 0.0f;
+        }
+        const float *b1p = net[p] + fc_off_b1(D[p]), *b2p = net[p] + fc_off_b2(D[p]);
+        p_b1a[p] = b1p[t]; p_b1b[p] = b1p[t + 256];
+        p_g1a[p] = b1p[H1 + t]; p_g1b[p] = b1p[H1 + t + 256];
+        p_be1a[p] = b1p[2 * H1 + t]; p_be1b[p] = b1p[2 * H1 + t + 256];
+        p_b2[p] = b2p[t]; p_g2[p] = b2p[H2 + t]; p_be2[p] = b2p[2 * H2 + t];
     }
-    const float *b1p = net + fc_off_b1(D), *b2p = net + fc_off_b2(D);
-    const float p_b1a = b1p[t], p_b1b = b1p[t + 256];
-    const float p_g1a = b1p[H1 + t], p_g1b = b1p[H1 + t + 256];
-    const float p_be1a = b1p[2 * H1 + t], p_be1b = b1p[2 * H1 + t + 256];
-    const float p_b2 = b2p[t], p_g2 = b2p[H2 + t], p_be2 = b2p[2 * H2 + t];
-    const float p_b3 = (t < R * NACT) ? net[fc_off_b3(D) + t % NACT] : 0.0f;
+    // per-row phases (env step + observation, output layer, argmax): wave p serves net p, lane = row or (row, action)
+    const int pw = (w < P) ? w : 0;  // wave-uniform
+    const bool row_wave = w < P;
+    const float p_b3 = (row_wave && l < R * NACT) ? net[pw][fc_off_b3(D[pw]) + l % NACT] : 0.0f;
 
     // ---- stage observations (zero padded) and the output layer -------------------------------------------
     if constexpr (MODE == MODE_FUSED) {
-        if (t < R) {  // one lane per row: advance its game in registers, observe, (owner row) publish the new state
+        if (row_wave && l < R) {  // one lane per row: advance its game in registers, observe, (owner row) publish
             float o[COEVO_OBS_STRIDE];
 #pragma unroll
             for (int k = 0; k < COEVO_OBS_STRIDE; ++k) o[k] = 0.0f;
-            if (t < nrows) {
-                const int row = row0 + t;
+            if (l < nrows[pw]) {
+                const int row = row0[pw] + l;
                 mpe_fused_observe(a.state, a.state_next, a.act_prev, a.game_limit, a.n_games, a.row_game[row],
                                   a.row_slot[row], a.cycle, a.pos_first, o);
 #pragma unroll
@@ -148,161 +177,211 @@ __device__ __forceinline__ void fc_policy_body(const FcArgs &a, FcSmem<R> &sm, c
                     if (!__builtin_isfinite(o[k])) st |= COEVO_ST_BAD_INPUT;
             }
 #pragma unroll
-            for (int k = 0; k < COEVO_OBS_STRIDE; ++k) sm.xs0[t][k] = o[k];
+            for (int k = 0; k < COEVO_OBS_STRIDE; ++k) sm.xs0[pw][l][k] = o[k];
         }
     } else {
-        for (int i = t; i < R * COEVO_OBS_STRIDE; i += 256) {
-            const int r = i / COEVO_OBS_STRIDE, k = i % COEVO_OBS_STRIDE;
-            float v = 0.0f;
-            if (r < nrows && k < D) {
-                if constexpr (MODE == MODE_STATE) {
-                    const int row = row0 + r;
-                    v = mpe_obs_element(a.state, a.n_games, a.row_game[row], a.row_slot[row], k);
-                } else {
-                    v = a.obs[(size_t)(row0 + r) * COEVO_OBS_STRIDE + k];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            for (int i = t; i < R * COEVO_OBS_STRIDE; i += 256) {
+                const int r = i / COEVO_OBS_STRIDE, k = i % COEVO_OBS_STRIDE;
+                float v = 0.0f;
+                if (r < nrows[p] && k < D[p]) {
+                    if constexpr (MODE == MODE_STATE) {
+                        const int row = row0[p] + r;
+                        v = mpe_obs_element(a.state, a.n_games, a.row_game[row], a.row_slot[row], k);
+                    } else {
+                        v = a.obs[(size_t)(row0[p] + r) * COEVO_OBS_STRIDE + k];
+                    }
+                    if (!__builtin_isfinite(v)) st |= COEVO_ST_BAD_INPUT;
                 }
-                if (!__builtin_isfinite(v)) st |= COEVO_ST_BAD_INPUT;
+                sm.xs0[p][r][k] = v;
             }
-            sm.xs0[r][k] = v;
         }
     }
-    {
-        const float *W3 = net + fc_off_w3(D);
-        for (int i = t; i < NACT * H2; i += 256) sm.w3s[i >> 8][i & 255] = W3[i];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const float *W3 = net[p] + fc_off_w3(D[p]);
+        for (int i = t; i < NACT * H2; i += 256) sm.w3s[p][i >> 8][i & 255] = W3[i];
     }
     __syncthreads();
     COEVO_STAMP(1);
 
     // ---- fc1: outputs j0 = t, j1 = t + 256; sequential-k chains from the bias -----------------------------
-    float a0[R], a1[R];
-    {
+    float a0[P][R], a1[P][R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) { a0[r] = p_b1a; a1[r] = p_b1b; }
+    for (int p = 0; p < P; ++p) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { a0[p][r] = p_b1a[p]; a1[p][r] = p_b1b[p]; }
 #pragma unroll
         for (int k = 0; k < DMAX; ++k) {
-            if (k < D) {  // wave-uniform
+            if (k < D[p]) {  // wave-uniform
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const float x = sm.xs0[r][k];
-                    a0[r] = __builtin_fmaf(w1a[k], x, a0[r]);
-                    a1[r] = __builtin_fmaf(w1b[k], x, a1[r]);
+                    const float x = sm.xs0[p][r][k];
+                    a0[p][r] = __builtin_fmaf(w1a[p][k], x, a0[p][r]);
+                    a1[p][r] = __builtin_fmaf(w1b[p][k], x, a1[p][r]);
                 }
             }
         }
     }
     // ---- LayerNorm(512) + ReLU: block b of the canonical reduce is wave (b & 3), half (b >> 2) -------------
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const float s0 = wave_tree_sum(a0[r]), s1 = wave_tree_sum(a1[r]);
-        if (l == 0) { sm.red[r][w] = s0; sm.red[r][4 + w] = s1; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        float tot = sm.red[r][0];
-#pragma unroll
-        for (int b = 1; b < 8; ++b) tot = tot + sm.red[r][b];
-        const float mean = tot * (1.0f / H1);
-        a0[r] = a0[r] - mean;
-        a1[r] = a1[r] - mean;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const float s0 = wave_tree_sum(a0[r] * a0[r]), s1 = wave_tree_sum(a1[r] * a1[r]);
-        if (l == 0) { sm.red[r][w] = s0; sm.red[r][4 + w] = s1; }
-    }
-    __syncthreads();
-    {
-        const float ga0 = p_g1a, ga1 = p_g1b, bt0 = p_be1a, bt1 = p_be1b;
+    for (int p = 0; p < P; ++p)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            float tot = sm.red[r][0];
+            const float s0 = wave_tree_sum(a0[p][r]), s1 = wave_tree_sum(a1[p][r]);
+            if (l == 0) { sm.red[p][r][w] = s0; sm.red[p][r][4 + w] = s1; }
+        }
+    __syncthreads();
 #pragma unroll
-            for (int b = 1; b < 8; ++b) tot = tot + sm.red[r][b];
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float tot = sm.red[p][r][0];
+#pragma unroll
+            for (int b = 1; b < 8; ++b) tot = tot + sm.red[p][r][b];
+            const float mean = tot * (1.0f / H1);
+            a0[p][r] = a0[p][r] - mean;
+            a1[p][r] = a1[p][r] - mean;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float s0 = wave_tree_sum(a0[p][r] * a0[p][r]), s1 = wave_tree_sum(a1[p][r] * a1[p][r]);
+            if (l == 0) { sm.red[p][r][w] = s0; sm.red[p][r][4 + w] = s1; }
+        }
+    __syncthreads();
+    // the normalised activations stay in registers (a0 / a1) until their net's turn at the single A-operand image
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float tot = sm.red[p][r][0];
+#pragma unroll
+            for (int b = 1; b < 8; ++b) tot = tot + sm.red[p][r][b];
             const float var = tot * (1.0f / H1);
             const float rstd = 1.0f / __builtin_sqrtf(var + LN_EPS);
-            const float y0 = __builtin_fmaf(a0[r] * rstd, ga0, bt0);
-            const float y1 = __builtin_fmaf(a1[r] * rstd, ga1, bt1);
-            if (r < nrows && (bad_post_relu(y0) || bad_post_relu(y1))) st |= COEVO_ST_BAD_FC1;
-            sm.h1q[t >> 2][r][t & 3] = relu_keep_nan(y0);
-            sm.h1q[(t + 256) >> 2][r][t & 3] = relu_keep_nan(y1);
+            const float y0 = __builtin_fmaf(a0[p][r] * rstd, p_g1a[p], p_be1a[p]);
+            const float y1 = __builtin_fmaf(a1[p][r] * rstd, p_g1b[p], p_be1b[p]);
+            if (r < nrows[p] && (bad_post_relu(y0) || bad_post_relu(y1))) st |= COEVO_ST_BAD_FC1;
+            a0[p][r] = relu_keep_nan(y0);
+            a1[p][r] = relu_keep_nan(y1);
         }
-    }
-    __syncthreads();
     COEVO_STAMP(2);
 
-    // ---- fc2: lane owns output 64w + l; 128 k-quads streamed as 16-byte pieces, 8 loads in flight ----------
-    float acc[R];
-    {
+    // ---- fc2 on the matrix cores: lane owns output column 64w + l; its streamed 16-byte piece is W2[64w + l][4q..4q+3],
+    //      used as is as the B operand of four v_mfma_f32_4x4x1_16B_f32 per row group ------------------------------
+    typedef float f32x4_acc __attribute__((ext_vector_type(4)));
+    constexpr int NG = FcSmem<R, P>::NG;
+    f32x4_acc acc[P][NG];  // acc[p][g][i]: row 4g + i of net p, column 64w + l
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = p_b2;
-        const float4 *wp = reinterpret_cast<const float4 *>(net + fc_off_w2(D)) + (size_t)w * 128 * 64 + l;
-        // U 16-byte loads per lane (U KiB per wave) are issued back to back, then consumed; a task therefore exposes
-        // 128/U memory latencies, hidden by the other workgroups resident on the CU.  (Deeper software pipelining was
-        // tried three ways - C++ double buffer, ping-pong buffers with sched_barrier, inline-asm loads with counted
-        // vmcnt - and hipcc either sinks the prefetch below its consumer or spills hundreds of registers.)
-        // (Also measured: activations in SGPRs instead of LDS broadcasts - h1 through a global scratch and s_load,
-        // v_pk_fma_f32 with an SGPR-pair operand.  Bit-exact, 22.7 vs 27 us for a lone workgroup's stream, but the 16 KiB
-        // scalar cache thrashes with several workgroups per CU: 326 vs 347 generations/s in situ.  Not shipped.)
-        constexpr int U = COEVO_LIGHT_U;
-        for (int kq = 0; kq < 128; kq += U) {
-            float4 wv[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) wv[u] = load_stream16(wp + (size_t)(kq + u) * 64);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const float4 x = *reinterpret_cast<const float4 *>(&sm.h1q[kq + u][r][0]);
-                    acc[r] = __builtin_fmaf(wv[u].x, x.x, acc[r]);
-                    acc[r] = __builtin_fmaf(wv[u].y, x.y, acc[r]);
-                    acc[r] = __builtin_fmaf(wv[u].z, x.z, acc[r]);
-                    acc[r] = __builtin_fmaf(wv[u].w, x.w, acc[r]);
-                }
-            }
-        }
-    }
-    COEVO_STAMP(3);
-    // ---- LayerNorm(256) + ReLU: block b = wave b ------------------------------------------------------------
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const float s = wave_tree_sum(acc[r]);
-        if (l == 0) sm.red[r][w] = s;
-    }
-    __syncthreads();  // also: every wave is done reading h1q, h2 may overwrite it below
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const float tot = ((sm.red[r][0] + sm.red[r][1]) + sm.red[r][2]) + sm.red[r][3];
-        acc[r] = acc[r] - tot * (1.0f / H2);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const float s = wave_tree_sum(acc[r] * acc[r]);
-        if (l == 0) sm.red[r][w] = s;
-    }
-    __syncthreads();
-    {
-        const float ga = p_g2, bt = p_be2;
+    for (int p = 0; p < P; ++p) {
+        if (p > 0) __syncthreads();  // every wave is done with the previous net's image
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const float tot = ((sm.red[r][0] + sm.red[r][1]) + sm.red[r][2]) + sm.red[r][3];
-            const float rstd = 1.0f / __builtin_sqrtf(tot * (1.0f / H2) + LN_EPS);
-            const float y = __builtin_fmaf(acc[r] * rstd, ga, bt);
-            if (r < nrows && bad_post_relu(y)) st |= COEVO_ST_BAD_FC2;
-            sm.h2[r][t] = relu_keep_nan(y);
+            sm.h1q[t >> 2][r][t & 3] = a0[p][r];
+            sm.h1q[(t + 256) >> 2][r][t & 3] = a1[p][r];
         }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[p][g][i] = p_b2[p];
+        const float4 *wp = reinterpret_cast<const float4 *>(net[p] + fc_off_w2(D[p])) + (size_t)w * 128 * 64 + l;
+        // Two register buffers of U pieces in ping-pong, the order pinned with sched_barrier: while one buffer's U
+        // pieces feed the matrix pipe the other buffer's U loads are in flight.  (Left alone, the scheduler interleaves
+        // loads and MFMAs pairwise with s_waitcnt vmcnt(1) in between - two loads in flight per lane, 28 us per net.
+        // Earlier VALU versions of this loop: C++ double buffers were sunk below their consumers, inline-asm loads
+        // spilled; with the activations in SGPRs through a global scratch and s_load a lone workgroup ran 22.7 instead
+        // of 27 us but the 16 KiB scalar cache thrashed with several workgroups per CU.)
+        constexpr int U = COEVO_LIGHT_U;
+        static_assert(128 % (2 * U) == 0, "the k-quads are consumed in pairs of buffers");
+        float4 bufA[U], bufB[U];
+        auto issue = [&](float4 (&buf)[U], int kq) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) buf[u] = load_stream16(wp + (size_t)(kq + u) * 64);
+        };
+        auto consume = [&](const float4 (&buf)[U], int kq) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float4 x[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) x[g] = *reinterpret_cast<const float4 *>(&sm.h1q[kq + u][4 * g + (l & 3)][0]);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[p][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].x, buf[u].x, acc[p][g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[p][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].y, buf[u].y, acc[p][g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[p][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].z, buf[u].z, acc[p][g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[p][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].w, buf[u].w, acc[p][g], 0, 0, 0);
+            }
+        };
+        issue(bufA, 0);
+        int kq = 0;
+        for (; kq < 128 - 2 * U; kq += 2 * U) {
+            issue(bufB, kq + U);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(bufA, kq);
+            issue(bufA, kq + 2 * U);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(bufB, kq + U);
+        }
+        issue(bufB, kq + U);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(bufA, kq);
+        consume(bufB, kq + U);
     }
+    COEVO_STAMP(3);
+    // ---- LayerNorm(256) + ReLU: canonical block b = wave b ------------------------------------------------------
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float s = wave_tree_sum(acc[p][r >> 2][r & 3]);
+            if (l == 0) sm.red[p][r][w] = s;
+        }
+    __syncthreads();  // also: every wave is done reading h1q, h2 may overwrite it below
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float *rr = sm.red[p][r];
+            const float tot = ((rr[0] + rr[1]) + rr[2]) + rr[3];
+            acc[p][r >> 2][r & 3] = acc[p][r >> 2][r & 3] - tot * (1.0f / H2);
+        }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float d = acc[p][r >> 2][r & 3];
+            const float s = wave_tree_sum(d * d);
+            if (l == 0) sm.red[p][r][w] = s;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float *rr = sm.red[p][r];
+            const float tot = ((rr[0] + rr[1]) + rr[2]) + rr[3];
+            const float rstd = 1.0f / __builtin_sqrtf(tot * (1.0f / H2) + LN_EPS);
+            const float y = __builtin_fmaf(acc[p][r >> 2][r & 3] * rstd, p_g2[p], p_be2[p]);
+            if (r < nrows[p] && bad_post_relu(y)) st |= COEVO_ST_BAD_FC2;
+            sm.h2[p][r][t] = relu_keep_nan(y);
+        }
     __syncthreads();
     COEVO_STAMP(4);
 
     // ---- output layer: one lane per (row, action), 256-long sequential chain out of LDS --------------------
-    if (t < R * NACT) {
-        const int r = t / NACT, o = t % NACT;
+    if (row_wave && l < R * NACT) {
+        const int r = l / NACT, o = l % NACT;
         float y = p_b3;
-        const float4 *wr = reinterpret_cast<const float4 *>(&sm.w3s[o][0]);
-        const float4 *xr = reinterpret_cast<const float4 *>(&sm.h2[r][0]);
+        const float4 *wr = reinterpret_cast<const float4 *>(&sm.w3s[pw][o][0]);
+        const float4 *xr = reinterpret_cast<const float4 *>(&sm.h2[pw][r][0]);
 #pragma unroll 8
         for (int k = 0; k < H2 / 4; ++k) {
             const float4 wv = wr[k], xv = xr[k];
@@ -311,31 +390,31 @@ __device__ __forceinline__ void fc_policy_body(const FcArgs &a, FcSmem<R> &sm, c
             y = __builtin_fmaf(wv.z, xv.z, y);
             y = __builtin_fmaf(wv.w, xv.w, y);
         }
-        sm.logit[r][o] = y;
+        sm.logit[pw][r][o] = y;
     }
     __syncthreads();
     COEVO_STAMP(5);
 
     // ---- first-max action (strict '>' scan from -inf), status --------------------------------------------
-    if (t < nrows) {
+    if (row_wave && l < nrows[pw]) {
         int best = -1;
         float cur = -__builtin_inff();
 #pragma unroll
         for (int o = 0; o < NACT; ++o) {
-            const float v = sm.logit[t][o];
+            const float v = sm.logit[pw][l][o];
             if (!__builtin_isfinite(v)) st |= COEVO_ST_BAD_OUT;
             if (v > cur) { cur = v; best = o; }
         }
         if (best < 0) { st |= COEVO_ST_NO_ACTION; best = 0; }
+        const int row = row0[pw] + l;
         if constexpr (MODE == MODE_FUSED) {
-            const int row = row0 + t;
             a.act_cur[3 * a.row_game[row] + a.row_slot[row]] = best;  // by (game, slot): next cycle's step reads it
         } else {
-            a.actions[row0 + t] = best;
+            a.actions[row] = best;
         }
         if (a.logits) {
 #pragma unroll
-            for (int o = 0; o < NACT; ++o) a.logits[(size_t)(row0 + t) * COEVO_LOGIT_STRIDE + o] = sm.logit[t][o];
+            for (int o = 0; o < NACT; ++o) a.logits[(size_t)row * COEVO_LOGIT_STRIDE + o] = sm.logit[pw][l][o];
         }
     }
     if (st) atomicOr(a.status, st);
@@ -345,9 +424,9 @@ __device__ __forceinline__ void fc_policy_body(const FcArgs &a, FcSmem<R> &sm, c
 template <int R, int MODE>
 __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
 {
-    __shared__ FcSmem<R> sm;
+    __shared__ FcSmem<R, 1> sm;
     stamp_begin(a.stamps);
-    fc_policy_body<R, MODE>(a, sm, a.tasks[blockIdx.x]);
+    fc_policy_body<R, MODE, 1>(a, sm, a.tasks, blockIdx.x, gridDim.x);
     stamp_end(a.stamps);
 }
 
@@ -383,7 +462,10 @@ __device__ __forceinline__ void fc_policy_mfma_body(const FcArgs &a, FcMfmaSmem 
 {
     // these workgroups are the long pole of a cycle when they share CUs with the streaming kernel's waves: let their
     // (few) waves win issue arbitration; the streaming waves are waiting on HBM most of the time anyway
-    __builtin_amdgcn_s_setprio(3);
+#ifndef COEVO_HEAVY_PRIO
+#define COEVO_HEAVY_PRIO 3
+#endif
+    __builtin_amdgcn_s_setprio(COEVO_HEAVY_PRIO);
     COEVO_STAMP(0);
     const int t = threadIdx.x, w = t >> 6, l = t & 63, lc = l & 31, lh = l >> 5;
     const int D = task.D, nrows = task.n_rows, row0 = task.row_begin;
@@ -664,18 +746,18 @@ __global__ __launch_bounds__(256, 2) void fc_policy_mfma_kernel(FcArgs a)
 // workgroup get the MFMA path's footprint (<= 256 registers, ~73 KiB LDS: two workgroups per CU), so a launch of a
 // few hundred workgroups occupies the CUs in waves - together with a second cohort's launch on another stream the
 // CUs' weight streams run out of phase and HBM stays busy through the non-streaming phases of any one workgroup.
-template <int R>
+template <int R, int P>
 __global__ __launch_bounds__(256, 2) void fc_cycle_kernel(FcArgs a)
 {
     __shared__ union CycleSmem {
         FcMfmaSmem heavy;
-        FcSmem<R> light;
+        FcSmem<R, P> light;
     } sm;
     stamp_begin(a.stamps);
     if ((int)blockIdx.x < a.n_heavy)  // workgroup-uniform
         fc_policy_mfma_body<MODE_FUSED>(a, sm.heavy, a.tasks[blockIdx.x]);
     else
-        fc_policy_body<R, MODE_FUSED>(a, sm.light, a.light_tasks[blockIdx.x - a.n_heavy]);
+        fc_policy_body<R, MODE_FUSED, P>(a, sm.light, a.light_tasks, P * ((int)blockIdx.x - a.n_heavy), a.n_light);
     stamp_end(a.stamps);
 }
 
@@ -714,7 +796,7 @@ extern "C" int coevo_fc_forward_argmax(const float *slab, const coevo_fc_task *t
     if (!slab || !tasks || !obs || !actions || !status || n_tasks < 0) return COEVO_ERR_ARG;
     if (max_rows_per_task < 1 || max_rows_per_task > COEVO_FC_MAX_ROWS) return COEVO_ERR_ARG;
     coevo::FcArgs a{slab, tasks, obs, nullptr, nullptr, nullptr, 0, actions, logits, status, nullptr,
-                    nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0};
+                    nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0};
     return coevo::launch_fc<coevo::MODE_OBS>(a, n_tasks, max_rows_per_task, (hipStream_t)stream);
 }
 
@@ -741,7 +823,7 @@ extern "C" int coevo_mpe_policy_cycle_stamped(const float *slab, const coevo_fc_
     if (n_tasks < 0 || n_games <= 0) return COEVO_ERR_ARG;
     if (max_rows_per_task < 1 || max_rows_per_task > COEVO_FC_MAX_ROWS) return COEVO_ERR_ARG;
     coevo::FcArgs a{slab, tasks, nullptr, state, row_game, row_slot, n_games, actions, nullptr, status,
-                    reinterpret_cast<unsigned long long *>(stamps), nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0};
+                    reinterpret_cast<unsigned long long *>(stamps), nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, 0, 0};
     return coevo::launch_fc<coevo::MODE_STATE>(a, n_tasks, max_rows_per_task, (hipStream_t)stream);
 }
 
@@ -758,7 +840,7 @@ extern "C" int coevo_mpe_policy_cycle_fused(const float *slab, const coevo_fc_ta
     if (max_rows_per_task < 1 || max_rows_per_task > COEVO_FC_MAX_ROWS) return COEVO_ERR_ARG;
     coevo::FcArgs a{slab, tasks, nullptr, state_prev, row_game, row_slot, n_games, nullptr, nullptr, status,
                     reinterpret_cast<unsigned long long *>(stamps), state_next, act_prev, act_cur, game_limit, cycle,
-                    pos_first, nullptr, 0};
+                    pos_first, nullptr, 0, 0};
     return coevo::launch_fc<coevo::MODE_FUSED>(a, n_tasks, max_rows_per_task, (hipStream_t)stream);
 }
 
@@ -767,7 +849,8 @@ extern "C" int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_t
                                              const double *state_prev, double *state_next, int n_games,
                                              const int32_t *row_game, const int32_t *row_slot, const int32_t *act_prev,
                                              int32_t *act_cur, const int32_t *game_limit, int cycle, int pos_first,
-                                             int32_t *status, uint64_t *stamps, void *stream)
+                                             int32_t *status, uint64_t *stamps, int concurrent_launches,
+                                             void *stream)
 {
     if (!slab || !heavy_tasks || !light_tasks || !state_prev || !state_next || !row_game || !row_slot || !act_prev ||
         !act_cur || !status)
@@ -777,13 +860,31 @@ extern "C" int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_t
     if (light_max_rows < 1 || light_max_rows > 8) return COEVO_ERR_ARG;
     coevo::FcArgs a{slab, heavy_tasks, nullptr, state_prev, row_game, row_slot, n_games, nullptr, nullptr, status,
                     reinterpret_cast<unsigned long long *>(stamps), state_next, act_prev, act_cur, game_limit, cycle,
-                    pos_first, light_tasks, n_heavy};
-    const dim3 grid(n_heavy + n_light), block(256);
+                    pos_first, light_tasks, n_heavy, n_light};
+    // Workgroup slots of this kernel: two per CU (<= 256 registers, ~73 KiB LDS).  If one net per streaming workgroup
+    // does not fit them in a single round, pair the nets: the second round would otherwise wait for the slots of
+    // the (long) shared-opponent workgroups.
+    static int slots = 0;
+    if (slots == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            return COEVO_ERR_HIP;
+        slots = 2 * cus;
+    }
+    const bool pair = (n_heavy + n_light) * (concurrent_launches > 1 ? concurrent_launches : 1) > slots;
+    const dim3 grid(n_heavy + (pair ? (n_light + 1) / 2 : n_light)), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (light_max_rows <= 1) hipLaunchKernelGGL((coevo::fc_cycle_kernel<1>), grid, block, 0, s, a);
-    else if (light_max_rows <= 2) hipLaunchKernelGGL((coevo::fc_cycle_kernel<2>), grid, block, 0, s, a);
-    else if (light_max_rows <= 5) hipLaunchKernelGGL((coevo::fc_cycle_kernel<5>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((coevo::fc_cycle_kernel<8>), grid, block, 0, s, a);
+#define COEVO_LAUNCH_CYCLE(RR)                                                                    \
+    do {                                                                                          \
+        if (pair) hipLaunchKernelGGL((coevo::fc_cycle_kernel<RR, 2>), grid, block, 0, s, a);      \
+        else hipLaunchKernelGGL((coevo::fc_cycle_kernel<RR, 1>), grid, block, 0, s, a);           \
+    } while (0)
+    if (light_max_rows <= 1) COEVO_LAUNCH_CYCLE(1);
+    else if (light_max_rows <= 2) COEVO_LAUNCH_CYCLE(2);
+    else if (light_max_rows <= 5) COEVO_LAUNCH_CYCLE(5);
+    else COEVO_LAUNCH_CYCLE(8);
+#undef COEVO_LAUNCH_CYCLE
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

@@ -63,7 +63,8 @@ def adapt_mutation_power(args, gen, hist):
         args.mutation_power_adversary = max(args.mutation_power_adversary * 0.95, args.min_mutation_power)
 
 
-DEFAULT_COHORTS = 1   # independent game cohorts per rollout (rollout.RolloutPlan._assign_cohorts); see DESIGN.md
+DEFAULT_COHORTS = 1       # independent game cohorts per rollout (rollout.RolloutPlan._assign_cohorts); see DESIGN.md
+DEVICE_LOOP_COHORTS = 2   # ... in the host-free loop, where their launches are enqueued eagerly and do overlap
 
 
 class GAEngine:
@@ -341,6 +342,11 @@ class GAEngine:
         """reset -> 25 cycles -> rewards -> sharing/fitness/rank -> evaluation means + adaptive sigma -> HoF push and
         offspring -> generation counter tick; every launch takes the generation from the device counter, so the
         captured graph is replayed unchanged generation after generation"""
+        self._enqueue_resets()
+        self.ro.enqueue(self.n_cycles)
+        self._enqueue_selection_and_breeding()
+
+    def _enqueue_resets(self):
         assert self.world == 1 and self.env_mode == "device"
         ro, M = self.ro, 3 * self.pop * self.hof
         per_gen, per_phase = M + N_EVAL, self.pop * self.hof
@@ -350,7 +356,11 @@ class GAEngine:
                    self.first_ordinal + ph * per_phase, g, per_gen)
         L.call("coevo_mpe_reset_gen", L._p(ro.state), self.plan.n_games, self.n_main, N_EVAL, ro.rng,
                self.first_ordinal - per_gen + M, g, per_gen)
-        ro.enqueue(self.n_cycles)
+
+    def _enqueue_selection_and_breeding(self):
+        ro, M = self.ro, 3 * self.pop * self.hof
+        per_gen, per_phase = M + N_EVAL, self.pop * self.hof
+        g = L._p(self.gen_dev)
         for ph, r in enumerate(ROLES):
             D = ROLE_D[r]
             L.call("coevo_sharing_score", L._p(self.dist[r]), self.pop, L._p(self.div[r]))
@@ -381,7 +391,23 @@ class GAEngine:
             if gen == 1:
                 limits[self.n_main:] = self.T_eval
             self.ro.set_limits(limits)
-        if self.ro.use_graph:
+        if self.ro.use_graph and self.ro.n_cohorts > 1:
+            # cohort chains only run side by side when their launches are enqueued eagerly on their own streams (inside a
+            # captured graph this runtime schedules them no better than one chain): the resets and the selection /
+            # breeding tail are two small graphs, the rollout between them is one C call
+            if self._gen_graph is None:
+                torch.cuda.synchronize()
+                parts = []
+                for fn in (self._enqueue_resets, self._enqueue_selection_and_breeding):
+                    gr = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gr):
+                        fn()
+                    parts.append(gr)
+                self._gen_graph = parts
+            self._gen_graph[0].replay()
+            self.ro.enqueue(self.n_cycles)
+            self._gen_graph[1].replay()
+        elif self.ro.use_graph:
             key = bool(self.ro.time_light)
             if self._gen_graph is None:
                 self._gen_graph = {}
@@ -441,20 +467,24 @@ class GATrainer:
         shard, gather = (0, 1), None
         if dist_ctx is not None and dist_ctx.world > 1:
             shard, gather = (dist_ctx.rank, dist_ctx.world), dist_ctx.gather_ga
+        # the host-free generation loop needs device-built offspring, the device env and a single rank
+        self.device_loop = (self.rng == "device_philox" and env_mode == "device" and shard == (0, 1)
+                            and getattr(args, "coevo_device_loop", True))
+        # cohort chains overlap only when enqueued eagerly (GAEngine.replay_generation): worth it in the host-free loop
+        cohorts = getattr(args, "coevo_cohorts", None)
+        if cohorts is None:
+            cohorts = DEVICE_LOOP_COHORTS if self.device_loop else DEFAULT_COHORTS
         self.eng = GAEngine(args.population, args.hof_size, args.elites_number, args.max_timesteps_per_episode,
                             args.max_evaluation_steps, max_cycles=getattr(env, "max_cycles", 25), rng=self.rng,
                             philox_seed=getattr(args, "coevo_seed", 0), env=env_mode,
                             first_ordinal=self.first_ordinal,
                             env_seed=getattr(env, "seed_value", ENV_SEED) or ENV_SEED, shard=shard, gather=gather,
-                            cohorts=int(getattr(args, "coevo_cohorts", DEFAULT_COHORTS)))
+                            cohorts=int(cohorts))
         self.eng.load_initial(pop_flat, hof_flat)
         self.res = GAResult()
         self.res.engine = self.eng
         self.gen = 0
         self.stamp_every = 1
-        # the host-free generation loop needs device-built offspring, the device env and a single rank
-        self.device_loop = (self.rng == "device_philox" and env_mode == "device" and shard == (0, 1)
-                            and getattr(args, "coevo_device_loop", True))
         if self.device_loop:
             self.eng.setup_device_loop(args, capacity=max(getattr(args, "generations", 0), 1) + 64)
 

@@ -182,6 +182,7 @@ class DeviceRollout:
         self.use_graph = True
         self._graphs = {}
         self._timed_ms = []
+        self._span_ms, self._span_cycles = [], 0
         self.ctx = L.load().coevo_rollout_ctx_create(int(timing_pairs))
         if not self.ctx:
             raise L.CoevoError("coevo_rollout_ctx_create failed")
@@ -268,6 +269,9 @@ class DeviceRollout:
             st = self.stamps[:n * self.n_cohorts].cpu().numpy()  # [cohort * n + cycle][slots][2]
             dur = st[:, :, 1].max(axis=1) - st[:, :, 0].min(axis=1)  # first workgroup start .. last workgroup end
             self._timed_ms.extend((dur * 1e-5).tolist())  # 100 MHz ticks -> ms
+            # first start .. last end over every policy launch of this rollout (cohorts overlap; gaps included)
+            self._span_ms.append(float(st[:, :, 1].max() - st[:, :, 0].min()) * 1e-5)
+            self._span_cycles = n
             self._pending_stamps = 0
 
     def _read_light_times(self, max_out=100000):
@@ -288,6 +292,7 @@ class DeviceRollout:
     def reset_timing(self):
         L.load().coevo_rollout_ctx_reset_timing(self.ctx)
         self._timed_ms = []
+        self._span_ms = []
 
     def check_status(self):
         L.raise_on_status(self.status)

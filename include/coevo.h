@@ -181,13 +181,15 @@ int coevo_mpe_policy_cycle_fused(const float *slab, const coevo_fc_task *tasks, 
 /* one env-cycle of one cohort in ONE launch: workgroups [0, n_heavy) run the shared-opponent tasks on the matrix
  * cores, the other n_light run the per-individual tasks (<= 8 rows each); same results as the two separate
  * coevo_mpe_policy_cycle_fused launches (replaces the per-agent-step forward of utils/game_logic_functions.py:152-163
- * for every row of the cohort at once) */
+ * for every row of the cohort at once).  The kernel holds two workgroups per CU; when the workgroups of
+ * `concurrent_launches` such launches (cohorts running side by side, else 1) exceed those slots, a streaming workgroup
+ * carries two nets so that everything is resident in one round. */
 int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_task *heavy_tasks, int n_heavy,
                                   const coevo_fc_task *light_tasks, int n_light, int light_max_rows,
                                   const double *state_prev, double *state_next, int n_games,
                                   const int32_t *row_game, const int32_t *row_slot, const int32_t *act_prev,
                                   int32_t *act_cur, const int32_t *game_limit, int cycle, int pos_first,
-                                  int32_t *status, uint64_t *stamps, void *stream);
+                                  int32_t *status, uint64_t *stamps, int concurrent_launches, void *stream);
 int coevo_mpe_final_step(const double *state, int n_games, const int32_t *actions_by_game, int cycle,
                          const int32_t *game_limit, int pos_first, double *rewards, void *stream);
 

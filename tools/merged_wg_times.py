@@ -22,7 +22,7 @@ for i in range(2):
     ro.run(eng.n_cycles)
 torch.cuda.synchronize()
 nh, nl = len(eng.plan.heavy_np), len(eng.plan.light_np)
-n = nh + nl
+n = nh + (nl + 1) // 2 if nh + nl > 512 else nh + nl
 dll.coevo_debug_read_phase_stamps.argtypes = [C.c_void_p, C.c_int]
 buf = (C.c_ulonglong * (n * 8))()
 assert dll.coevo_debug_read_phase_stamps(buf, n * 8) == 0
@@ -35,9 +35,10 @@ heavy = np.arange(nh); light = np.arange(nh, n)
 desc("heavy", heavy)
 first = light[b[light] < 5]; later = light[b[light] >= 5]
 desc("light, first round", first)
-desc("light, later", later)
+if len(later): desc("light, later", later)
 ph = np.diff(st[:, :7], axis=1) / 100.0
 for nm, idx in (("heavy", heavy), ("light first", first), ("light later", later)):
+    if not len(idx): continue
     print(nm, "phases us:", np.round(ph[idx].mean(axis=0), 1))
 print("launch span us:", e.max())
 
