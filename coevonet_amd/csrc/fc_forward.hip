@@ -139,7 +139,9 @@ __device__ __forceinline__ void fc_policy_body(const FcArgs &a, FcSmem<R, P> &sm
     int st = 0;
 
     // ---- every small parameter this thread will need, requested up front: one HBM round trip instead of one
-    //      per layer (they would otherwise be loaded at first use, behind a barrier, with nothing else in flight)
+    //      per layer (they would otherwise be loaded at first use, behind a barrier, with nothing else in flight).
+    //      (Measured: requesting the row lanes' game state even before these - vmcnt completes in order - and marking
+    //      consecutive-game tasks to skip the row table costs registers, spills in the paired kernel: 438 vs 451.)
     constexpr int DMAX = 10;
     float w1a[P][DMAX], w1b[P][DMAX];
     float p_b1a[P], p_b1b[P], p_g1a[P], p_g1b[P], p_be1a[P], p_be1b[P];
