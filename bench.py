@@ -109,6 +109,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="enqueue every launch eagerly instead of replaying the "
                     "captured hipGraph of a generation's rollout")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--no-device-loop", action="store_true", help="drive every generation from the host (the code path "
+                    "the sharded multi-GPU run uses), also on one GPU")
+    ap.add_argument("--sharded-path", action="store_true", help="run the population-sharded loop (what --gpus N > 1 "
+                    "uses) even on one GPU: its per-GPU cost without the all-gather")
     ap.add_argument("--cohorts", type=int, default=None, help="independent game cohorts per rollout (default: the "
                     "engine's DEFAULT_COHORTS)")
     a = ap.parse_args()
@@ -133,6 +137,10 @@ def main():
     args.generations = a.steps + a.warmup  # sizes the device-resident evaluation / sigma histories
     if a.cohorts is not None:
         args.coevo_cohorts = a.cohorts
+    if a.no_device_loop:
+        args.coevo_device_loop = False
+    if a.sharded_path:
+        args.coevo_force_sharded_loop = True
     env = initialize_env(args)
     tr = GATrainer(env, args, rng="device_philox", env_mode=a.env, collect=False, dist_ctx=ctx)
     eng = tr.eng

@@ -386,6 +386,68 @@ class GAEngine:
                        L._p(self.dist[r]), 1, L._p(self.best_dist[r]))
         L.call("coevo_counter_add", g, 1)
 
+    def step_sharded(self, gen):
+        """One generation of the population-sharded run (world > 1) without a host round trip: the same launches as
+        enqueue_generation, restricted to this rank's individuals, with the fitness all-gather (stream-ordered on RCCL)
+        between the rollout and the selection.  Evaluation means and the adaptive sigma rule run on the device on every
+        rank alike (the 10 evaluation games are replicated), elites are rebuilt from last generation's elites, children
+        are bred with their stale-agent distance fused in.  Enqueued eagerly - the host knows `gen`, only data-dependent
+        values (sigma, ranks, distances) have to stay on the device."""
+        assert self.env_mode == "device" and self.rng_mode == "device_philox"
+        ro, M = self.ro, 3 * self.pop * self.hof
+        if gen <= 1:
+            limits = np.zeros(self.plan.n_games, dtype=np.int32)
+            limits[:self.n_main] = self.T_train
+            if gen == 1:
+                limits[self.n_main:] = self.T_eval
+            ro.set_limits(limits)
+        base = self._ordinal_base(gen)
+        per_phase = self.n_local * self.hof
+        for ph in range(3):
+            ro.reset(ph * per_phase, per_phase, base + ph * self.pop * self.hof + self.lo * self.hof)
+        if gen > 0:
+            ro.reset(self.n_main, N_EVAL, self._ordinal_base(gen - 1) + M)
+        ro.enqueue(self.n_cycles)
+        # last HoF game of every local individual (Q2) + its stale-agent distance -> every rank (one fused all-gather)
+        for ph in range(3):
+            idx = ph * per_phase + torch.arange(self.n_local, device=self.device) * self.hof + self.hof - 1
+            self.last_reward[ph, self.lo:self.hi] = ro.rewards[idx]
+        if self.world > 1:
+            self.gather(self)
+        for ph, r in enumerate(ROLES):
+            L.call("coevo_sharing_score", L._p(self.dist[r]), self.pop, L._p(self.div[r]))
+            L.call("coevo_ga_fitness", self.last_reward[ph].data_ptr(), 0, self.pop, 1, self.hof, RET_SLOT[r],
+                   L._p(self.div[r]), L._p(self.fitness[r]))
+            L.call("coevo_rank_desc", L._p(self.fitness[r]), self.pop, L._p(self.order[r]))
+        g = L._p(self.gen_dev)
+        mn, mx, adaptive = self.loop_args
+        self.sigma32_prev.copy_(self.sigma32)  # what last generation's children were bred with (elite rebuild)
+        L.call("coevo_ga_adapt_sigma", L._p(ro.rewards), self.n_main, g, L._p(self.hist), L._p(self.sig_hist), self.cap,
+               L._p(self.sigma64), L._p(self.sigma32), mn, mx, adaptive)
+        c_lo, c_hi = max(self.lo, 1) - 1, self.hi - 1  # child c = individual c + 1
+        for ri, r in enumerate(ROLES):
+            D = ROLE_D[r]
+            if gen > 0:
+                L.call("coevo_fc_gather", self._ptr(r, "elite"), L._p(self.iota), self._ptr(r, "elite_prev"), 0, self.E, D)
+                L.call("coevo_fc_rebuild_elites", self._ptr(r, "elite_prev"), L._p(self.order[r]), self._ptr(r, "elite"),
+                       self.E, D, self.sigma32_prev.data_ptr() + 4 * ri, self.philox_seed, (gen - 1) * 4 + ri, None)
+            else:  # generation 0's population is the host-initialised one, present on every rank
+                L.call("coevo_fc_gather", self._ptr(r, "pop"), L._p(self.order[r]), self._ptr(r, "elite"), 0, self.E, D)
+            self._hof_push(r)
+            L.call("coevo_gather_f32", L._p(self.best_dist[r]), L._p(self.dist[r]), L._p(self.order[r]), 1)  # the best
+            if self.lo == 0:
+                L.call("coevo_fc_gather", self._ptr(r, "elite"), L._p(self.iota), self._ptr(r, "pop"), 0, 1, D)
+            if c_hi > c_lo:
+                L.call("coevo_fc_perturb_dist", self._ptr(r, "elite"), self.parent_idx.data_ptr() + 4 * c_lo,
+                       self._ptr(r, "pop"), 1 + c_lo, c_hi - c_lo, D, self.sigma32.data_ptr() + 4 * ri,
+                       self.philox_seed, c_lo, gen * 4 + ri, 0, None, self._ptr(r, "stale"),
+                       L._p(self.dist_partial[r]))
+                L.call("coevo_fc_distance_finalize", L._p(self.dist_partial[r]), self.pblocks[r], c_hi - c_lo,
+                       L._p(self.dist[r]), 1 + c_lo, L._p(self.best_dist[r]) if c_lo == 0 else None)
+            elif self.lo == 0:  # a shard that holds only the unchanged best
+                self.dist[r][0:1].copy_(self.best_dist[r])
+        L.call("coevo_counter_add", g, 1)
+
     def replay_generation(self, gen):
         if gen <= 1:  # the evaluation games of "generation -1" do not exist: disabled in generation 0 only
             limits = np.zeros(self.plan.n_games, dtype=np.int32)
@@ -473,9 +535,15 @@ class GATrainer:
         self.device_loop = (self.rng == "device_philox" and env_mode == "device" and shard == (0, 1)
                             and getattr(args, "coevo_device_loop", True))
         # cohort chains overlap only when enqueued eagerly (GAEngine.replay_generation): worth it in the host-free loop
+        # ... and its population-sharded counterpart (GAEngine.step_sharded)
+        force = bool(getattr(args, "coevo_force_sharded_loop", False))  # measurement: the N>1 code path on one GPU
+        self.sharded_loop = (self.rng == "device_philox" and env_mode == "device" and (shard != (0, 1) or force)
+                             and getattr(args, "coevo_device_loop", True))
+        if self.sharded_loop:
+            self.device_loop = False
         cohorts = getattr(args, "coevo_cohorts", None)
         if cohorts is None:
-            cohorts = DEVICE_LOOP_COHORTS if self.device_loop else DEFAULT_COHORTS
+            cohorts = DEVICE_LOOP_COHORTS if (self.device_loop or self.sharded_loop) else DEFAULT_COHORTS
         self.eng = GAEngine(args.population, args.hof_size, args.elites_number, args.max_timesteps_per_episode,
                             args.max_evaluation_steps, max_cycles=getattr(env, "max_cycles", 25), rng=self.rng,
                             philox_seed=getattr(args, "coevo_seed", 0), env=env_mode,
@@ -487,21 +555,24 @@ class GATrainer:
         self.res.engine = self.eng
         self.gen = 0
         self.stamp_every = 1
-        if self.device_loop:
+        if self.device_loop or self.sharded_loop:
             self.eng.setup_device_loop(args, capacity=max(getattr(args, "generations", 0), 1) + 64)
 
     def step(self):
         """generation self.gen: play its games (+ the previous generation's 10 evaluation games), select, breed"""
         eng, args, res, gen = self.eng, self.args, self.res, self.gen
         t0 = time.perf_counter()
-        if self.device_loop:
+        if self.device_loop or self.sharded_loop:
             if gen > eng.cap:
                 raise RuntimeError(f"generation {gen} exceeds the device history capacity ({eng.cap}) this trainer was "
                                    f"set up with (args.generations + 64): the adaptive mutation power could no longer "
                                    f"be updated on the device")
             # no host round trip: evaluation means, adaptive sigma, selection and offspring all stay on the device;
             # the host only enqueues (replays) the generation and may run ahead of the GPU
-            eng.replay_generation(gen)
+            if self.sharded_loop:
+                eng.step_sharded(gen)
+            else:
+                eng.replay_generation(gen)
             if self.collect:
                 self._collect_device_loop(gen)
             elif eng.ro.time_light and gen % self.stamp_every == 0:
@@ -554,7 +625,7 @@ class GATrainer:
     def finish(self):
         """flush the last generation's evaluation games and leave the env's reset counter where the reference would"""
         if self.gen > 0:
-            if self.device_loop:
+            if self.device_loop or self.sharded_loop:
                 torch.cuda.synchronize()
                 self.eng.ro.check_status()
                 self._sync_history_from_device(upto=self.gen - 1)
