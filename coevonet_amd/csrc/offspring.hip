@@ -218,6 +218,45 @@ __global__ __launch_bounds__(256) void fc_gather_kernel(const float *src_slab, c
     *reinterpret_cast<float4 *>(dst_slab + (int64_t)(dst_first + c) * stride + s0) = v;
 }
 
+// ---- elites -> elite buffer, HoF FIFO push, best -> pop[0] for up to three roles in ONE launch (instead of five net
+// copies per role).  A thread owns one 16-byte piece of every net it touches: it reads its piece of all sources first,
+// so the in-place HoF shift and a best individual that already sits in pop[0] need no second buffer.
+struct GaPromoteArgs {
+    coevo_ga_promote_role role[3];
+    int E, hof;
+};
+constexpr int PROMOTE_MAX_E = 8, PROMOTE_MAX_HOF = 16;
+
+__global__ __launch_bounds__(256) void ga_promote_kernel(GaPromoteArgs a)
+{
+    const coevo_ga_promote_role R = a.role[blockIdx.y];
+    const int64_t stride = fc_stride(R.D);
+    const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (s0 >= stride) return;
+    float4 e[PROMOTE_MAX_E];
+#pragma unroll
+    for (int k = 0; k < PROMOTE_MAX_E; ++k) {
+        if (k < a.E) {
+            const float *src = R.elites_from_pop ? R.pop + (int64_t)R.order[k] * stride : R.elite + (int64_t)k * stride;
+            e[k] = *reinterpret_cast<const float4 *>(src + s0);
+        }
+    }
+    float4 h[PROMOTE_MAX_HOF];
+#pragma unroll
+    for (int i = 1; i < PROMOTE_MAX_HOF; ++i)
+        if (i < a.hof) h[i] = *reinterpret_cast<const float4 *>(R.hof + (int64_t)i * stride + s0);
+#pragma unroll
+    for (int i = 1; i < PROMOTE_MAX_HOF; ++i)
+        if (i < a.hof) *reinterpret_cast<float4 *>(R.hof + (int64_t)(i - 1) * stride + s0) = h[i];
+    *reinterpret_cast<float4 *>(R.hof + (int64_t)(a.hof - 1) * stride + s0) = e[0];
+    if (R.elites_from_pop) {
+#pragma unroll
+        for (int k = 0; k < PROMOTE_MAX_E; ++k)
+            if (k < a.E) *reinterpret_cast<float4 *>(R.elite + (int64_t)k * stride + s0) = e[k];
+    }
+    if (R.best_to_pop0) *reinterpret_cast<float4 *>(R.pop + s0) = e[0];
+}
+
 // theta[p] += lr/(n*sigma) * sum_i fitness[i] * (pert_i[p] - theta[p]), i ascending, one fmaf per term.
 // The perturbation is read back from the materialised perturbed nets (one coalesced streaming pass over n*4P bytes)
 // instead of being regenerated: 0.3 ms instead of 2 ms per role at n = 1000.  LayerNorm entries are never perturbed
@@ -370,6 +409,25 @@ extern "C" int coevo_fc_gather(const float *src_slab, const int32_t *src_idx, fl
     const dim3 grid((unsigned)((fc_stride(D) / 4 + 255) / 256), (unsigned)n);
     hipLaunchKernelGGL(fc_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, src_slab, src_idx, dst_slab,
                        dst_first, fc_stride(D));
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_ga_promote(const coevo_ga_promote_role *roles, int n_roles, int E, int hof, void *stream)
+{
+    if (!roles || n_roles < 1 || n_roles > 3 || E < 1 || E > PROMOTE_MAX_E || hof < 1 || hof > PROMOTE_MAX_HOF)
+        return COEVO_ERR_ARG;
+    GaPromoteArgs a{};
+    int64_t max_stride = 0;
+    for (int r = 0; r < n_roles; ++r) {
+        const coevo_ga_promote_role &R = roles[r];
+        if (!R.pop || !R.hof || !R.elite || !fc_dim_ok(R.D) || (R.elites_from_pop && !R.order)) return COEVO_ERR_ARG;
+        a.role[r] = R;
+        if (fc_stride(R.D) > max_stride) max_stride = fc_stride(R.D);
+    }
+    a.E = E; a.hof = hof;
+    const dim3 grid((unsigned)((max_stride / 4 + 255) / 256), (unsigned)n_roles);
+    hipLaunchKernelGGL(ga_promote_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

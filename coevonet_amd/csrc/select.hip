@@ -110,6 +110,52 @@ __global__ __launch_bounds__(256) void rank_desc_kernel(const float *fitness, in
     }
 }
 
+// ---- the three per-role selection launches (score, fitness, rank) + the best individual's distance, for up to three
+// roles in ONE launch: block r serves role r with exactly the arithmetic of the kernels above -----------------------
+struct GaSelectArgs {
+    coevo_ga_select_role role[3];
+    int pop, games_per_individual, hof;
+};
+
+__global__ __launch_bounds__(256) void ga_select_kernel(GaSelectArgs a)
+{
+    __shared__ double scratch[4];
+    __shared__ float f[4096];
+    __shared__ float div_s;
+    const coevo_ga_select_role R = a.role[blockIdx.x];
+    const int n = a.pop;
+    // sharing score (sharing_score_kernel)
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)R.dist[i];
+    const float sigma = (float)(block_sum_f64(s, scratch) / (double)n);
+    double sc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float sh = 1.0f - R.dist[i] / sigma;
+        if (sh > 0.0f) sc += (double)sh;
+    }
+    const double tot = block_sum_f64(sc, scratch);
+    if (threadIdx.x == 0) { div_s = (float)tot; *R.diversity = (float)tot; }
+    __syncthreads();
+    // fitness (ga_fitness_kernel)
+    const int gpi = a.games_per_individual;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double last = R.rewards[3 * (size_t)(R.game_first + i * gpi + gpi - 1) + R.slot];
+        const float total = (float)(last / (double)a.hof);
+        const float fit = total / (1.0f + div_s);
+        f[i] = fit;
+        R.fitness[i] = fit;
+    }
+    __syncthreads();
+    // rank (rank_desc_kernel) + the best individual's distance (gather_f32 of order[0])
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float fi = f[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += rank_less(f[j], j, fi, i) ? 1 : 0;
+        R.order[n - 1 - rank] = i;
+        if (rank == n - 1 && R.best_dist) *R.best_dist = R.dist[i];
+    }
+}
+
 // np.mean of n <= 10 float64 values exactly as numpy computes it (pairwise_sum: n < 8 sequential from 0; otherwise
 // eight running sums combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), remainder added sequentially), then / n
 __device__ inline double np_mean_le10(const double *a, int n)
@@ -251,6 +297,25 @@ extern "C" int coevo_rank_desc(const float *fitness, int n, int32_t *order, void
 {
     if (!fitness || !order || n <= 0 || n > 4096) return COEVO_ERR_ARG;
     hipLaunchKernelGGL(rank_desc_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, fitness, n, order);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_ga_select(const coevo_ga_select_role *roles, int n_roles, int pop, int games_per_individual,
+                               int hof, void *stream)
+{
+    if (!roles || n_roles < 1 || n_roles > 3 || pop <= 0 || pop > 4096 || hof <= 0 || games_per_individual <= 0)
+        return COEVO_ERR_ARG;
+    coevo::GaSelectArgs a{};
+    for (int r = 0; r < n_roles; ++r) {
+        const coevo_ga_select_role &R = roles[r];
+        if (!R.dist || !R.rewards || !R.diversity || !R.fitness || !R.order || R.slot < 0 || R.slot > 2 ||
+            R.game_first < 0)
+            return COEVO_ERR_ARG;
+        a.role[r] = R;
+    }
+    a.pop = pop; a.games_per_individual = games_per_individual; a.hof = hof;
+    hipLaunchKernelGGL(coevo::ga_select_kernel, dim3(n_roles), dim3(256), 0, (hipStream_t)stream, a);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

@@ -337,6 +337,23 @@ class GAEngine:
         for r in ROLES:
             L.call("coevo_fc_distance", self._ptr(r, "stale"), self._ptr(r, "pop"), self.pop, ROLE_D[r],
                    L._p(self.dist[r]))
+        # argument blocks of the fused selection / promotion launches (one launch for the three roles)
+        self.fused_tail = self.E <= 8 and self.hof <= 16 and self.pop <= 4096
+
+    def _select_roles(self, rewards_ptr_of, game_first_of, games_per_individual):
+        roles = (L.GaSelectRole * 3)()
+        for ri, r in enumerate(ROLES):
+            roles[ri] = L.GaSelectRole(L._p(self.dist[r]), rewards_ptr_of(ri), L._p(self.div[r]), L._p(self.fitness[r]),
+                                       L._p(self.order[r]), L._p(self.best_dist[r]), game_first_of(ri), RET_SLOT[r])
+        L.call("coevo_ga_select", roles, 3, self.pop, games_per_individual, self.hof)
+
+    def _promote_roles(self, elites_from_pop, best_to_pop0):
+        roles = (L.GaPromoteRole * 3)()
+        for ri, r in enumerate(ROLES):
+            roles[ri] = L.GaPromoteRole(self._ptr(r, "pop"), self._ptr(r, "hof"), self._ptr(r, "elite"),
+                                        L._p(self.order[r]), ROLE_D[r], 1 if elites_from_pop else 0,
+                                        1 if best_to_pop0 else 0, 0)
+        L.call("coevo_ga_promote", roles, 3, self.E, self.hof)
 
     def enqueue_generation(self):
         """reset -> 25 cycles -> rewards -> sharing/fitness/rank -> evaluation means + adaptive sigma -> HoF push and
@@ -363,21 +380,26 @@ class GAEngine:
         ro, M = self.ro, 3 * self.pop * self.hof
         per_gen, per_phase = M + N_EVAL, self.pop * self.hof
         g = L._p(self.gen_dev)
-        for ph, r in enumerate(ROLES):
-            D = ROLE_D[r]
-            L.call("coevo_sharing_score", L._p(self.dist[r]), self.pop, L._p(self.div[r]))
-            L.call("coevo_ga_fitness", L._p(ro.rewards), ph * per_phase, self.pop, self.hof, self.hof, RET_SLOT[r],
-                   L._p(self.div[r]), L._p(self.fitness[r]))
-            L.call("coevo_rank_desc", L._p(self.fitness[r]), self.pop, L._p(self.order[r]))
         mn, mx, adaptive = self.loop_args
+        if self.fused_tail:
+            self._select_roles(lambda ri: L._p(ro.rewards), lambda ri: ri * per_phase, self.hof)
+        else:
+            for ph, r in enumerate(ROLES):
+                L.call("coevo_sharing_score", L._p(self.dist[r]), self.pop, L._p(self.div[r]))
+                L.call("coevo_ga_fitness", L._p(ro.rewards), ph * per_phase, self.pop, self.hof, self.hof, RET_SLOT[r],
+                       L._p(self.div[r]), L._p(self.fitness[r]))
+                L.call("coevo_rank_desc", L._p(self.fitness[r]), self.pop, L._p(self.order[r]))
         L.call("coevo_ga_adapt_sigma", L._p(ro.rewards), self.n_main, g, L._p(self.hist), L._p(self.sig_hist), self.cap,
                L._p(self.sigma64), L._p(self.sigma32), mn, mx, adaptive)
+        if self.fused_tail:
+            self._promote_roles(elites_from_pop=True, best_to_pop0=True)
         for ri, r in enumerate(ROLES):
             D = ROLE_D[r]
-            L.call("coevo_fc_gather", self._ptr(r, "pop"), L._p(self.order[r]), self._ptr(r, "elite"), 0, self.E, D)
-            self._hof_push(r)
-            L.call("coevo_fc_gather", self._ptr(r, "elite"), L._p(self.iota), self._ptr(r, "pop"), 0, 1, D)
-            L.call("coevo_gather_f32", L._p(self.best_dist[r]), L._p(self.dist[r]), L._p(self.order[r]), 1)  # the best
+            if not self.fused_tail:
+                L.call("coevo_fc_gather", self._ptr(r, "pop"), L._p(self.order[r]), self._ptr(r, "elite"), 0, self.E, D)
+                self._hof_push(r)
+                L.call("coevo_fc_gather", self._ptr(r, "elite"), L._p(self.iota), self._ptr(r, "pop"), 0, 1, D)
+                L.call("coevo_gather_f32", L._p(self.best_dist[r]), L._p(self.dist[r]), L._p(self.order[r]), 1)
             if self.pop > 1:
                 L.call("coevo_fc_perturb_dist", self._ptr(r, "elite"), L._p(self.parent_idx), self._ptr(r, "pop"), 1,
                        self.pop - 1, D, self.sigma32.data_ptr() + 4 * ri, self.philox_seed, 0, ri, 0, g,
@@ -414,11 +436,14 @@ class GAEngine:
             self.last_reward[ph, self.lo:self.hi] = ro.rewards[idx]
         if self.world > 1:
             self.gather(self)
-        for ph, r in enumerate(ROLES):
-            L.call("coevo_sharing_score", L._p(self.dist[r]), self.pop, L._p(self.div[r]))
-            L.call("coevo_ga_fitness", self.last_reward[ph].data_ptr(), 0, self.pop, 1, self.hof, RET_SLOT[r],
-                   L._p(self.div[r]), L._p(self.fitness[r]))
-            L.call("coevo_rank_desc", L._p(self.fitness[r]), self.pop, L._p(self.order[r]))
+        if self.fused_tail:
+            self._select_roles(lambda ri: self.last_reward[ri].data_ptr(), lambda ri: 0, 1)
+        else:
+            for ph, r in enumerate(ROLES):
+                L.call("coevo_sharing_score", L._p(self.dist[r]), self.pop, L._p(self.div[r]))
+                L.call("coevo_ga_fitness", self.last_reward[ph].data_ptr(), 0, self.pop, 1, self.hof, RET_SLOT[r],
+                       L._p(self.div[r]), L._p(self.fitness[r]))
+                L.call("coevo_rank_desc", L._p(self.fitness[r]), self.pop, L._p(self.order[r]))
         g = L._p(self.gen_dev)
         mn, mx, adaptive = self.loop_args
         self.sigma32_prev.copy_(self.sigma32)  # what last generation's children were bred with (elite rebuild)
@@ -431,12 +456,17 @@ class GAEngine:
                 L.call("coevo_fc_gather", self._ptr(r, "elite"), L._p(self.iota), self._ptr(r, "elite_prev"), 0, self.E, D)
                 L.call("coevo_fc_rebuild_elites", self._ptr(r, "elite_prev"), L._p(self.order[r]), self._ptr(r, "elite"),
                        self.E, D, self.sigma32_prev.data_ptr() + 4 * ri, self.philox_seed, (gen - 1) * 4 + ri, None)
-            else:  # generation 0's population is the host-initialised one, present on every rank
+            elif not self.fused_tail:  # generation 0's population is the host-initialised one, present on every rank
                 L.call("coevo_fc_gather", self._ptr(r, "pop"), L._p(self.order[r]), self._ptr(r, "elite"), 0, self.E, D)
-            self._hof_push(r)
-            L.call("coevo_gather_f32", L._p(self.best_dist[r]), L._p(self.dist[r]), L._p(self.order[r]), 1)  # the best
-            if self.lo == 0:
-                L.call("coevo_fc_gather", self._ptr(r, "elite"), L._p(self.iota), self._ptr(r, "pop"), 0, 1, D)
+            if not self.fused_tail:
+                self._hof_push(r)
+                L.call("coevo_gather_f32", L._p(self.best_dist[r]), L._p(self.dist[r]), L._p(self.order[r]), 1)
+                if self.lo == 0:
+                    L.call("coevo_fc_gather", self._ptr(r, "elite"), L._p(self.iota), self._ptr(r, "pop"), 0, 1, D)
+        if self.fused_tail:
+            self._promote_roles(elites_from_pop=(gen == 0), best_to_pop0=(self.lo == 0))
+        for ri, r in enumerate(ROLES):
+            D = ROLE_D[r]
             if c_hi > c_lo:
                 L.call("coevo_fc_perturb_dist", self._ptr(r, "elite"), self.parent_idx.data_ptr() + 4 * c_lo,
                        self._ptr(r, "pop"), 1 + c_lo, c_hi - c_lo, D, self.sigma32.data_ptr() + 4 * ri,

@@ -54,6 +54,16 @@ class RolloutDesc(C.Structure):
                 ("merged", C.c_int32), ("reserved", C.c_int32)]
 
 
+class GaSelectRole(C.Structure):
+    _fields_ = [("dist", C.c_void_p), ("rewards", C.c_void_p), ("diversity", C.c_void_p), ("fitness", C.c_void_p),
+                ("order", C.c_void_p), ("best_dist", C.c_void_p), ("game_first", C.c_int32), ("slot", C.c_int32)]
+
+
+class GaPromoteRole(C.Structure):
+    _fields_ = [("pop", C.c_void_p), ("hof", C.c_void_p), ("elite", C.c_void_p), ("order", C.c_void_p),
+                ("D", C.c_int32), ("elites_from_pop", C.c_int32), ("best_to_pop0", C.c_int32), ("reserved", C.c_int32)]
+
+
 class CoevoError(RuntimeError):
     pass
 
@@ -78,6 +88,8 @@ _SIGS = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "coevo_rollout_ctx_create": (C.c_void_p, [C.c_int]),
     "coevo_rollout_ctx_destroy": (None, [C.c_void_p]),
+    "coevo_ga_select": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "coevo_ga_promote": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "coevo_rollout_ctx_reserve_cohorts": (C.c_int, [C.c_void_p, C.c_int]),
     "coevo_rollout_ctx_reset_timing": (C.c_int, [C.c_void_p]),
     "coevo_rollout_ctx_light_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),

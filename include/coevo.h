@@ -229,6 +229,31 @@ int coevo_gather_f32(float *dst, const float *src, const int32_t *idx, int n, vo
 int coevo_fc_rebuild_elites(const float *elite_prev, const int32_t *order, float *elite_new, int E, int D,
                             const float *sigma_prev_dev, uint64_t seed, uint32_t stream_hi_prev,
                             const int32_t *gen_dev /* or NULL; adds 4*(*gen_dev - 1) */, void *stream);
+/* Selection of up to three roles in ONE launch = coevo_sharing_score + coevo_ga_fitness + coevo_rank_desc per role
+ * (same arithmetic), plus best_dist = dist[order[0]] when best_dist is set (the distance the unchanged best individual
+ * keeps, see coevo_fc_distance_finalize).  All pointers are device memory; pop <= 4096. */
+typedef struct coevo_ga_select_role {
+    const float *dist;       /* [pop] distances to the stale agent */
+    const double *rewards;   /* play_game triples [n_games][3] */
+    float *diversity;        /* [1] out: the sharing score */
+    float *fitness;          /* [pop] out */
+    int32_t *order;          /* [pop] out: argsort(fitness)[::-1] */
+    float *best_dist;        /* [1] out, or NULL */
+    int32_t game_first;      /* individual i's games are game_first + i*games_per_individual .. (last one counts, Q2) */
+    int32_t slot;            /* which element of the triple is this role's return */
+} coevo_ga_select_role;
+int coevo_ga_select(const coevo_ga_select_role *roles, int n_roles, int pop, int games_per_individual, int hof,
+                    void *stream);
+/* Promotion of up to three roles in ONE launch (replaces five coevo_fc_gather launches per role;
+ * genetic_algorithm.py:262-275): elite[k] = pop[order[k]] (k < E <= 8; skipped when elites_from_pop == 0: the elites
+ * are already in `elite`, e.g. rebuilt by coevo_fc_rebuild_elites), hof.pop(0); hof.append(elite[0]) (hof <= 16 nets,
+ * shifted in place), and pop[0] = elite[0] when best_to_pop0 != 0. */
+typedef struct coevo_ga_promote_role {
+    float *pop, *hof, *elite;   /* first net of each region (slab layout of width D) */
+    const int32_t *order;       /* device, [>= E]; may be NULL when elites_from_pop == 0 */
+    int32_t D, elites_from_pop, best_to_pop0, reserved;
+} coevo_ga_promote_role;
+int coevo_ga_promote(const coevo_ga_promote_role *roles, int n_roles, int E, int hof, void *stream);
 /* net copies inside/between slabs driven by device-resident indices: dst[dst_first+i] = src[src_idx[i]] */
 int coevo_fc_gather(const float *src_slab, const int32_t *src_idx, float *dst_slab, int dst_first, int n, int D,
                     void *stream);

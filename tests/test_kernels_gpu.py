@@ -369,3 +369,58 @@ def test_diversity_fitness_rank():
     d_f = torch.from_numpy(f).to(DEV)
     L.call("coevo_rank_desc", L._p(d_f), 200, L._p(order))
     assert np.array_equal(order.cpu().numpy(), np.argsort(f, kind="stable")[::-1])
+
+
+def test_fused_select_and_promote_equal_separate_launches():
+    """coevo_ga_select / coevo_ga_promote (one launch for the three roles) == the per-role launches they replace"""
+    rng = np.random.default_rng(3)
+    pop, hof, E, gpi = 37, 4, 3, 4
+    n_games = 3 * pop * gpi
+    rewards = torch.from_numpy(rng.normal(size=(n_games, 3)) * 10).to(DEV)
+    Ds = [10, 10, 8]
+    sel = (L.GaSelectRole * 3)()
+    keep, want = [], []
+    for ri in range(3):
+        dist = torch.from_numpy(rng.random(pop).astype(np.float32) * 3).to(DEV)
+        div0, fit0 = torch.zeros(1, device=DEV), torch.zeros(pop, device=DEV)
+        order0 = torch.zeros(pop, dtype=torch.int32, device=DEV)
+        L.call("coevo_sharing_score", L._p(dist), pop, L._p(div0))
+        L.call("coevo_ga_fitness", L._p(rewards), ri * pop * gpi, pop, gpi, hof, ri, L._p(div0), L._p(fit0))
+        L.call("coevo_rank_desc", L._p(fit0), pop, L._p(order0))
+        div1, fit1 = torch.zeros(1, device=DEV), torch.zeros(pop, device=DEV)
+        order1 = torch.zeros(pop, dtype=torch.int32, device=DEV)
+        best = torch.zeros(1, device=DEV)
+        sel[ri] = L.GaSelectRole(L._p(dist), L._p(rewards), L._p(div1), L._p(fit1), L._p(order1), L._p(best),
+                                 ri * pop * gpi, ri)
+        keep.append((dist, div1, fit1, order1, best))
+        want.append((div0, fit0, order0))
+    L.call("coevo_ga_select", sel, 3, pop, gpi, hof)
+    torch.cuda.synchronize()
+    for (dist, div1, fit1, order1, best), (div0, fit0, order0) in zip(keep, want):
+        assert torch.equal(div0, div1) and torch.equal(fit0, fit1) and torch.equal(order0, order1)
+        assert best.item() == dist[int(order0[0])].item()
+
+    pro = (L.GaPromoteRole * 3)()
+    checks = []
+    iota = torch.arange(16, dtype=torch.int32, device=DEV)
+    shift = torch.arange(1, 16, dtype=torch.int32, device=DEV)
+    for ri, D in enumerate(Ds):
+        stride = L.fc_slab_stride(D)
+        order = torch.from_numpy(rng.permutation(pop).astype(np.int32)).to(DEV)
+        if ri == 1:
+            order[0] = 0   # the best already sits in pop[0]
+        slabs = [torch.from_numpy(rng.normal(size=n * stride).astype(np.float32)).to(DEV) for n in (pop, hof, E)]
+        ref = [x.clone() for x in slabs] + [torch.zeros(hof * stride, device=DEV)]
+        rp_, rh, re_, rt = ref
+        L.call("coevo_fc_gather", L._p(rp_), L._p(order), L._p(re_), 0, E, D)
+        L.call("coevo_fc_gather", L._p(rh), L._p(shift), L._p(rt), 0, hof - 1, D)
+        L.call("coevo_fc_gather", L._p(rt), L._p(iota), L._p(rh), 0, hof - 1, D)
+        L.call("coevo_fc_gather", L._p(re_), L._p(iota), L._p(rh), hof - 1, 1, D)
+        L.call("coevo_fc_gather", L._p(re_), L._p(iota), L._p(rp_), 0, 1, D)
+        pro[ri] = L.GaPromoteRole(L._p(slabs[0]), L._p(slabs[1]), L._p(slabs[2]), L._p(order), D, 1, 1, 0)
+        checks.append((slabs, ref, order))
+    L.call("coevo_ga_promote", pro, 3, E, hof)
+    torch.cuda.synchronize()
+    for slabs, ref, _ in checks:
+        for got, exp in zip(slabs, ref[:3]):
+            assert torch.equal(got, exp)
