@@ -146,14 +146,32 @@ __global__ __launch_bounds__(256) void fc_perturb_kernel(const float *parent_sla
         float *ch = child_slab + (int64_t)(child_first + c) * stride;
         const float4 pv = *reinterpret_cast<const float4 *>(par + s0);
         float z[4];
-        slab_quad_normals(seed, stream_lo_first + (uint32_t)c, stream_hi, s0, D, P, z);
+        bool keep[4], in_dist[4];
+        const int32_t o_w2 = (int32_t)fc_off_w2(D), o_b2 = (int32_t)fc_off_b2(D), s32 = (int32_t)s0;
+        if (s32 >= o_w2 && s32 < o_b2) {
+            // fc2 block (93.8 % of a net): W2q[jb][kq][l][0..3] are the four consecutive canonical indices
+            // fc2.w[64*jb + l][4*kq .. 4*kq+3], one Philox block, never LayerNorm, never padding - 32-bit index math
+            const int32_t t = s32 - o_w2;
+            const int32_t l = (t >> 2) & 63, kq = (t >> 8) & 127, jb = t >> 15;
+            const int32_t p0 = o_w2 + (jb * 64 + l) * H1 + kq * 4;  // multiple of 4
+            philox_normal4(seed, stream_lo_first + (uint32_t)c, stream_hi, (uint32_t)(p0 >> 2), z);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { keep[i] = false; in_dist[i] = true; }
+        } else {
+            slab_quad_normals(seed, stream_lo_first + (uint32_t)c, stream_hi, s0, D, P, z);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t s = s0 + i;
+                const bool ln = fc_slab_is_layernorm(s, D);
+                keep[i] = (s >= P) || (skip_layernorm && ln);
+                in_dist[i] = s < P && !ln;
+            }
+        }
         float in[4] = {pv.x, pv.y, pv.z, pv.w}, out[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int64_t s = s0 + i;
-            const bool keep = (s >= P) || (skip_layernorm && fc_slab_is_layernorm(s, D));
             const float noise = sigma * z[i];  // rounded first, then added (agent.py:28-29)
-            out[i] = keep ? in[i] : in[i] + noise;
+            out[i] = keep[i] ? in[i] : in[i] + noise;
         }
         *reinterpret_cast<float4 *>(ch + s0) = make_float4(out[0], out[1], out[2], out[3]);
         if (dist_partial) {  // fitness-sharing distance of the new child to a reference net, while it is in registers
@@ -161,8 +179,7 @@ __global__ __launch_bounds__(256) void fc_perturb_kernel(const float *parent_sla
             const float ref[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int64_t s = s0 + i;
-                if (s < P && !fc_slab_is_layernorm(s, D)) {
+                if (in_dist[i]) {
                     const float d = out[i] - ref[i];
                     d2 += (double)d * (double)d;
                 }
