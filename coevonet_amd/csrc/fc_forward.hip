@@ -743,6 +743,310 @@ __global__ __launch_bounds__(256, 2) void fc_policy_mfma_kernel(FcArgs a)
     fc_policy_mfma_body<MODE>(a, sm, a.tasks[blockIdx.x]);
 }
 
+// =====================================================================================================
+// The lean shared-opponent body: up to 16 rows per task on v_mfma_f32_16x16x4_f32 (tools/mfma16_chain_probe.hip: the
+// same bits as the fmaf chain), <= 128 registers and < 40 KiB of LDS, so that FOUR workgroups fit a CU and the merged
+// cycle launch keeps every streaming workgroup resident next to the shared-opponent ones (the 32-row body above costs
+// 256 registers and 73 KiB: two workgroups per CU).  Wave w owns fc1 columns [128w, 128w+128) = 8 tiles and fc2 columns
+// [64w, 64w+64) = 4 tiles.  Operands of one MFMA: lane (c = l%16, kk = l/16) supplies A[row c][k = 4q + kk] and
+// B[k = 4q + kk][column c]; accumulator register i of lane (c, g = l/16) is row 4g + i, column c of the tile.
+struct FcMfma16Smem {
+    union {
+        // A operands of fc2: h1a[k][row ^ ((k >> 2) & 3)] - the xor makes both the scatter from the accumulator layout
+        // and the gather by (row, kk) conflict-free at a pitch of 16
+        float h1a[H1][16];
+        float h2[16][260];
+    };
+    float xst[12][16];  // observations transposed [k][row], zero padded to 12 inputs: A operands of fc1
+    float w3s[NACT][260];
+    float red[16][8];
+    float logit[16][COEVO_LOGIT_STRIDE];
+};
+static_assert(sizeof(FcMfma16Smem) <= 40960, "four workgroups per CU");
+
+template <int MODE>
+__device__ __forceinline__ void fc_policy_mfma16_body(const FcArgs &a, FcMfma16Smem &sm, const coevo_fc_task &task)
+{
+    typedef float f32x4_acc __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2_s __attribute__((ext_vector_type(2)));
+    COEVO_STAMP(0);
+    const int t = threadIdx.x, w = t >> 6, l = t & 63, lc = l & 15, lg = l >> 4;
+    const int D = task.D, nrows = task.n_rows, row0 = task.row_begin;
+    const float *net = a.slab + task.net_off;
+    int st = 0;
+
+    // ---- all small parameters and the whole fc1 B operand requested up front ---------------------------------
+    constexpr int KS = 3;  // k-steps of fc1 (D <= 12)
+    float w1[KS][8], p_b1[8], p_g1[8], p_be1[8], p_b2[4], p_g2[4], p_be2[4];
+    {
+        const float *b1p = net + fc_off_b1(D), *b2p = net + fc_off_b2(D);
+#pragma unroll
+        for (int q = 0; q < KS; ++q)
+#pragma unroll
+            for (int T = 0; T < 8; ++T)  // a padded k contributes fma(0, -0, acc) = acc for every acc, -0 included
+                w1[q][T] = (4 * q + lg < D) ? net[(size_t)(4 * q + lg) * H1 + 128 * w + 16 * T + lc] : -0.0f;
+#pragma unroll
+        for (int T = 0; T < 8; ++T) {
+            const int j = 128 * w + 16 * T + lc;
+            p_b1[T] = b1p[j]; p_g1[T] = b1p[H1 + j]; p_be1[T] = b1p[2 * H1 + j];
+        }
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            const int j = 64 * w + 16 * T + lc;
+            p_b2[T] = b2p[j]; p_g2[T] = b2p[H2 + j]; p_be2[T] = b2p[2 * H2 + j];
+        }
+    }
+    const float p_b3 = (t < 16 * NACT) ? net[fc_off_b3(D) + t % NACT] : 0.0f;
+
+    if constexpr (MODE == MODE_FUSED) {
+        if (t < 16) {
+            float o[COEVO_OBS_STRIDE];
+#pragma unroll
+            for (int k = 0; k < COEVO_OBS_STRIDE; ++k) o[k] = 0.0f;
+            if (t < nrows) {
+                const int row = row0 + t;
+                mpe_fused_observe(a.state, a.state_next, a.act_prev, a.game_limit, a.n_games, a.row_game[row],
+                                  a.row_slot[row], a.cycle, a.pos_first, o);
+#pragma unroll
+                for (int k = 0; k < 10; ++k)
+                    if (!__builtin_isfinite(o[k])) st |= COEVO_ST_BAD_INPUT;
+            }
+#pragma unroll
+            for (int k = 0; k < COEVO_OBS_STRIDE; ++k) sm.xst[k][t] = o[k];
+        }
+    } else {
+        for (int i = t; i < 16 * COEVO_OBS_STRIDE; i += 256) {
+            const int r = i / COEVO_OBS_STRIDE, k = i % COEVO_OBS_STRIDE;
+            float v = 0.0f;
+            if (r < nrows && k < D) {
+                if constexpr (MODE == MODE_STATE) {
+                    const int row = row0 + r;
+                    v = mpe_obs_element(a.state, a.n_games, a.row_game[row], a.row_slot[row], k);
+                } else {
+                    v = a.obs[(size_t)(row0 + r) * COEVO_OBS_STRIDE + k];
+                }
+                if (!__builtin_isfinite(v)) st |= COEVO_ST_BAD_INPUT;
+            }
+            sm.xst[k][r] = v;
+        }
+    }
+    {
+        const float *W3 = net + fc_off_w3(D);
+        for (int i = t; i < NACT * H2; i += 256) sm.w3s[i >> 8][i & 255] = W3[i];
+    }
+    __syncthreads();
+    COEVO_STAMP(1);
+
+    // ---- fc1: 8 column tiles per wave, ceil(D/4) k-steps --------------------------------------------------
+    f32x4_acc c1[8];
+#pragma unroll
+    for (int T = 0; T < 8; ++T)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c1[T][i] = p_b1[T];
+#pragma unroll
+    for (int q = 0; q < KS; ++q) {
+        if (4 * q < D) {  // wave-uniform
+            const float av = sm.xst[4 * q + lg][lc];
+#pragma unroll
+            for (int T = 0; T < 8; ++T) c1[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w1[q][T], c1[T], 0, 0, 0);
+        }
+    }
+    // ---- LayerNorm(512): canonical blocks 2w (tiles 0..3) and 2w+1 (tiles 4..7); inside a block feature 16T' + lc:
+    //      four tree levels inside the 16-lane row, then (T0 + T1) + (T2 + T3) ---------------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float s_lo = (row16_tree_sum(c1[0][i]) + row16_tree_sum(c1[1][i])) +
+                           (row16_tree_sum(c1[2][i]) + row16_tree_sum(c1[3][i]));
+        const float s_hi = (row16_tree_sum(c1[4][i]) + row16_tree_sum(c1[5][i])) +
+                           (row16_tree_sum(c1[6][i]) + row16_tree_sum(c1[7][i]));
+        if (lc == 0) { sm.red[4 * lg + i][2 * w] = s_lo; sm.red[4 * lg + i][2 * w + 1] = s_hi; }
+    }
+    __syncthreads();
+    float stat[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float *rr = sm.red[4 * lg + i];
+        float tot = rr[0];
+#pragma unroll
+        for (int b = 1; b < 8; ++b) tot = tot + rr[b];
+        stat[i] = tot * (1.0f / H1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int T = 0; T < 8; ++T) c1[T][i] = c1[T][i] - stat[i];
+        const float s_lo = (row16_tree_sum(c1[0][i] * c1[0][i]) + row16_tree_sum(c1[1][i] * c1[1][i])) +
+                           (row16_tree_sum(c1[2][i] * c1[2][i]) + row16_tree_sum(c1[3][i] * c1[3][i]));
+        const float s_hi = (row16_tree_sum(c1[4][i] * c1[4][i]) + row16_tree_sum(c1[5][i] * c1[5][i])) +
+                           (row16_tree_sum(c1[6][i] * c1[6][i]) + row16_tree_sum(c1[7][i] * c1[7][i]));
+        if (lc == 0) { sm.red[4 * lg + i][2 * w] = s_lo; sm.red[4 * lg + i][2 * w + 1] = s_hi; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 4 * lg + i;
+        const float *rr = sm.red[row];
+        float tot = rr[0];
+#pragma unroll
+        for (int b = 1; b < 8; ++b) tot = tot + rr[b];
+        const float rstd = 1.0f / __builtin_sqrtf(tot * (1.0f / H1) + LN_EPS);
+#pragma unroll
+        for (int T = 0; T < 8; ++T) {
+            const float y = __builtin_fmaf(c1[T][i] * rstd, p_g1[T], p_be1[T]);
+            if (row < nrows && bad_post_relu(y)) st |= COEVO_ST_BAD_FC1;
+            const int k = 128 * w + 16 * T + lc;  // this activation is input k of fc2
+            sm.h1a[k][row ^ ((k >> 2) & 3)] = relu_keep_nan(y);
+        }
+    }
+    __syncthreads();
+    COEVO_STAMP(2);
+
+    // ---- fc2: 4 column tiles per wave, 128 k-steps; B operands of the four tiles from the lane's own 16-byte piece by
+    //      a 4x4 (register x 16-lane row) transpose -------------------------------------------------------------
+    f32x4_acc c2[4];
+    {
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c2[T][i] = p_b2[T];
+        const float4 *wp = reinterpret_cast<const float4 *>(net + fc_off_w2(D)) + (size_t)w * 128 * 64 + l;
+        constexpr int U = 4;
+        float4 bufA[U], bufB[U];
+        auto issue = [&](float4 (&buf)[U], int kq) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) buf[u] = wp[(size_t)(kq + u) * 64];
+        };
+        auto consume = [&](const float4 (&buf)[U], int kq) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = kq + u;
+                const float av = sm.h1a[4 * q + lg][lc ^ (q & 3)];  // A[row lc][k = 4q + lg]
+                const u32x2_s s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(buf[u].x), __float_as_uint(buf[u].z), false, false);
+                const u32x2_s s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(buf[u].y), __float_as_uint(buf[u].w), false, false);
+                const u32x2_s y01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+                const u32x2_s y23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+                c2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, __uint_as_float(y01[0]), c2[0], 0, 0, 0);
+                c2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, __uint_as_float(y01[1]), c2[1], 0, 0, 0);
+                c2[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, __uint_as_float(y23[0]), c2[2], 0, 0, 0);
+                c2[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, __uint_as_float(y23[1]), c2[3], 0, 0, 0);
+            }
+        };
+        issue(bufA, 0);
+        int kq = 0;
+        for (; kq < 128 - 2 * U; kq += 2 * U) {
+            issue(bufB, kq + U);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(bufA, kq);
+            issue(bufA, kq + 2 * U);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(bufB, kq + U);
+        }
+        issue(bufB, kq + U);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(bufA, kq);
+        consume(bufB, kq + U);
+    }
+    COEVO_STAMP(3);
+    // ---- LayerNorm(256): canonical block w = this wave's four tiles --------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float s = (row16_tree_sum(c2[0][i]) + row16_tree_sum(c2[1][i])) +
+                        (row16_tree_sum(c2[2][i]) + row16_tree_sum(c2[3][i]));
+        if (lc == 0) sm.red[4 * lg + i][w] = s;
+    }
+    __syncthreads();  // every wave is done with h1a: h2 may overwrite it below
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float *rr = sm.red[4 * lg + i];
+        stat[i] = (((rr[0] + rr[1]) + rr[2]) + rr[3]) * (1.0f / H2);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int T = 0; T < 4; ++T) c2[T][i] = c2[T][i] - stat[i];
+        const float s = (row16_tree_sum(c2[0][i] * c2[0][i]) + row16_tree_sum(c2[1][i] * c2[1][i])) +
+                        (row16_tree_sum(c2[2][i] * c2[2][i]) + row16_tree_sum(c2[3][i] * c2[3][i]));
+        if (lc == 0) sm.red[4 * lg + i][w] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 4 * lg + i;
+        const float *rr = sm.red[row];
+        const float tot = ((rr[0] + rr[1]) + rr[2]) + rr[3];
+        const float rstd = 1.0f / __builtin_sqrtf(tot * (1.0f / H2) + LN_EPS);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            const float y = __builtin_fmaf(c2[T][i] * rstd, p_g2[T], p_be2[T]);
+            if (row < nrows && bad_post_relu(y)) st |= COEVO_ST_BAD_FC2;
+            sm.h2[row][64 * w + 16 * T + lc] = relu_keep_nan(y);
+        }
+    }
+    __syncthreads();
+    COEVO_STAMP(4);
+
+    // ---- output layer, argmax, status - as in the other bodies ------------------------------------------------
+    if (t < 16 * NACT) {
+        const int r = t / NACT, o = t % NACT;
+        float y = p_b3;
+        const float4 *wr = reinterpret_cast<const float4 *>(&sm.w3s[o][0]);
+        const float4 *xr = reinterpret_cast<const float4 *>(&sm.h2[r][0]);
+#pragma unroll 8
+        for (int k = 0; k < H2 / 4; ++k) {
+            const float4 wv = wr[k], xv = xr[k];
+            y = __builtin_fmaf(wv.x, xv.x, y);
+            y = __builtin_fmaf(wv.y, xv.y, y);
+            y = __builtin_fmaf(wv.z, xv.z, y);
+            y = __builtin_fmaf(wv.w, xv.w, y);
+        }
+        sm.logit[r][o] = y;
+    }
+    __syncthreads();
+    COEVO_STAMP(5);
+    if (t < nrows) {
+        int best = -1;
+        float cur = -__builtin_inff();
+#pragma unroll
+        for (int o = 0; o < NACT; ++o) {
+            const float v = sm.logit[t][o];
+            if (!__builtin_isfinite(v)) st |= COEVO_ST_BAD_OUT;
+            if (v > cur) { cur = v; best = o; }
+        }
+        if (best < 0) { st |= COEVO_ST_NO_ACTION; best = 0; }
+        if constexpr (MODE == MODE_FUSED) {
+            const int row = row0 + t;
+            a.act_cur[3 * a.row_game[row] + a.row_slot[row]] = best;  // by (game, slot): next cycle's step reads it
+        } else {
+            a.actions[row0 + t] = best;
+        }
+        if (a.logits) {
+#pragma unroll
+            for (int o = 0; o < NACT; ++o) a.logits[(size_t)(row0 + t) * COEVO_LOGIT_STRIDE + o] = sm.logit[t][o];
+        }
+    }
+    if (st) atomicOr(a.status, st);
+    COEVO_STAMP(6);
+}
+
+// The lean merged cycle launch: shared-opponent tasks of <= 16 rows (fc_policy_mfma16_body) + one per-individual net per
+// streaming workgroup, four workgroups per CU.
+template <int R>
+__global__ __launch_bounds__(256, 4) void fc_cycle16_kernel(FcArgs a)
+{
+    __shared__ union Cycle16Smem {
+        FcMfma16Smem heavy;
+        FcSmem<R, 1> light;
+    } sm;
+    stamp_begin(a.stamps);
+    if ((int)blockIdx.x < a.n_heavy)  // workgroup-uniform
+        fc_policy_mfma16_body<MODE_FUSED>(a, sm.heavy, a.tasks[blockIdx.x]);
+    else
+        fc_policy_body<R, MODE_FUSED, 1>(a, sm.light, a.light_tasks, (int)blockIdx.x - a.n_heavy, a.n_light);
+    stamp_end(a.stamps);
+}
+
 // One launch = one env-cycle of one cohort of games (fused env step): the shared-opponent tasks first (lowest block
 // indices: they are dispatched first and are the longer workgroups), then the per-individual tasks.  Both kinds of
 // workgroup get the MFMA path's footprint (<= 256 registers, ~73 KiB LDS: two workgroups per CU), so a launch of a
@@ -852,7 +1156,7 @@ extern "C" int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_t
                                              const int32_t *row_game, const int32_t *row_slot, const int32_t *act_prev,
                                              int32_t *act_cur, const int32_t *game_limit, int cycle, int pos_first,
                                              int32_t *status, uint64_t *stamps, int concurrent_launches,
-                                             void *stream)
+                                             int heavy_max_rows, void *stream)
 {
     if (!slab || !heavy_tasks || !light_tasks || !state_prev || !state_next || !row_game || !row_slot || !act_prev ||
         !act_cur || !status)
@@ -874,9 +1178,20 @@ extern "C" int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_t
             return COEVO_ERR_HIP;
         slots = 2 * cus;
     }
-    const bool pair = (n_heavy + n_light) * (concurrent_launches > 1 ? concurrent_launches : 1) > slots;
-    const dim3 grid(n_heavy + (pair ? (n_light + 1) / 2 : n_light)), block(256);
+    const int conc = concurrent_launches > 1 ? concurrent_launches : 1;
     hipStream_t s = (hipStream_t)stream;
+    if (heavy_max_rows >= 1 && heavy_max_rows <= 16 && (n_heavy + n_light) * conc <= 2 * slots) {
+        // the lean kernel: four workgroups per CU hold everything at one net per streaming workgroup
+        const dim3 grid16(n_heavy + n_light), block16(256);
+        if (light_max_rows <= 1) hipLaunchKernelGGL((coevo::fc_cycle16_kernel<1>), grid16, block16, 0, s, a);
+        else if (light_max_rows <= 2) hipLaunchKernelGGL((coevo::fc_cycle16_kernel<2>), grid16, block16, 0, s, a);
+        else if (light_max_rows <= 5) hipLaunchKernelGGL((coevo::fc_cycle16_kernel<5>), grid16, block16, 0, s, a);
+        else hipLaunchKernelGGL((coevo::fc_cycle16_kernel<8>), grid16, block16, 0, s, a);
+        COEVO_HIP_CHECK(hipGetLastError());
+        return COEVO_OK;
+    }
+    const bool pair = (n_heavy + n_light) * conc > slots;
+    const dim3 grid(n_heavy + (pair ? (n_light + 1) / 2 : n_light)), block(256);
 #define COEVO_LAUNCH_CYCLE(RR)                                                                    \
     do {                                                                                          \
         if (pair) hipLaunchKernelGGL((coevo::fc_cycle_kernel<RR, 2>), grid, block, 0, s, a);      \

@@ -166,7 +166,7 @@ extern "C" int coevo_mpe_rollout(const coevo_rollout_desc *d, void *ctx, int tim
                     d->slab, heavy, n_heavy, light, n_light, d->light_max_rows, st_prev, st_next, d->n_games, d->row_game,
                     d->row_slot, act_prev, act_cur, d->game_limit, cyc, d->pos_first, d->status,
                     d->light_stamps ? d->light_stamps + 2 * COEVO_STAMP_SLOTS * ((size_t)k * d->n_cycles + cyc) : nullptr,
-                    K, ls);
+                    K, d->heavy_max_rows, ls);
                 if (rc) return rc;
                 continue;
             }

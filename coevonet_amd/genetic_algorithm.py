@@ -127,7 +127,10 @@ class GAEngine:
         self.n_main = len(games)
         for _ in range(N_EVAL):  # evaluate_current_weights(best trio) = newest HoF members (:12-29, :301)
             games.append((net("hof", "adversary_0", h - 1), net("hof", "agent_0", h - 1), net("hof", "agent_1", h - 1)))
-        self.plan = RolloutPlan(np.array(games), net_off, net_D, device=device,
+        # 16-row shared-opponent tasks select the lean merged cycle kernel (four workgroups per CU); COEVO_HEAVY_ROWS=32
+        # keeps the 32-row tiles for A/B runs
+        heavy_rows = int(os.environ.get("COEVO_HEAVY_ROWS", "16")) if env == "device" else 32
+        self.plan = RolloutPlan(np.array(games), net_off, net_D, device=device, heavy_rows=heavy_rows,
                                 n_cohorts=cohorts if env == "device" else 1)
         if env == "device":
             self.ro = DeviceRollout(self.plan, self.slab, env_seed=env_seed, timing_pairs=timing_pairs)

@@ -183,13 +183,15 @@ int coevo_mpe_policy_cycle_fused(const float *slab, const coevo_fc_task *tasks, 
  * coevo_mpe_policy_cycle_fused launches (replaces the per-agent-step forward of utils/game_logic_functions.py:152-163
  * for every row of the cohort at once).  The kernel holds two workgroups per CU; when the workgroups of
  * `concurrent_launches` such launches (cohorts running side by side, else 1) exceed those slots, a streaming workgroup
- * carries two nets so that everything is resident in one round. */
+ * carries two nets so that everything is resident in one round.  heavy_max_rows <= 16 selects the lean kernel (four
+ * workgroups per CU, 16-row shared-opponent tiles) when everything then fits at one net per workgroup. */
 int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_task *heavy_tasks, int n_heavy,
                                   const coevo_fc_task *light_tasks, int n_light, int light_max_rows,
                                   const double *state_prev, double *state_next, int n_games,
                                   const int32_t *row_game, const int32_t *row_slot, const int32_t *act_prev,
                                   int32_t *act_cur, const int32_t *game_limit, int cycle, int pos_first,
-                                  int32_t *status, uint64_t *stamps, int concurrent_launches, void *stream);
+                                  int32_t *status, uint64_t *stamps, int concurrent_launches, int heavy_max_rows,
+                                  void *stream);
 int coevo_mpe_final_step(const double *state, int n_games, const int32_t *actions_by_game, int cycle,
                          const int32_t *game_limit, int pos_first, double *rewards, void *stream);
 

@@ -22,7 +22,8 @@ for i in range(2):
     ro.run(eng.n_cycles)
 torch.cuda.synchronize()
 nh, nl = len(eng.plan.heavy_np), len(eng.plan.light_np)
-n = nh + (nl + 1) // 2 if nh + nl > 512 else nh + nl
+lean = eng.plan.heavy_max <= 16 and nh + nl <= 1024
+n = nh + nl if lean else (nh + (nl + 1) // 2 if nh + nl > 512 else nh + nl)
 dll.coevo_debug_read_phase_stamps.argtypes = [C.c_void_p, C.c_int]
 buf = (C.c_ulonglong * (n * 8))()
 assert dll.coevo_debug_read_phase_stamps(buf, n * 8) == 0
