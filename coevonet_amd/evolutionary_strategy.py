@@ -16,6 +16,7 @@ rng modes
 """
 from __future__ import annotations
 
+import os
 import time
 
 import numpy as np
@@ -65,7 +66,8 @@ class ESEngine:
         # They get their own 10-game rollout after each update.
         eval_games = [(net("base", "adversary_0"), net("base", "agent_0"), net("base", "agent_1"))] * N_EVAL
         cls = DeviceRollout if env == "device" else HostEnvRollout
-        self.plan = RolloutPlan(np.array(games), net_off, net_D, device=device)
+        heavy_rows = int(os.environ.get("COEVO_HEAVY_ROWS", "32"))
+        self.plan = RolloutPlan(np.array(games), net_off, net_D, device=device, heavy_rows=heavy_rows)
         self.ro = cls(self.plan, self.slab, env_seed=env_seed)
         self.eval_plan = RolloutPlan(np.array(eval_games), net_off, net_D, device=device)
         self.eval_ro = cls(self.eval_plan, self.slab, env_seed=env_seed)
