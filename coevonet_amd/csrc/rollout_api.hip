@@ -81,6 +81,15 @@ extern "C" int coevo_rollout_ctx_reserve_cohorts(void *ctx, int n_cohorts)
     return COEVO_OK;
 }
 
+// the stream cohort k (>= 1) of this context runs on (cohort 0 runs on the caller's stream): for callers that enqueue
+// per-cohort work (breeding, resets) in front of a cohort's chain themselves
+extern "C" void *coevo_rollout_ctx_cohort_stream(void *ctx, int k)
+{
+    auto *c = static_cast<coevo_rollout_ctx *>(ctx);
+    if (!c || k < 1 || k > (int)c->lanes.size()) return nullptr;
+    return c->lanes[k - 1].s;
+}
+
 extern "C" int coevo_rollout_ctx_reset_timing(void *ctx)
 {
     auto *c = static_cast<coevo_rollout_ctx *>(ctx);
@@ -166,7 +175,7 @@ extern "C" int coevo_mpe_rollout(const coevo_rollout_desc *d, void *ctx, int tim
                     d->slab, heavy, n_heavy, light, n_light, d->light_max_rows, st_prev, st_next, d->n_games, d->row_game,
                     d->row_slot, act_prev, act_cur, d->game_limit, cyc, d->pos_first, d->status,
                     d->light_stamps ? d->light_stamps + 2 * COEVO_STAMP_SLOTS * ((size_t)k * d->n_cycles + cyc) : nullptr,
-                    K, d->heavy_max_rows, ls);
+                    d->concurrent_hint > K ? d->concurrent_hint : K, d->heavy_max_rows, ls);
                 if (rc) return rc;
                 continue;
             }
@@ -219,7 +228,8 @@ extern "C" int coevo_mpe_rollout(const coevo_rollout_desc *d, void *ctx, int tim
         }
     }
     if (fused) {
-        if (!d->rewards) return COEVO_ERR_ARG;
+        if (!d->rewards) return COEVO_OK;  // the caller closes the rollout itself (coevo_mpe_final_step), e.g. after
+                                            // several per-cohort calls on different streams
         const int last = d->n_cycles - 1;  // -1: no cycle ran, the books are the reset state's zeros
         const double *st_last = (last <= 0) ? d->state : ((last & 1) ? d->state_alt : d->state);
         return coevo_mpe_final_step(st_last, d->n_games, d->actions_by_game + (size_t)((last < 0 ? 0 : last) & 1) * act_stride,

@@ -130,8 +130,19 @@ class GAEngine:
         # 16-row shared-opponent tasks select the lean merged cycle kernel (four workgroups per CU); COEVO_HEAVY_ROWS=32
         # keeps the 32-row tiles for A/B runs
         heavy_rows = int(os.environ.get("COEVO_HEAVY_ROWS", "16")) if env == "device" else 32
-        self.plan = RolloutPlan(np.array(games), net_off, net_D, device=device, heavy_rows=heavy_rows,
-                                n_cohorts=cohorts if env == "device" else 1)
+        # cohorts = contiguous ranges of this rank's individuals (so that offspring can be bred cohort by cohort and a
+        # cohort's chain can start while the next cohort is still being bred); the evaluation games go with the last
+        self.K = max(1, min(int(cohorts), self.n_local)) if env == "device" else 1
+        game_cohort = None
+        if self.K > 1:
+            per_ind = np.repeat((np.arange(self.n_local) * self.K) // self.n_local, self.hof)
+            game_cohort = np.concatenate([per_ind, per_ind, per_ind, np.full(N_EVAL, self.K - 1)]).astype(np.int32)
+        try:
+            self.plan = RolloutPlan(np.array(games), net_off, net_D, device=device, heavy_rows=heavy_rows,
+                                    n_cohorts=self.K, game_cohort=game_cohort)
+        except ValueError:  # tiny populations: the shared opponents have so few rows that they tie all games together
+            self.K = 1
+            self.plan = RolloutPlan(np.array(games), net_off, net_D, device=device, heavy_rows=heavy_rows)
         if env == "device":
             self.ro = DeviceRollout(self.plan, self.slab, env_seed=env_seed, timing_pairs=timing_pairs)
         else:
@@ -162,6 +173,8 @@ class GAEngine:
         return flat  # keep alive until the stream has consumed it
 
     def download(self, role, region, first, n):
+        if region == "pop":
+            self.flush_breeding()
         out = torch.zeros(n, self.P[role], dtype=torch.float32, device=self.device)
         L.call("coevo_fc_unpack", self._ptr(role, region, first), L._p(out), n, ROLE_D[role])
         return out.cpu().numpy()
@@ -342,6 +355,7 @@ class GAEngine:
                    L._p(self.dist[r]))
         # argument blocks of the fused selection / promotion launches (one launch for the three roles)
         self.fused_tail = self.E <= 8 and self.hof <= 16 and self.pop <= 4096
+        self.pipelined = os.environ.get("COEVO_PIPELINED", "1") != "0"   # breed / reset / roll out cohort by cohort
 
     def _select_roles(self, rewards_ptr_of, game_first_of, games_per_individual):
         roles = (L.GaSelectRole * 3)()
@@ -377,7 +391,7 @@ class GAEngine:
         L.call("coevo_mpe_reset_gen", L._p(ro.state), self.plan.n_games, self.n_main, N_EVAL, ro.rng,
                self.first_ordinal - per_gen + M, g, per_gen)
 
-    def _enqueue_selection_and_breeding(self):
+    def _enqueue_selection_and_breeding(self, breed=True):
         """(Measured: running the three roles' chains as parallel graph branches gains 1 % in the split loop and costs
         30 % inside the single whole-generation graph - this runtime schedules branched graphs badly; kept serial.)"""
         ro, M = self.ro, 3 * self.pop * self.hof
@@ -403,13 +417,104 @@ class GAEngine:
                 self._hof_push(r)
                 L.call("coevo_fc_gather", self._ptr(r, "elite"), L._p(self.iota), self._ptr(r, "pop"), 0, 1, D)
                 L.call("coevo_gather_f32", L._p(self.best_dist[r]), L._p(self.dist[r]), L._p(self.order[r]), 1)
-            if self.pop > 1:
+            if self.pop > 1 and breed:
                 L.call("coevo_fc_perturb_dist", self._ptr(r, "elite"), L._p(self.parent_idx), self._ptr(r, "pop"), 1,
                        self.pop - 1, D, self.sigma32.data_ptr() + 4 * ri, self.philox_seed, 0, ri, 0, g,
                        self._ptr(r, "stale"), L._p(self.dist_partial[r]))
                 L.call("coevo_fc_distance_finalize", L._p(self.dist_partial[r]), self.pblocks[r], self.pop - 1,
                        L._p(self.dist[r]), 1, L._p(self.best_dist[r]))
         L.call("coevo_counter_add", g, 1)
+
+    # ------------------------------------------------------------------ pipelined generation (cohort by cohort)
+    def _cohort_individuals(self, k):
+        return self.lo + k * self.n_local // self.K, self.lo + (k + 1) * self.n_local // self.K
+
+    def _breed_cohort(self, k, noise_gen):
+        """children of the individuals of cohort k (child c = individual c + 1; individual 0 is the unchanged best),
+        bred from the elites of generation `noise_gen` with that generation's noise streams"""
+        lo_k, hi_k = self._cohort_individuals(k)
+        c_lo, c_hi = max(lo_k, 1) - 1, hi_k - 1
+        for ri, r in enumerate(ROLES):
+            D = ROLE_D[r]
+            if c_hi > c_lo:
+                part = self.dist_partial[r].data_ptr() + 8 * c_lo * self.pblocks[r]
+                L.call("coevo_fc_perturb_dist", self._ptr(r, "elite"), self.parent_idx.data_ptr() + 4 * c_lo,
+                       self._ptr(r, "pop"), 1 + c_lo, c_hi - c_lo, D, self.sigma32.data_ptr() + 4 * ri,
+                       self.philox_seed, c_lo, noise_gen * 4 + ri, 0, None, self._ptr(r, "stale"), part)
+                L.call("coevo_fc_distance_finalize", part, self.pblocks[r], c_hi - c_lo, L._p(self.dist[r]), 1 + c_lo,
+                       L._p(self.best_dist[r]) if c_lo == 0 else None)
+            elif lo_k == 0:
+                self.dist[r][0:1].copy_(self.best_dist[r])
+
+    def _reset_cohort(self, k, gen):
+        lo_k, hi_k = self._cohort_individuals(k)
+        base, M = self._ordinal_base(gen), 3 * self.pop * self.hof
+        per_phase = self.n_local * self.hof
+        for ph in range(3):
+            self.ro.reset(ph * per_phase + (lo_k - self.lo) * self.hof, (hi_k - lo_k) * self.hof,
+                          base + ph * self.pop * self.hof + lo_k * self.hof)
+        if k == self.K - 1 and gen > 0:
+            self.ro.reset(self.n_main, N_EVAL, self._ordinal_base(gen - 1) + M)
+
+    def flush_breeding(self):
+        """the pipelined loop breeds generation g+1's population at the start of call g+1; anything that reads the
+        population slab before that (export, tests) asks for it here"""
+        if getattr(self, "_breeding_pending", False):
+            torch.cuda.synchronize()
+            for k in range(self.K):
+                self._breed_cohort(k, self.generation_enqueued - 1)
+            torch.cuda.synchronize()
+            self._breeding_pending = False
+
+    def replay_generation_pipelined(self, gen):
+        """Generation `gen`, cohort by cohort: cohort k's stream breeds ITS children (deferred from the previous
+        generation's selection), resets its games and runs its 25-cycle chain; the caller's stream then closes the
+        rollout and replays the selection graph.  Cohort k+1 is still breeding (Philox / Box-Muller: compute-bound)
+        while cohort k's chain already streams weights, and the chains start a breeding time apart, which is the stagger
+        they want anyway.  The host knows `gen`; sigma, ranks and distances stay on the device."""
+        assert self.world == 1 and self.env_mode == "device" and self.fused_tail and self.K > 1
+        ro = self.ro
+        if gen <= 1:  # the evaluation games of "generation -1" do not exist: disabled in generation 0 only
+            limits = np.zeros(self.plan.n_games, dtype=np.int32)
+            limits[:self.n_main] = self.T_train
+            if gen == 1:
+                limits[self.n_main:] = self.T_eval
+            ro.set_limits(limits)
+        main = torch.cuda.current_stream()
+        if getattr(self, "_cohort_streams", None) is None:
+            # cohort 0 on the caller's stream, the others on the rollout context's own lane streams (streams from
+            # torch's pool did not overlap with each other here: 356 vs 510 generations/s)
+            self._cohort_streams = [main] + [
+                torch.cuda.ExternalStream(L.load().coevo_rollout_ctx_cohort_stream(ro.ctx, k), device=self.device)
+                for k in range(1, self.K)]
+            self._cohort_done = [torch.cuda.Event() for _ in range(self.K)]
+            self._tail_done = torch.cuda.Event()
+            self._tail_graph = None
+            self._breeding_pending = False
+        self._tail_done.record(main)  # everything enqueued so far (the previous tail, or the initial uploads)
+        for k, s in reversed(list(enumerate(self._cohort_streams))):  # the caller's stream (cohort 0) last
+            if k:
+                s.wait_event(self._tail_done)
+            with torch.cuda.stream(s):
+                if self._breeding_pending:
+                    self._breed_cohort(k, gen - 1)
+                self._reset_cohort(k, gen)
+                ro.enqueue_cohort(k, self.n_cycles, s)
+            if k:
+                self._cohort_done[k].record(s)
+        self._breeding_pending = False
+        for ev in self._cohort_done[1:]:
+            main.wait_event(ev)
+        ro.enqueue_final_step(self.n_cycles)
+        if self._tail_graph is None:
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                self._enqueue_selection_and_breeding(breed=False)
+            self._tail_graph = gr
+        self._tail_graph.replay()
+        self._breeding_pending = self.pop > 1
+        self.generation_enqueued = gen + 1
 
     def step_sharded(self, gen):
         """One generation of the population-sharded run (world > 1) without a host round trip: the same launches as
@@ -488,6 +593,8 @@ class GAEngine:
             if gen == 1:
                 limits[self.n_main:] = self.T_eval
             self.ro.set_limits(limits)
+        if self.ro.use_graph and self.ro.n_cohorts > 1 and self.fused_tail and self.pipelined:
+            return self.replay_generation_pipelined(gen)
         if self.ro.use_graph and self.ro.n_cohorts > 1:
             # cohort chains only run side by side when their launches are enqueued eagerly on their own streams (inside a
             # captured graph this runtime schedules them no better than one chain): the resets and the selection /
@@ -659,6 +766,7 @@ class GATrainer:
         """flush the last generation's evaluation games and leave the env's reset counter where the reference would"""
         if self.gen > 0:
             if self.device_loop or self.sharded_loop:
+                self.eng.flush_breeding()
                 torch.cuda.synchronize()
                 self.eng.ro.check_status()
                 self._sync_history_from_device(upto=self.gen - 1)

@@ -51,7 +51,7 @@ class RolloutDesc(C.Structure):
                 ("rewards", C.c_void_p), ("pos_first", C.c_int32), ("n_cohorts", C.c_int32),
                 ("state_alt", C.c_void_p), ("actions_by_game", C.c_void_p), ("light_stamps", C.c_void_p),
                 ("heavy_begin", C.c_void_p), ("light_begin", C.c_void_p),
-                ("merged", C.c_int32), ("reserved", C.c_int32)]
+                ("merged", C.c_int32), ("concurrent_hint", C.c_int32)]
 
 
 class GaSelectRole(C.Structure):
@@ -91,6 +91,7 @@ _SIGS = {
     "coevo_ga_select": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "coevo_ga_promote": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "coevo_rollout_ctx_reserve_cohorts": (C.c_int, [C.c_void_p, C.c_int]),
+    "coevo_rollout_ctx_cohort_stream": (C.c_void_p, [C.c_void_p, C.c_int]),
     "coevo_rollout_ctx_reset_timing": (C.c_int, [C.c_void_p]),
     "coevo_rollout_ctx_light_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "coevo_mpe_rollout": (C.c_int, [C.POINTER(RolloutDesc), C.c_void_p, C.c_int, C.c_void_p]),

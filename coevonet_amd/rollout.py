@@ -28,7 +28,8 @@ class RolloutPlan:
     """game_nets: int array [n_games][3] of net ids for env slots (adversary_0, agent_0, agent_1);
     net_off / net_D: per net id, float offset inside the slab and observation width."""
 
-    def __init__(self, game_nets, net_off, net_D, device="cuda", heavy_rows=HEAVY_ROWS, n_cohorts=1):
+    def __init__(self, game_nets, net_off, net_D, device="cuda", heavy_rows=HEAVY_ROWS, n_cohorts=1,
+                 game_cohort=None):
         game_nets = np.asarray(game_nets, dtype=np.int64)
         self.n_games = int(game_nets.shape[0])
         by_net = {}
@@ -39,7 +40,18 @@ class RolloutPlan:
             d = int(net_D[net])
             for g, slot in rows:
                 assert d == (8 if slot == 0 else 10), "net width does not match the env slot it plays"
-        cohort = self._assign_cohorts(by_net, self.n_games, max(1, int(n_cohorts)))
+        if game_cohort is not None:
+            # the caller's own partition (e.g. contiguous ranges of individuals, so that offspring can be bred cohort by
+            # cohort); it must keep every per-individual net's games together
+            cohort = np.asarray(game_cohort, dtype=np.int32)
+            assert cohort.shape == (self.n_games,) and cohort.min() >= 0
+            for net, rows in by_net.items():
+                if len(rows) <= LIGHT_ROWS and len({int(cohort[g]) for g, _ in rows}) != 1:
+                    raise ValueError("a net with few rows (one task) plays in two cohorts: this partition is not valid")
+            if len(np.unique(cohort)) != int(cohort.max()) + 1:
+                raise ValueError("empty cohort")
+        else:
+            cohort = self._assign_cohorts(by_net, self.n_games, max(1, int(n_cohorts)))
         self.n_cohorts = int(cohort.max()) + 1 if self.n_games else 1
         self.game_cohort_np = cohort
         light = [[] for _ in range(self.n_cohorts)]
@@ -261,6 +273,37 @@ class DeviceRollout:
         L.call("coevo_mpe_rollout", L.C.byref(self.desc), self.ctx if (self.overlap or self.n_cohorts > 1) else None, 0)
         if self.time_light:
             self._pending_stamps = int(n_cycles)
+
+    def enqueue_cohort(self, k, n_cycles, stream):
+        """the cycle chain of cohort k alone on `stream` (a torch stream), without the closing step: callers that breed
+        and reset cohort by cohort run one such call per cohort on its own stream, then enqueue_final_step() once"""
+        assert self.n_cohorts > 1 and self.desc.merged
+        p = self.plan
+        hb, he = int(p.heavy_begin_np[k]), int(p.heavy_begin_np[k + 1])
+        lb, le = int(p.light_begin_np[k]), int(p.light_begin_np[k + 1])
+        tsz = L.TASK_DTYPE.itemsize
+        d = L.RolloutDesc()
+        L.C.memmove(L.C.byref(d), L.C.byref(self.desc), L.C.sizeof(d))
+        d.heavy = (p.heavy.data_ptr() + hb * tsz) if he > hb else None
+        d.n_heavy = he - hb
+        d.light = (p.light.data_ptr() + lb * tsz) if le > lb else None
+        d.n_light = le - lb
+        d.n_cohorts, d.heavy_begin, d.light_begin = 0, None, None
+        d.concurrent_hint = self.n_cohorts
+        d.n_cycles = int(n_cycles)
+        d.rewards = None
+        d.light_stamps = (self.stamps.data_ptr() + 16 * L.STAMP_SLOTS * k * int(n_cycles)) if self.time_light else None
+        L._check(L.load().coevo_mpe_rollout(L.C.byref(d), self.ctx, 0, stream.cuda_stream), "coevo_mpe_rollout")
+        if self.time_light:
+            self._pending_stamps = int(n_cycles)
+
+    def enqueue_final_step(self, n_cycles):
+        """close the books of a rollout whose chains were enqueued with enqueue_cohort (current stream)"""
+        n, last = self.plan.n_games, int(n_cycles) - 1
+        st_last = self.state2[0] if last <= 0 or (last & 1) == 0 else self.state2[1]
+        act = self.actions_by_game[(last if last > 0 else 0) & 1]
+        L.call("coevo_mpe_final_step", L._p(st_last), n, L._p(act), last, L._p(self.limits), self.pos_first,
+               L._p(self.rewards))
 
     def collect_stamps(self):
         """after the replay has finished (the caller synchronised): fold this replay's clock stamps into the log"""

@@ -132,7 +132,7 @@ typedef struct {
     const int32_t *row_game; const int32_t *row_slot; const int32_t *game_rows;
     int32_t *actions; int32_t *status;
     const int32_t *game_limit;   /* per game agent-step limit, or NULL */
-    double *rewards;             /* [n_games][3] or NULL */
+    double *rewards;             /* [n_games][3] or NULL (fused step: NULL = no closing coevo_mpe_final_step) */
     int32_t pos_first;
     int32_t n_cohorts;           /* 0/1: one lock-step chain.  K > 1: the games are partitioned into K cohorts whose
                                     cycle chains are independent (no task of one cohort touches a game of another);
@@ -153,13 +153,16 @@ typedef struct {
     const int32_t *light_begin;
     int32_t merged;              /* fused env step only: a cohort's cycle is ONE launch (coevo_mpe_policy_cycle_merged)
                                     instead of the shared-opponent launch beside / before the per-individual one */
-    int32_t reserved;
+    int32_t concurrent_hint;     /* how many such rollouts the caller runs side by side on other streams (one call per
+                                    cohort); 0 = none.  Only sizes the merged launch (coevo_mpe_policy_cycle_merged) */
 } coevo_rollout_desc;
 #define COEVO_MAX_COHORTS 8
 void *coevo_rollout_ctx_create(int n_timing_pairs);
 void coevo_rollout_ctx_destroy(void *ctx);
 /* create the streams for rollouts with up to n_cohorts cohorts; must not be called during graph capture */
 int coevo_rollout_ctx_reserve_cohorts(void *ctx, int n_cohorts);
+/* the hipStream_t cohort k >= 1 runs on (NULL for k = 0: the caller's stream, or when k was not reserved) */
+void *coevo_rollout_ctx_cohort_stream(void *ctx, int k);
 int coevo_rollout_ctx_reset_timing(void *ctx);
 int coevo_rollout_ctx_light_times(void *ctx, float *host_ms_out, int max_out);  /* returns the count; blocks */
 int coevo_mpe_rollout(const coevo_rollout_desc *desc, void *ctx, int time_light, void *stream);
