@@ -212,6 +212,8 @@ def main():
                              "rollout_span_ms": span_ms, "launches": K * eng.ro._span_cycles,
                              "note": "algorithmic bytes of every policy launch of one rollout / (first workgroup start "
                                      ".. last workgroup end of the rollout)"}
+            lean = merged and eng.plan.heavy_max <= 16
+            kernel_id = ("fc_cycle16_kernel<5>" if lean else "fc_cycle_kernel<5") if merged else "fc_policy_kernel<5, 2>"
             traffic, traffic_note = None, None
             pmc = os.path.join(REPO, "profiles", "r01_pmc_hbm_traffic.json")
             if a.pop_per_gpu == 200 and a.hof == 5 and os.path.exists(pmc):
@@ -219,12 +221,13 @@ def main():
                 # passes of this same command, gfx950 correction applied) - collected offline, see the file
                 with open(pmc) as f:
                     j = json.load(f)
-                want = "fc_cycle_kernel<5>" if merged else "fc_policy_kernel<5, 2>"
+                want = kernel_id
                 if want in j.get("dominant_kernel", ""):
                     traffic = j["dominant_kernel_hbm_bytes_per_launch"]
                     traffic_note = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc passes of this command)"
-            kname = ("fc_cycle_kernel<5> (one env-cycle: per-individual weight sets streamed once + shared-opponent "
-                     "tasks on the matrix cores, fused env step)" if merged else
+            kname = ((kernel_id.rstrip("<5") if not lean else kernel_id) +
+                     " (one env-cycle of one cohort: per-individual weight sets streamed once + shared-opponent tasks "
+                     "on the matrix cores, fused env step)" if merged else
                      "fc_policy_kernel<5, 2> (per-individual weight sets, fused env step)")
             out["roofline"] = {"bound": "hbm", "kernel": kname,
                                "timing": ("HIP events around each launch on its stream" if a.no_graph else
