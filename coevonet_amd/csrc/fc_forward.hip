@@ -275,6 +275,8 @@ __device__ __forceinline__ void fc_policy_body(const FcArgs &a, FcSmem<R, P> &sm
 
     // ---- fc2 on the matrix cores: lane owns output column 64w + l; its streamed 16-byte piece is W2[64w + l][4q..4q+3],
     //      used as is as the B operand of four v_mfma_f32_4x4x1_16B_f32 per row group ------------------------------
+    // (Measured: a single left-over row - R = 5 - as VALU FMAs instead of a second 4-row MFMA group halves these
+    // workgroups' matrix-pipe use but its serial fma chain and extra broadcast read cost more: 449 vs 516.)
     typedef float f32x4_acc __attribute__((ext_vector_type(4)));
     constexpr int NG = FcSmem<R, P>::NG;
     f32x4_acc acc[P][NG];  // acc[p][g][i]: row 4g + i of net p, column 64w + l
