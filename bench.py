@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-device-loop", action="store_true", help="drive every generation from the host (the code path "
                     "the sharded multi-GPU run uses), also on one GPU")
+    ap.add_argument("--max-cycles", type=int, default=25, help="world steps before the env truncates a game; 25 is what "
+                    "the reference constructs (75 agent-steps per game); >= 67 lets T=200 bind (SURVEY 8d, cfg 2-T200)")
     ap.add_argument("--sharded-path", action="store_true", help="run the population-sharded loop (what --gpus N > 1 "
                     "uses) even on one GPU: its per-GPU cost without the all-gather")
     ap.add_argument("--cohorts", type=int, default=None, help="independent game cohorts per rollout (default: the "
@@ -142,6 +144,7 @@ def main():
     if a.sharded_path:
         args.coevo_force_sharded_loop = True
     env = initialize_env(args)
+    env.max_cycles = a.max_cycles
     tr = GATrainer(env, args, rng="device_philox", env_mode=a.env, collect=False, dist_ctx=ctx)
     eng = tr.eng
 
@@ -180,8 +183,10 @@ def main():
         "n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"Co-GA simple_adversary_v3 pop={pop} ({a.pop_per_gpu}/GPU) HoF={a.hof} "
-                               f"elites={a.elites} T={a.limit} (env max_cycles=25 caps a game at 75 agent-steps, as in "
-                               f"the reference), fitness sharing, adaptive sigma",
+                               f"elites={a.elites} T={a.limit} (env max_cycles={a.max_cycles} caps a game at "
+                               f"{3 * a.max_cycles} agent-steps" + (", as in the reference" if a.max_cycles == 25 else
+                                                                     ": the T=200 variant, SURVEY 8d cfg 2-T200") +
+                               "), fitness sharing, adaptive sigma",
                    "population": pop, "hof": a.hof, "games_per_generation": 3 * pop * a.hof + 10,
                    "agent_steps_per_generation": steps_per_gen, "env": a.env, "offspring": "device_philox",
                    "parallelism": f"population shard x{ctx.world}" if ctx.world > 1 else "single GPU"},
@@ -238,6 +243,11 @@ def main():
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
                                "launches_timed": len(d), "concurrent_launches": K, "rollout_aggregate": aggregate}
+            # SURVEY 8d's per-generation form: every distinct weight set that acts, once per env-cycle, over the whole
+            # generation (selection, breeding and the perturb kernel's own 0.67 GB of writes are not in the numerator)
+            gen_bytes = alg_bytes * K * eng.n_cycles
+            out["roofline"]["generation"] = {"algorithmic_bytes": gen_bytes, "achieved": gen_bytes * gens_per_s / 1e9,
+                                             "frac": gen_bytes * gens_per_s / 1e9 / HBM_PEAK_GBS}
         if not a.no_cpu_baseline and ctx.world == 1:
             out["cpu_baseline"] = cpu_baseline(a.pop_per_gpu, a.hof, a.limit)
             try:

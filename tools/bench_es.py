@@ -22,5 +22,9 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps):
     tr.step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
+P = {"agent_0": 559124, "agent_1": 559124, "adversary_0": 555028}
+cyc = tr.eng.plan and (tr.eng.T_train + 2) // 3
+gb = sum(a.pop * (1 + cyc) * b for b in P.values()) / 1e9   # materialise-once model of SURVEY 8d: write n*4P, read C*n*4P
+print(f"  materialise-once bytes {gb:.1f} GB/generation -> {gb / dt / 1e3:.2f} TB/s = {gb / dt / 8000:.2f} of the 8 TB/s peak")
 print(f"Co-ES pop={a.pop}: {1/dt:.2f} generations/s, {dt*1e3:.2f} ms/generation, "
       f"{tr.eng.steps_per_generation/dt/1e6:.1f} M agent-steps/s; tasks light {len(tr.eng.plan.light_np)} heavy {len(tr.eng.plan.heavy_np)}")
