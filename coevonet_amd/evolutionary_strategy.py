@@ -67,7 +67,9 @@ class ESEngine:
         eval_games = [(net("base", "adversary_0"), net("base", "agent_0"), net("base", "agent_1"))] * N_EVAL
         cls = DeviceRollout if env == "device" else HostEnvRollout
         heavy_rows = int(os.environ.get("COEVO_HEAVY_ROWS", "32"))
-        self.plan = RolloutPlan(np.array(games), net_off, net_D, device=device, heavy_rows=heavy_rows)
+        es_cohorts = int(os.environ.get("COEVO_ES_COHORTS", "2")) if env == "device" else 1  # 114 vs 109 generations/s at cfg3
+        self.plan = RolloutPlan(np.array(games), net_off, net_D, device=device, heavy_rows=heavy_rows,
+                                n_cohorts=es_cohorts)
         self.ro = cls(self.plan, self.slab, env_seed=env_seed)
         self.eval_plan = RolloutPlan(np.array(eval_games), net_off, net_D, device=device)
         self.eval_ro = cls(self.eval_plan, self.slab, env_seed=env_seed)
@@ -110,7 +112,10 @@ class ESEngine:
             ro.reset(0, self.n_main, self._ordinal_base(gen))
         else:
             ro.reset_from_ordinals(self._ordinal_base(gen) + np.arange(self.n_main))
-        ro.run((self.T_train + 2) // 3)
+        if getattr(ro, "n_cohorts", 1) > 1:
+            ro.enqueue((self.T_train + 2) // 3)  # cohort chains overlap only when enqueued eagerly
+        else:
+            ro.run((self.T_train + 2) // 3)
 
     def evaluate(self, gen):
         """evaluate_current_weights: 10 games of the current base trio -> mean reward triple (:22-59, :272)"""
