@@ -203,22 +203,27 @@ def main():
                 for t in arr:
                     nets[int(t["net_off"])] = L.fc_param_count(int(t["D"])) * 4
                     rows += int(t["n_rows"])
-            alg_bytes = (sum(nets.values()) + rows * (4 * 10 + 4)) / max(eng.ro.n_cohorts, 1)
+            cycle_bytes = sum(nets.values()) + rows * (4 * 10 + 4)   # all cohorts, one env-cycle
+            persistent = bool(getattr(eng.ro, "_persistent_cycles", 0))
+            # a launch = one cohort's env-cycle, or (persistent rollout kernel) the whole rollout of all cohorts
+            alg_bytes = cycle_bytes * eng.n_cycles if persistent else cycle_bytes / max(eng.ro.n_cohorts, 1)
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-            K = max(eng.ro.n_cohorts, 1)
+            K = 1 if persistent else max(eng.ro.n_cohorts, 1)
             aggregate = None
             if getattr(eng.ro, "_span_ms", None):
                 # all policy launches of a rollout together: bytes of every launch / (first start .. last end); with one
                 # cohort this is the per-launch figure minus the inter-launch gaps, with K cohorts it accounts for the
                 # launches that run side by side
                 span_ms = float(np.mean(eng.ro._span_ms))
-                tot = alg_bytes * K * eng.ro._span_cycles
+                tot = alg_bytes if persistent else alg_bytes * K * eng.ro._span_cycles
                 aggregate = {"achieved": tot / (span_ms * 1e-3) / 1e9, "frac": tot / (span_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "rollout_span_ms": span_ms, "launches": K * eng.ro._span_cycles,
+                             "rollout_span_ms": span_ms, "launches": 1 if persistent else K * eng.ro._span_cycles,
                              "note": "algorithmic bytes of every policy launch of one rollout / (first workgroup start "
                                      ".. last workgroup end of the rollout)"}
             lean = merged and eng.plan.heavy_max <= 16
             kernel_id = ("fc_cycle16_kernel<5>" if lean else "fc_cycle_kernel<5") if merged else "fc_policy_kernel<5, 2>"
+            if persistent:
+                kernel_id = "fc_rollout16_kernel<5>"
             traffic, traffic_note = None, None
             pmc = os.path.join(REPO, "profiles", "r01_pmc_hbm_traffic.json")
             if a.pop_per_gpu == 200 and a.hof == 5 and os.path.exists(pmc):
@@ -231,8 +236,10 @@ def main():
                     traffic = j["dominant_kernel_hbm_bytes_per_launch"]
                     traffic_note = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc passes of this command)"
             kname = ((kernel_id.rstrip("<5") if not lean else kernel_id) +
-                     " (one env-cycle of one cohort: per-individual weight sets streamed once + shared-opponent tasks "
-                     "on the matrix cores, fused env step)" if merged else
+                     (" (the whole rollout in one persistent launch: per env-cycle every per-individual weight set "
+                      "streamed once + shared-opponent tasks on the matrix cores, fused env step)" if persistent else
+                      " (one env-cycle of one cohort: per-individual weight sets streamed once + shared-opponent tasks "
+                      "on the matrix cores, fused env step)") if merged else
                      "fc_policy_kernel<5, 2> (per-individual weight sets, fused env step)")
             out["roofline"] = {"bound": "hbm", "kernel": kname,
                                "timing": ("HIP events around each launch on its stream" if a.no_graph else
@@ -245,7 +252,7 @@ def main():
                                "launches_timed": len(d), "concurrent_launches": K, "rollout_aggregate": aggregate}
             # SURVEY 8d's per-generation form: every distinct weight set that acts, once per env-cycle, over the whole
             # generation (selection, breeding and the perturb kernel's own 0.67 GB of writes are not in the numerator)
-            gen_bytes = alg_bytes * K * eng.n_cycles
+            gen_bytes = cycle_bytes * eng.n_cycles
             out["roofline"]["generation"] = {"algorithmic_bytes": gen_bytes, "achieved": gen_bytes * gens_per_s / 1e9,
                                              "frac": gen_bytes * gens_per_s / 1e9 / HBM_PEAK_GBS}
         if not a.no_cpu_baseline and ctx.world == 1:

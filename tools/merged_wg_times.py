@@ -19,15 +19,18 @@ eng, ro = tr.eng, tr.eng.ro
 tr.step()
 ro.use_graph = False
 for i in range(2):
-    ro.run(eng.n_cycles)
+    if ro.persistent_ok():
+        ro.enqueue_persistent(eng.n_cycles)
+    else:
+        ro.run(eng.n_cycles)
 torch.cuda.synchronize()
 nh, nl = len(eng.plan.heavy_np), len(eng.plan.light_np)
 lean = eng.plan.heavy_max <= 16 and nh + nl <= 1024
 n = nh + nl if lean else (nh + (nl + 1) // 2 if nh + nl > 512 else nh + nl)
 dll.coevo_debug_read_phase_stamps.argtypes = [C.c_void_p, C.c_int]
-buf = (C.c_ulonglong * (n * 8))()
-assert dll.coevo_debug_read_phase_stamps(buf, n * 8) == 0
-st = np.frombuffer(buf, dtype=np.uint64).reshape(n, 8).astype(np.int64)
+buf = (C.c_ulonglong * (n * 16))()
+assert dll.coevo_debug_read_phase_stamps(buf, n * 16) == 0
+st = np.frombuffer(buf, dtype=np.uint64).reshape(n, 16).astype(np.int64)
 t0 = st[:, 0].min()
 b, e = (st[:, 0] - t0) / 100.0, (st[:, 6] - t0) / 100.0   # us (100 MHz ticks)
 def desc(name, idx):
@@ -47,3 +50,17 @@ order = np.argsort(e)
 print("last 10 to finish:", [(int(i), "H" if i < nh else "L", round(float(b[i]), 1), round(float(e[i]), 1)) for i in order[-10:]])
 hist, edges = np.histogram(b[light], bins=12)
 print("light begin histogram (us):", list(zip(np.round(edges[:-1], 0).tolist(), hist.tolist())))
+
+if len(light):
+    f = st[light]
+    names = ["entry barrier -> fc1 done", "fc1 done -> sums written", "sums barrier", "mean/var/normalise (2 barriers)", "h1q write + barrier"]
+    idx = [(1, 8), (8, 9), (9, 10), (10, 11), (11, 12)]
+    for nm, (i, j) in zip(names, idx):
+        print(f"  light {nm:34s} {np.mean(f[:, j] - f[:, i]) / 100.0:6.2f} us")
+
+if st[:, 14].max() > 0:   # persistent rollout kernel: the last cycle's wait
+    wait = (st[:, 14] - st[:, 13]) / 100.0
+    print(f"persistent: wait for the cohort (last cycle) mean {wait.mean():.1f} us, min {wait.min():.1f}, max {wait.max():.1f}; "
+          f"body (stamp 0 -> 6) mean {np.mean(st[:, 6] - st[:, 0]) / 100.0:.1f} us")
+    print("  spin exit spread (us):", round(float(st[:, 14].max() - st[:, 14].min()) / 100.0, 1),
+          " body end spread:", round(float(st[:, 6].max() - st[:, 6].min()) / 100.0, 1))

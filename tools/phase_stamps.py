@@ -24,9 +24,9 @@ for rep in range(3):
     L.call("coevo_mpe_policy_cycle", L._p(ro.slab), L._p(p.heavy), nh, p.heavy_max, L._p(ro.state), p.n_games,
            L._p(p.row_game), L._p(p.row_slot), L._p(ro.actions), L._p(ro.status))
 torch.cuda.synchronize()
-buf = (C.c_ulonglong * (nh * 8))()
-assert dll.coevo_debug_read_phase_stamps(buf, nh * 8) == 0
-st = np.frombuffer(buf, dtype=np.uint64).reshape(nh, 8).astype(np.int64)
+buf = (C.c_ulonglong * (nh * 16))()
+assert dll.coevo_debug_read_phase_stamps(buf, nh * 16) == 0
+st = np.frombuffer(buf, dtype=np.uint64).reshape(nh, 16).astype(np.int64)
 d = np.diff(st[:, :7], axis=1)
 for i, nm in enumerate(["entry->obs staged", "fc1 (MFMA) + LN1 + h1 image", "fc2 (MFMA) stream", "LN2", "output chain", "argmax/store"]):
     print(f"  {nm:28s} {d[:, i].mean():9.0f}  (min {d[:, i].min():7d} max {d[:, i].max():7d})")
@@ -37,9 +37,9 @@ for n in (128, 256, 600):
         L.call("coevo_mpe_policy_cycle", L._p(ro.slab), L._p(p.light), n, p.light_max, L._p(ro.state), p.n_games,
                L._p(p.row_game), L._p(p.row_slot), L._p(ro.actions), L._p(ro.status))
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * (n * 8))()
-    assert dll.coevo_debug_read_phase_stamps(buf, n * 8) == 0
-    st = np.frombuffer(buf, dtype=np.uint64).reshape(n, 8).astype(np.int64)
+    buf = (C.c_ulonglong * (n * 16))()
+    assert dll.coevo_debug_read_phase_stamps(buf, n * 16) == 0
+    st = np.frombuffer(buf, dtype=np.uint64).reshape(n, 16).astype(np.int64)
     d = np.diff(st[:, :7], axis=1)
     print(f"--- {n} workgroups: mean cycles per phase (100 MHz realtime? no: shader clock via s_memtime)")
     for i, nm in enumerate(names):
