@@ -20,6 +20,9 @@
 
 namespace coevo {
 
+#ifndef COEVO_HEAVY16_U
+#define COEVO_HEAVY16_U 4  // 16-byte pieces per lane and buffer in the lean shared-opponent body (two buffers)
+#endif
 #ifndef COEVO_LIGHT_U
 #define COEVO_LIGHT_U 8   // 16-byte pieces per lane and buffer (two buffers in ping-pong)
 #endif
@@ -923,7 +926,7 @@ __device__ __forceinline__ void fc_policy_mfma16_body(const FcArgs &a, FcMfma16S
 #pragma unroll
             for (int i = 0; i < 4; ++i) c2[T][i] = p_b2[T];
         const float4 *wp = reinterpret_cast<const float4 *>(net + fc_off_w2(D)) + (size_t)w * 128 * 64 + l;
-        constexpr int U = 4;
+        constexpr int U = COEVO_HEAVY16_U;
         float4 bufA[U], bufB[U];
         auto issue = [&](float4 (&buf)[U], int kq) {
 #pragma unroll
