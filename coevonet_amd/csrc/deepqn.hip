@@ -10,7 +10,8 @@
 //                     BN statistics are reduced in the accumulator layout in the canonical tree order, activations stay
 //                     in LDS between layers; conv3's output goes to HBM as act[row][3136].
 //   dqn_fc1_kernel    the 6.4 MB fc1 matrix of each net is streamed exactly once per task (<= 16 rows): a grouped GEMV
-//                     like fc2 of the MPE net, [8][784][64][4] tiling, lane = output, activations as scalar broadcasts.
+//                     like fc2 of the MPE net, [8][784][64][4] tiling, lane = output, rows in groups of four on
+//                     v_mfma_f32_4x4x1_16B_f32 with the activations of a chunk staged in LDS.
 //   dqn_out_kernel    512 -> n logits, first-max action.
 // fp32 arithmetic follows the canonical order of oracle/coevo_oracle.c (taps in (ci,ky,kx) order, sequential-k fc
 // chains), so logits equal the oracle's bit for bit.
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(256) void dqn_conv_kernel(const float *slab, const 
 // memory-level parallelism has to come from depth).  The activations of a chunk (rows x 28 k-quads) are staged in LDS
 // with coalesced loads and read back as broadcasts (scalar loads of them serialise: 12 500 dependent s_loads per wave).
 constexpr int DQ_RMAX = 16;
+template <int NG>  // row groups of four the launch provides for (max rows per task rounded up)
 __global__ __launch_bounds__(64) void dqn_fc1_kernel(const float *slab, const coevo_dqn_task *tasks, int C,
                                                       int n_actions, const float *act, float *hid)
 {
@@ -272,39 +274,61 @@ __global__ __launch_bounds__(64) void dqn_fc1_kernel(const float *slab, const co
     const DqnLayout L = dqn_layout(C, n_actions);
     const int nrows = task.n_rows;
     const float bb = net[L.bf + 64 * ob + l];
-    float acc[DQ_RMAX];
+    // rows in groups of four on v_mfma_f32_4x4x1_16B_f32 (16 blocks x 4 columns = the wave's 64 outputs, one k per
+    // instruction; bit-identical to the fmaf chain, tools/mfma4_chain_probe.hip): the lane's streamed 16-byte piece is
+    // the B operand as is, the A operand x[4g + l%4][4q..4q+3] is one ds_read_b128 per group.  (As VALU FMAs fed by one
+    // LDS broadcast per row this kernel ran at 1.4 TB/s.)
+    typedef float f32x4_acc __attribute__((ext_vector_type(4)));
+    f32x4_acc acc[NG];
 #pragma unroll
-    for (int r = 0; r < DQ_RMAX; ++r) acc[r] = bb;
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[g][i] = bb;
     const float4 *wp = reinterpret_cast<const float4 *>(net + L.wf) + (size_t)ob * 784 * 64 + l;
     const float *arow = act + (size_t)task.row_begin * DQ_FC1_IN;
     for (int kq = 0; kq < 784; kq += U) {
         float4 wv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) wv[u] = wp[(size_t)(kq + u) * 64];
+        // the chunk's activations (rows x 28 float4 pieces, coalesced per row; pad rows: zeros): all requested at once,
+        // next to the weight loads (one iteration at a time they cost six serial memory latencies per chunk)
+        constexpr int XI = (4 * NG * U + 63) / 64;
+        float4 xr[XI];
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {
+            const int i = l + 64 * j, r = i / U, q = i % U;
+            xr[j] = (i < 4 * NG * U && r < nrows)
+                        ? *reinterpret_cast<const float4 *>(arow + (size_t)r * DQ_FC1_IN + 4 * (kq + q))
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         __syncthreads();  // the previous chunk's activations have been consumed
-        for (int i = l; i < nrows * U; i += 64) {  // rows x 28 float4 pieces, coalesced per row
-            const int r = i / U, q = i % U;
-            *reinterpret_cast<float4 *>(&xs[r][4 * q]) =
-                *reinterpret_cast<const float4 *>(arow + (size_t)r * DQ_FC1_IN + 4 * (kq + q));
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {
+            const int i = l + 64 * j;
+            if (i < 4 * NG * U) *reinterpret_cast<float4 *>(&xs[i / U][4 * (i % U)]) = xr[j];
         }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            float4 x[NG];
 #pragma unroll
-            for (int r = 0; r < DQ_RMAX; ++r) {
-                if (r < nrows) {  // wave-uniform
-                    const float4 x = *reinterpret_cast<const float4 *>(&xs[r][4 * u]);
-                    acc[r] = __builtin_fmaf(wv[u].x, x.x, acc[r]);
-                    acc[r] = __builtin_fmaf(wv[u].y, x.y, acc[r]);
-                    acc[r] = __builtin_fmaf(wv[u].z, x.z, acc[r]);
-                    acc[r] = __builtin_fmaf(wv[u].w, x.w, acc[r]);
-                }
-            }
+            for (int g = 0; g < NG; ++g) x[g] = *reinterpret_cast<const float4 *>(&xs[4 * g + (l & 3)][4 * u]);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].x, wv[u].x, acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].y, wv[u].y, acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].z, wv[u].z, acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].w, wv[u].w, acc[g], 0, 0, 0);
         }
     }
 #pragma unroll
-    for (int r = 0; r < DQ_RMAX; ++r)
-        if (r < nrows) hid[(size_t)(task.row_begin + r) * DQ_FC1_OUT + 64 * ob + l] = relu_keep_nan(acc[r]);
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (4 * g + i < nrows)
+                hid[(size_t)(task.row_begin + 4 * g + i) * DQ_FC1_OUT + 64 * ob + l] = relu_keep_nan(acc[g][i]);
 }
 
 // output layer + first-max action: one 64-thread workgroup per (task, row)
@@ -379,7 +403,13 @@ extern "C" int coevo_dqn_forward_argmax(const float *slab, const coevo_dqn_task 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(dqn_conv_kernel, dim3(n_tasks, max_rows_per_task), dim3(256), 0, s, slab, tasks, C, n_actions,
                        frames, act);
-    hipLaunchKernelGGL(dqn_fc1_kernel, dim3(n_tasks, 8), dim3(64), 0, s, slab, tasks, C, n_actions, act, hid);
+    const dim3 g1(n_tasks, 8), b1(64);
+    switch ((max_rows_per_task + 3) / 4) {
+    case 1: hipLaunchKernelGGL(dqn_fc1_kernel<1>, g1, b1, 0, s, slab, tasks, C, n_actions, act, hid); break;
+    case 2: hipLaunchKernelGGL(dqn_fc1_kernel<2>, g1, b1, 0, s, slab, tasks, C, n_actions, act, hid); break;
+    case 3: hipLaunchKernelGGL(dqn_fc1_kernel<3>, g1, b1, 0, s, slab, tasks, C, n_actions, act, hid); break;
+    default: hipLaunchKernelGGL(dqn_fc1_kernel<4>, g1, b1, 0, s, slab, tasks, C, n_actions, act, hid); break;
+    }
     hipLaunchKernelGGL(dqn_out_kernel, dim3(n_tasks, max_rows_per_task), dim3(64), 0, s, slab, tasks, C, n_actions, hid,
                        actions, logits, status);
     COEVO_HIP_CHECK(hipGetLastError());
