@@ -27,14 +27,15 @@ namespace coevo {
 #define COEVO_LIGHT_U 8   // 16-byte pieces per lane and buffer (two buffers in ping-pong)
 #endif
 
-// A per-individual weight set is read exactly once per launch by exactly one CU.  Non-temporal loads (which would
-// keep that stream from evicting the shared-opponent nets out of L2, MI355X_MICROARCH.md row nt-weights) were measured
-// here and change nothing (350 vs 349 generations/s, 85 vs 81 us in situ): plain loads ship, -DCOEVO_NT builds the
-// other variant for A/B runs.
+// A per-individual weight set is read exactly once per launch by exactly one CU: non-temporal loads keep that stream
+// (335 MB per env-cycle through 32 MB of L2) from evicting what IS reused - the shared-opponent nets and the kernel's own
+// code (MI355X_MICROARCH.md row nt-weights).  With the first, VALU-bound version of this kernel they changed nothing
+// (350 vs 349 generations/s); with the current one: 539.5 vs 517 (three alternating runs each).  -DCOEVO_NO_NT builds
+// the plain-load variant for A/B runs.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ inline float4 load_stream16(const float4 *p)
 {
-#ifndef COEVO_NT
+#ifdef COEVO_NO_NT
     return *p;
 #else
     const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(p));
