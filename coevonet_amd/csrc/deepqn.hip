@@ -289,7 +289,11 @@ __global__ __launch_bounds__(64) void dqn_fc1_kernel(const float *slab, const co
     for (int kq = 0; kq < 784; kq += U) {
         float4 wv[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) wv[u] = wp[(size_t)(kq + u) * 64];
+        for (int u = 0; u < U; ++u) {  // read once per launch: non-temporal, keeps the conv weights / activations in L2
+            typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+            const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt *>(wp + (size_t)(kq + u) * 64));
+            wv[u] = make_float4(v[0], v[1], v[2], v[3]);
+        }
         // the chunk's activations (rows x 28 float4 pieces, coalesced per row; pad rows: zeros): all requested at once,
         // next to the weight loads (one iteration at a time they cost six serial memory latencies per chunk)
         constexpr int XI = (4 * NG * U + 63) / 64;
