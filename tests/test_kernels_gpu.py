@@ -239,12 +239,17 @@ def test_device_rollout_matches_oracle_play_game(limit, max_cycles):
         assert list(r[g]) == want["rewards"], (g, r[g], want["rewards"])
 
 
-@pytest.mark.parametrize("mode", ["two_launches", "merged", "cohorts2", "cohorts3_eager"])
-def test_rollout_variants_match_oracle(mode):
+@pytest.mark.parametrize("mode,nh,heavy_rows", [
+    ("two_launches", 2, 32), ("merged", 2, 32), ("cohorts2", 2, 32), ("cohorts3_eager", 2, 32),
+    # the lean kernel (16-row shared-opponent tiles) and every per-individual row-count instantiation (1, 2, 5, 8)
+    ("merged", 1, 16), ("merged", 2, 16), ("merged", 5, 16), ("merged", 8, 16), ("cohorts2", 5, 16),
+    ("merged", 5, 32), ("merged", 8, 32), ("persistent", 5, 16), ("persistent_cohorts2", 3, 16)])
+def test_rollout_variants_match_oracle(mode, nh, heavy_rows, monkeypatch):
     """A GA-shaped batch (per-individual nets against shared opponents) through DeviceRollout: the two-launch cycle,
-    the merged one-launch cycle and the cohort chains all give the oracle's rewards bit for bit."""
+    the merged one-launch cycle (32-row and lean 16-row tiles), the cohort chains and the persistent one-launch rollout
+    all give the oracle's rewards bit for bit."""
     from coevonet_amd.rollout import RolloutPlan, DeviceRollout
-    npop, nh, limit, max_cycles = 20, 2, 40, 25
+    npop, limit, max_cycles = 20, 40, 25
     nets10 = make_nets(npop + nh, 10, seed=91, mutate=False)      # individuals (agent_0) + opponents for agent_1
     nets8 = make_nets(nh, 8, seed=92, mutate=False)               # opponent adversaries
     s10, s8 = L.fc_slab_stride(10), L.fc_slab_stride(8)
@@ -252,16 +257,23 @@ def test_rollout_variants_match_oracle(mode):
     off = [i * s10 for i in range(npop + nh)] + [(npop + nh) * s10 + k * s8 for k in range(nh)]
     D = [10] * (npop + nh) + [8] * nh
     games = [(npop + nh + k, i, npop + k) for i in range(npop) for k in range(nh)]   # (adversary, agent_0, agent_1)
-    K = {"two_launches": 1, "merged": 1, "cohorts2": 2, "cohorts3_eager": 3}[mode]
-    plan = RolloutPlan(np.array(games), off, D, device=DEV, n_cohorts=K)
+    K = {"two_launches": 1, "merged": 1, "cohorts2": 2, "cohorts3_eager": 3, "persistent": 1,
+         "persistent_cohorts2": 2}[mode]
+    monkeypatch.setenv("COEVO_PERSISTENT", "1" if mode.startswith("persistent") else "0")
+    plan = RolloutPlan(np.array(games), off, D, device=DEV, n_cohorts=K, heavy_rows=heavy_rows)
     assert plan.n_cohorts == K and len(plan.heavy_np) > 0 and len(plan.light_np) == npop
+    assert plan.light_max == nh and plan.heavy_max <= heavy_rows
     ro = DeviceRollout(plan, slab, merged=(mode != "two_launches"))
     ro.use_graph = mode != "cohorts3_eager"
     T = min(limit, 3 * max_cycles)
     ro.set_limits(np.full(plan.n_games, T))
     first = 3
     ro.reset(0, plan.n_games, first)
-    ro.run((T + 2) // 3)
+    if mode.startswith("persistent"):
+        assert ro.persistent_ok()
+        ro.enqueue_persistent((T + 2) // 3)
+    else:
+        ro.run((T + 2) // 3)
     torch.cuda.synchronize()
     ro.check_status()
     r = ro.rewards.cpu().numpy()
