@@ -283,6 +283,37 @@ def test_rollout_variants_match_oracle(mode, nh, heavy_rows, monkeypatch):
         assert list(r[g]) == want["rewards"], (mode, g, r[g], want["rewards"])
 
 
+def test_paired_streaming_workgroups_odd_count():
+    """more tasks than the 32-row merged kernel has workgroup slots -> two per-individual nets per workgroup; an odd
+    number of them leaves the last workgroup's second net absent (it must write nothing).  523 one-row tasks."""
+    from coevonet_amd.rollout import RolloutPlan, DeviceRollout
+    npop, limit, max_cycles = 523, 12, 25
+    base10 = make_nets(3, 10, seed=11, mutate=False)
+    base8 = make_nets(1, 8, seed=12, mutate=False)
+    rng = np.random.default_rng(5)
+    nets10 = [base10[0] + (rng.standard_normal(base10[0].shape) * 0.01).astype(np.float32) for _ in range(npop)]
+    nets10 += [base10[1]]                                          # the shared agent_1 opponent
+    s10, s8 = L.fc_slab_stride(10), L.fc_slab_stride(8)
+    slab = torch.cat([to_slab(np.stack(nets10), 10).reshape(-1), to_slab(base8, 8).reshape(-1)]).contiguous()
+    off = [i * s10 for i in range(npop + 1)] + [(npop + 1) * s10]
+    D = [10] * (npop + 1) + [8]
+    games = [(npop + 1, i, npop) for i in range(npop)]             # (adversary, agent_0, agent_1)
+    plan = RolloutPlan(np.array(games), off, D, device=DEV, heavy_rows=32)
+    assert len(plan.light_np) == npop and len(plan.heavy_np) + npop > 512 and npop % 2 == 1
+    ro = DeviceRollout(plan, slab, merged=True)
+    T = min(limit, 3 * max_cycles)
+    ro.set_limits(np.full(plan.n_games, T))
+    ro.reset(0, plan.n_games, 7)
+    ro.run((T + 2) // 3)
+    torch.cuda.synchronize()
+    ro.check_status()
+    r = ro.rewards.cpu().numpy()
+    stream = rp.Stream()
+    for g in list(range(0, npop, 37)) + [npop - 2, npop - 1]:
+        want = rp.play_game(stream, nets10[g], nets10[npop], base8[0], limit, max_cycles, ordinal=7 + g)
+        assert list(r[g]) == want["rewards"], (g, r[g], want["rewards"])
+
+
 # ----------------------------------------------------------------------------------- offspring
 @pytest.mark.parametrize("D,skip_ln", [(10, 0), (8, 1)])
 def test_perturb_bit_exact_vs_oracle(D, skip_ln):
