@@ -195,8 +195,8 @@ __device__ __forceinline__ double mpe_ux(int act) { return act == 1 ? -1.0 : (ac
 __device__ __forceinline__ double mpe_uy(int act) { return act == 3 ? -1.0 : (act == 4 ? 1.0 : 0.0); }
 
 // PettingZoo World.step for three discrete actions (no collisions, no noise) + the two reward values
-__device__ __forceinline__ void mpe_world_step(MpeGame &s, int act_a, int act_b, int act_c, int pos_first,
-                                               double &r_good, double &r_adv)
+// the movement alone (rows that are not their game's owner do not need the rewards: three fp64 square roots less)
+__device__ __forceinline__ void mpe_world_move(MpeGame &s, int act_a, int act_b, int act_c, int pos_first)
 {
     mpe_move(s.ax, s.avx, mpe_ux(act_a), pos_first);
     mpe_move(s.ay, s.avy, mpe_uy(act_a), pos_first);
@@ -204,6 +204,12 @@ __device__ __forceinline__ void mpe_world_step(MpeGame &s, int act_a, int act_b,
     mpe_move(s.by, s.bvy, mpe_uy(act_b), pos_first);
     mpe_move(s.cx, s.cvx, mpe_ux(act_c), pos_first);
     mpe_move(s.cy, s.cvy, mpe_uy(act_c), pos_first);
+}
+
+__device__ __forceinline__ void mpe_world_step(MpeGame &s, int act_a, int act_b, int act_c, int pos_first,
+                                               double &r_good, double &r_adv)
+{
+    mpe_world_move(s, act_a, act_b, act_c, pos_first);
     double dx = s.ax - s.gx, dy = s.ay - s.gy;
     const double da = sqrt(dx * dx + dy * dy);
     dx = s.bx - s.gx; dy = s.by - s.gy;
@@ -259,9 +265,12 @@ __device__ __forceinline__ void mpe_fused_observe(const double *st_prev, double 
         const int t0 = 3 * (cycle - 1);
         const bool stepped = t0 + 2 < limit;  // agent_1 acted in the previous cycle: the world moved
         double r_good = 0.0, r_adv = 0.0;
-        if (stepped)
-            mpe_world_step(s, ld_i32<COH>(act_prev + 3 * g), ld_i32<COH>(act_prev + 3 * g + 1),
-                           ld_i32<COH>(act_prev + 3 * g + 2), pos_first, r_good, r_adv);
+        if (stepped) {
+            const int a0 = ld_i32<COH>(act_prev + 3 * g), a1 = ld_i32<COH>(act_prev + 3 * g + 1),
+                      a2 = ld_i32<COH>(act_prev + 3 * g + 2);
+            if (slot == COEVO_SLOT_ADVERSARY) mpe_world_step(s, a0, a1, a2, pos_first, r_good, r_adv);
+            else mpe_world_move(s, a0, a1, a2, pos_first);  // only the owner row credits rewards
+        }
         if (slot == COEVO_SLOT_ADVERSARY) {  // the game's owner row: carry the bookkeeping into the new buffer
             double rg_prev = ld_f64<COH>(st_prev + 18 * N + g), a_adv = ld_f64<COH>(st_prev + 19 * N + g),
                    a_a0 = ld_f64<COH>(st_prev + 20 * N + g), a_a1 = ld_f64<COH>(st_prev + 21 * N + g);
