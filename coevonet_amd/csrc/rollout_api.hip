@@ -1,11 +1,11 @@
 // coevo_mpe_rollout - a whole batch of games in ONE C-ABI call: the replacement for the reference's per-game
 // play_game()/play_MPE() loop (utils/game_logic_functions.py:123-228) at batch scale.
 //
-// Per env-cycle it enqueues: [side stream] the shared-opponent (MFMA) policy launch || [main stream] the
-// per-individual (streaming) policy launch, joined by an event, then the env step on the main stream.  The two policy
-// launches touch disjoint rows and different bottlenecks (matrix cores fed from L2 vs HBM streaming), so they are
-// meant to overlap.  Nothing here synchronises with the host; the whole sequence can also be captured into a hipGraph
-// by the caller (capture `stream`; the side stream joins the capture through the fork event).
+// Per env-cycle and cohort it enqueues ONE merged launch (coevo_mpe_policy_cycle_merged: shared-opponent workgroups on
+// the matrix cores + per-individual streaming workgroups, env step fused in); cohorts are independent chains on their
+// own streams (cohort 0: the caller's).  With d->merged == 0 the older two-launch form is used instead: [side stream]
+// the shared-opponent launch || [main stream] the per-individual launch, joined by an event.  Nothing here synchronises
+// with the host; a single-cohort sequence can also be captured into a hipGraph by the caller.
 #include <vector>
 
 #include "coevo_common.hip.h"

@@ -2,8 +2,9 @@
 genetic_algorithm.py:51) over a batched engine.
 
 Per generation the reference plays 3*pop*hof + 10 sequential games; here all of them advance together on the device
-(coevonet_amd.rollout), fitness / sharing / ranking / HoF update / offspring stay on the device, and the only host
-round trip is the 10-game evaluation result that drives the adaptive mutation power.
+(coevonet_amd.rollout), fitness / sharing / ranking / HoF update / offspring stay on the device; with device-built
+offspring ("device_philox") the evaluation means and the adaptive mutation power do too, and a generation has no host
+round trip at all (GAEngine.replay_generation_pipelined on one GPU, GAEngine.step_sharded on several).
 
 reference_exact semantics kept: Q1 reward attribution (device step kernel), Q2 only the last
 HoF game counts, Q3 diversity against the stale agent left over from the init loop, always applied, Q4 the adversary

@@ -4,10 +4,13 @@ The reference plays its games one after another (play_game -> play_MPE, utils/ga
 batch-1 forward per agent-step.  All games of a generation are independent given the generation's weights and each
 game's ordinal in the seeded reset stream, so they are flattened here into E env copies that advance in
 lock-step world cycles.  Per cycle: every distinct weight set that acts is read ONCE (a task = one net x the rows that
-share it), all three agents of a cycle observe the same world state, then one step kernel advances all games.
+share it), all three agents of a cycle observe the same world state, and the world step itself is fused into the next
+cycle's policy launch (each row derives its game's state from the previous buffer + actions).
 
-``RolloutPlan``   static description of a batch: which net plays which slot of which game -> task/row tables on device
-``DeviceRollout`` env state + action buffers + the cycle loop, env on the device (fused observe+policy kernel)
+``RolloutPlan``   static description of a batch: which net plays which slot of which game -> task/row tables on device,
+                  optionally partitioned into independent game cohorts
+``DeviceRollout`` env state + action buffers + the cycle loop, env on the device: one merged launch per env-cycle (and
+                  cohort), cohort chains on their own streams, or the opt-in persistent one-launch rollout
 ``HostEnvRollout`` the same plan with the env stepped on the host cores (north_star's first configuration)
 """
 from __future__ import annotations
@@ -20,8 +23,8 @@ import torch
 from . import lib as L
 from .mpe import simple_adversary as sa
 
-LIGHT_ROWS = 8      # tasks up to this many rows use the 8-row kernel
-HEAVY_ROWS = 32     # larger row sets are cut into chunks of this size
+LIGHT_ROWS = 8      # a net with up to this many rows is ONE per-individual (streaming) task
+HEAVY_ROWS = 32     # larger row sets (shared opponents) are cut into chunks of this size (GA engine: 16, lean kernel)
 
 
 class RolloutPlan:
@@ -166,8 +169,10 @@ def effective_steps(limit, max_cycles):
 
 
 class DeviceRollout:
-    """Env copies resident on the GPU.  One C-ABI call (coevo_mpe_rollout) enqueues every cycle: the shared-opponent
-    (MFMA) launch on a side HIP stream concurrently with the per-individual (streaming) launch, then the env step."""
+    """Env copies resident on the GPU.  One C-ABI call (coevo_mpe_rollout) enqueues every cycle of every cohort: per
+    cycle and cohort ONE merged launch (shared-opponent workgroups on the matrix cores + per-individual streaming
+    workgroups, env step fused in); ``merged=False`` keeps the two-launch form (shared-opponent launch on a side stream
+    beside the streaming launch) for A/B runs."""
 
     def __init__(self, plan: RolloutPlan, slab: torch.Tensor, env_seed=sa.ENV_SEED, timing_pairs=0, fused_step=True,
                  merged=None):
