@@ -220,10 +220,22 @@ def main():
                              "rollout_span_ms": span_ms, "launches": 1 if persistent else K * eng.ro._span_cycles,
                              "note": "algorithmic bytes of every policy launch of one rollout / (first workgroup start "
                                      ".. last workgroup end of the rollout)"}
-            lean = merged and eng.plan.heavy_max <= 16
-            kernel_id = ("fc_cycle16_kernel<5>" if lean else "fc_cycle_kernel<5") if merged else "fc_policy_kernel<5, 2>"
+            # which instantiation the C side picks (coevo_mpe_policy_cycle_merged): row-count template, lean 16-row
+            # tiles when both cohorts' workgroups fit four per CU, else 32-row tiles (two nets per streaming workgroup
+            # when one per workgroup would not fit two per CU)
+            Kc = max(eng.ro.n_cohorts, 1)
+            R = next(r for r in (1, 2, 5, 8, 32) if eng.plan.light_max <= r)
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            per_launch = (len(eng.plan.heavy_np) + len(eng.plan.light_np)) / Kc
+            lean = merged and eng.plan.heavy_max <= 16 and per_launch * Kc <= 4 * cus
             if persistent:
-                kernel_id = "fc_rollout16_kernel<5>"
+                kernel_id = f"fc_rollout16_kernel<{R}>"
+            elif lean:
+                kernel_id = f"fc_cycle16_kernel<{R}>"
+            elif merged:
+                kernel_id = f"fc_cycle_kernel<{R}, {2 if per_launch * Kc > 2 * cus else 1}>"
+            else:
+                kernel_id = f"fc_policy_kernel<{R}, 2>"
             traffic, traffic_note = None, None
             pmc = os.path.join(REPO, "profiles", "r01_pmc_hbm_traffic.json")
             if a.pop_per_gpu == 200 and a.hof == 5 and os.path.exists(pmc):
@@ -235,12 +247,12 @@ def main():
                 if want in j.get("dominant_kernel", ""):
                     traffic = j["dominant_kernel_hbm_bytes_per_launch"]
                     traffic_note = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc passes of this command)"
-            kname = ((kernel_id.rstrip("<5") if not lean else kernel_id) +
+            kname = (kernel_id +
                      (" (the whole rollout in one persistent launch: per env-cycle every per-individual weight set "
                       "streamed once + shared-opponent tasks on the matrix cores, fused env step)" if persistent else
                       " (one env-cycle of one cohort: per-individual weight sets streamed once + shared-opponent tasks "
                       "on the matrix cores, fused env step)") if merged else
-                     "fc_policy_kernel<5, 2> (per-individual weight sets, fused env step)")
+                     kernel_id + " (per-individual weight sets, fused env step)")
             out["roofline"] = {"bound": "hbm", "kernel": kname,
                                "timing": ("HIP events around each launch on its stream" if a.no_graph else
                                           "in-kernel 100 MHz clock stamps, first workgroup start to last workgroup "
