@@ -477,6 +477,20 @@ class GAEngine:
         while cohort k's chain already streams weights, and the chains start a breeding time apart, which is the stagger
         they want anyway.  The host knows `gen`; sigma, ranks and distances stay on the device."""
         assert self.world == 1 and self.env_mode == "device" and self.fused_tail and self.K > 1
+        self._enqueue_cohort_chains(gen)
+        if self._tail_graph is None:
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                self._enqueue_selection_and_breeding(breed=False)
+            self._tail_graph = gr
+        self._tail_graph.replay()
+        self._breeding_pending = self.pop > 1
+        self.generation_enqueued = gen + 1
+
+    def _enqueue_cohort_chains(self, gen):
+        """per cohort stream: deferred breeding of its children -> reset of its games -> its chain of merged launches;
+        then, on the caller's stream, the closing step of the rollout"""
         ro = self.ro
         if gen <= 1:  # the evaluation games of "generation -1" do not exist: disabled in generation 0 only
             limits = np.zeros(self.plan.n_games, dtype=np.int32)
@@ -510,15 +524,6 @@ class GAEngine:
         for ev in self._cohort_done[1:]:
             main.wait_event(ev)
         ro.enqueue_final_step(self.n_cycles)
-        if self._tail_graph is None:
-            torch.cuda.synchronize()
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
-                self._enqueue_selection_and_breeding(breed=False)
-            self._tail_graph = gr
-        self._tail_graph.replay()
-        self._breeding_pending = self.pop > 1
-        self.generation_enqueued = gen + 1
 
     def step_sharded(self, gen):
         """One generation of the population-sharded run (world > 1) without a host round trip: the same launches as
@@ -529,6 +534,13 @@ class GAEngine:
         values (sigma, ranks, distances) have to stay on the device."""
         assert self.env_mode == "device" and self.rng_mode == "device_philox"
         ro, M = self.ro, 3 * self.pop * self.hof
+        if self.K > 1 and self.fused_tail and self.pipelined and ro.desc.merged:
+            # as on one GPU: each cohort stream breeds its children (deferred), resets its games, runs its chain
+            self._enqueue_cohort_chains(gen)
+            self._sharded_tail(gen, breed=False)
+            self._breeding_pending = self.n_local > 0 and self.pop > 1
+            self.generation_enqueued = gen + 1
+            return
         if gen <= 1:
             limits = np.zeros(self.plan.n_games, dtype=np.int32)
             limits[:self.n_main] = self.T_train
@@ -542,6 +554,12 @@ class GAEngine:
         if gen > 0:
             ro.reset(self.n_main, N_EVAL, self._ordinal_base(gen - 1) + M)
         ro.enqueue(self.n_cycles)
+        self._sharded_tail(gen, breed=True)
+
+    def _sharded_tail(self, gen, breed):
+        """all-gather of the fitness inputs -> selection -> sigma rule -> elites (rebuilt) / HoF / best -> [children]"""
+        ro = self.ro
+        per_phase = self.n_local * self.hof
         # last HoF game of every local individual (Q2) + its stale-agent distance -> every rank (one fused all-gather)
         for ph in range(3):
             idx = ph * per_phase + torch.arange(self.n_local, device=self.device) * self.hof + self.hof - 1
@@ -579,6 +597,8 @@ class GAEngine:
             self._promote_roles(elites_from_pop=(gen == 0), best_to_pop0=(self.lo == 0))
         for ri, r in enumerate(ROLES):
             D = ROLE_D[r]
+            if not breed:
+                break
             if c_hi > c_lo:
                 L.call("coevo_fc_perturb_dist", self._ptr(r, "elite"), self.parent_idx.data_ptr() + 4 * c_lo,
                        self._ptr(r, "pop"), 1 + c_lo, c_hi - c_lo, D, self.sigma32.data_ptr() + 4 * ri,
