@@ -561,11 +561,27 @@ class GAEngine:
         ro = self.ro
         per_phase = self.n_local * self.hof
         # last HoF game of every local individual (Q2) + its stale-agent distance -> every rank (one fused all-gather)
-        for ph in range(3):
-            idx = ph * per_phase + torch.arange(self.n_local, device=self.device) * self.hof + self.hof - 1
-            self.last_reward[ph, self.lo:self.hi] = ro.rewards[idx]
+        if getattr(self, "_last_game_idx", None) is None:  # built once: one gather launch per generation
+            one = torch.arange(self.n_local, device=self.device) * self.hof + self.hof - 1
+            self._last_game_idx = torch.cat([ph * per_phase + one for ph in range(3)])
+        self.last_reward[:, self.lo:self.hi] = ro.rewards[self._last_game_idx].view(3, self.n_local, 3)
         if self.world > 1:
             self.gather(self)
+        # everything after the all-gather replays as one graph from generation 1 on (the elite rebuild then takes the
+        # generation from the device counter); generation 0 (elites out of the initial population) runs eagerly
+        if not breed and gen > 0 and self.fused_tail and self.ro.use_graph:
+            if getattr(self, "_sharded_tail_graph", None) is None:
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    self._sharded_tail_post(gen, breed=False, gen_from_device=True)
+                self._sharded_tail_graph = gr
+            self._sharded_tail_graph.replay()
+            return
+        self._sharded_tail_post(gen, breed, gen_from_device=False)
+
+    def _sharded_tail_post(self, gen, breed, gen_from_device):
+        ro = self.ro
         if self.fused_tail:
             self._select_roles(lambda ri: self.last_reward[ri].data_ptr(), lambda ri: 0, 1)
         else:
@@ -585,7 +601,8 @@ class GAEngine:
             if gen > 0:
                 L.call("coevo_fc_gather", self._ptr(r, "elite"), L._p(self.iota), self._ptr(r, "elite_prev"), 0, self.E, D)
                 L.call("coevo_fc_rebuild_elites", self._ptr(r, "elite_prev"), L._p(self.order[r]), self._ptr(r, "elite"),
-                       self.E, D, self.sigma32_prev.data_ptr() + 4 * ri, self.philox_seed, (gen - 1) * 4 + ri, None)
+                       self.E, D, self.sigma32_prev.data_ptr() + 4 * ri, self.philox_seed,
+                       ri if gen_from_device else (gen - 1) * 4 + ri, g if gen_from_device else None)
             elif not self.fused_tail:  # generation 0's population is the host-initialised one, present on every rank
                 L.call("coevo_fc_gather", self._ptr(r, "pop"), L._p(self.order[r]), self._ptr(r, "elite"), 0, self.E, D)
             if not self.fused_tail:
