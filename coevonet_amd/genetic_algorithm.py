@@ -481,7 +481,7 @@ class GAEngine:
         if self._tail_graph is None:
             torch.cuda.synchronize()
             gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
+            with torch.cuda.graph(gr, capture_error_mode="thread_local"):
                 self._enqueue_selection_and_breeding(breed=False)
             self._tail_graph = gr
         self._tail_graph.replay()
@@ -573,7 +573,7 @@ class GAEngine:
             if getattr(self, "_sharded_tail_graph", None) is None:
                 torch.cuda.synchronize()
                 gr = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gr):
+                with torch.cuda.graph(gr, capture_error_mode="thread_local"):
                     self._sharded_tail_post(gen, breed=False, gen_from_device=True)
                 self._sharded_tail_graph = gr
             self._sharded_tail_graph.replay()
@@ -646,7 +646,7 @@ class GAEngine:
                 parts = []
                 for fn in (self._enqueue_resets, self._enqueue_selection_and_breeding):
                     gr = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gr):
+                    with torch.cuda.graph(gr, capture_error_mode="thread_local"):
                         fn()
                     parts.append(gr)
                 self._gen_graph = parts
@@ -660,7 +660,7 @@ class GAEngine:
             if key not in self._gen_graph:
                 torch.cuda.synchronize()
                 gr = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gr):
+                with torch.cuda.graph(gr, capture_error_mode="thread_local"):
                     self.enqueue_generation()
                 self._gen_graph[key] = gr
                 # the capture did not execute anything: the counter still holds `gen`

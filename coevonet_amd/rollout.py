@@ -260,7 +260,7 @@ class DeviceRollout:
                 self.desc.n_cycles = n_cycles
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     L.call("coevo_mpe_rollout", L.C.byref(self.desc), ctx, 0)
                 self._graphs[key] = g
             g.replay()
