@@ -32,3 +32,14 @@ def test_version_and_layout_constants():
     assert L.fc_param_count(10) == 139781 and L.fc_param_count(8) == 138757
     assert L.fc_slab_stride(10) % 64 == 0 and L.fc_slab_stride(10) >= 139781
     assert L.fc_param_count(9) < 0  # unsupported width is an argument error, not a crash
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/coevo.h is the drop-in boundary: it must compile as C99 (what a cgo / JNI / ctypes-gen binding includes)"""
+    import os
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "coevo.h"\nint main(void) { return coevo_version() ? 0 : 0; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(repo, "include"),
+                    "-c", str(src), "-o", str(tmp_path / "hdr.o")], check=True)
