@@ -119,11 +119,15 @@ struct GaSelectArgs {
 
 __global__ __launch_bounds__(256) void ga_select_kernel(GaSelectArgs a)
 {
+    // grid (role, slice): every workgroup recomputes the O(pop) parts (score, all fitness values into LDS) and ranks
+    // only its own 256 individuals - rank counting is O(pop^2), and weak scaling multiplies pop by the number of GPUs
+    // (one workgroup per role took 0.19 ms at pop 1600)
     __shared__ double scratch[4];
     __shared__ float f[4096];
     __shared__ float div_s;
     const coevo_ga_select_role R = a.role[blockIdx.x];
     const int n = a.pop;
+    const bool first_slice = blockIdx.y == 0;
     // sharing score (sharing_score_kernel)
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) s += (double)R.dist[i];
@@ -134,7 +138,10 @@ __global__ __launch_bounds__(256) void ga_select_kernel(GaSelectArgs a)
         if (sh > 0.0f) sc += (double)sh;
     }
     const double tot = block_sum_f64(sc, scratch);
-    if (threadIdx.x == 0) { div_s = (float)tot; *R.diversity = (float)tot; }
+    if (threadIdx.x == 0) {
+        div_s = (float)tot;
+        if (first_slice) *R.diversity = (float)tot;
+    }
     __syncthreads();
     // fitness (ga_fitness_kernel)
     const int gpi = a.games_per_individual;
@@ -143,11 +150,12 @@ __global__ __launch_bounds__(256) void ga_select_kernel(GaSelectArgs a)
         const float total = (float)(last / (double)a.hof);
         const float fit = total / (1.0f + div_s);
         f[i] = fit;
-        R.fitness[i] = fit;
+        if (first_slice) R.fitness[i] = fit;
     }
     __syncthreads();
-    // rank (rank_desc_kernel) + the best individual's distance (gather_f32 of order[0])
-    for (int i = threadIdx.x; i < n; i += 256) {
+    // rank (rank_desc_kernel) of this slice's individuals + the best individual's distance (gather_f32 of order[0])
+    const int i = blockIdx.y * 256 + threadIdx.x;
+    if (i < n) {
         const float fi = f[i];
         int rank = 0;
         for (int j = 0; j < n; ++j) rank += rank_less(f[j], j, fi, i) ? 1 : 0;
@@ -315,7 +323,7 @@ extern "C" int coevo_ga_select(const coevo_ga_select_role *roles, int n_roles, i
         a.role[r] = R;
     }
     a.pop = pop; a.games_per_individual = games_per_individual; a.hof = hof;
-    hipLaunchKernelGGL(coevo::ga_select_kernel, dim3(n_roles), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(coevo::ga_select_kernel, dim3(n_roles, (pop + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

@@ -414,10 +414,12 @@ def test_diversity_fitness_rank():
     assert np.array_equal(order.cpu().numpy(), np.argsort(f, kind="stable")[::-1])
 
 
-def test_fused_select_and_promote_equal_separate_launches():
-    """coevo_ga_select / coevo_ga_promote (one launch for the three roles) == the per-role launches they replace"""
+@pytest.mark.parametrize("pop", [37, 1600])
+def test_fused_select_and_promote_equal_separate_launches(pop):
+    """coevo_ga_select / coevo_ga_promote (one launch for the three roles) == the per-role launches they replace
+    (pop 1600 = the global population of an 8-GPU weak-scaling run: several ranking slices per role)"""
     rng = np.random.default_rng(3)
-    pop, hof, E, gpi = 37, 4, 3, 4
+    hof, E, gpi = 4, 3, 4
     n_games = 3 * pop * gpi
     rewards = torch.from_numpy(rng.normal(size=(n_games, 3)) * 10).to(DEV)
     Ds = [10, 10, 8]
