@@ -51,12 +51,10 @@ class DistContext:
         lo, hi = eng.lo, eng.hi
         local = torch.empty(3, hi - lo, 4, dtype=torch.float64, device=eng.last_reward.device)
         local[:, :, :3] = eng.last_reward[:, lo:hi]
-        for ri, r in enumerate(ROLES):
-            local[ri, :, 3] = eng.dist[r][lo:hi].to(torch.float64)
+        local[:, :, 3] = eng.dist_all[:, lo:hi]          # fp32 -> fp64 (exact), all roles in one copy
         full = allgather_shards(local, self.world)
         eng.last_reward.copy_(full[:, :, :3])
-        for ri, r in enumerate(ROLES):
-            eng.dist[r].copy_(full[ri, :, 3].to(torch.float32))
+        eng.dist_all.copy_(full[:, :, 3])               # back to fp32 (exact: they were fp32 values)
 
     def barrier(self):
         if self.world > 1:

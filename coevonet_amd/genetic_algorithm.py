@@ -150,7 +150,8 @@ class GAEngine:
             self.ro = HostEnvRollout(self.plan, self.slab, env_seed=env_seed)
         # ---- small device buffers ---------------------------------------------------------------------------
         f32 = dict(dtype=torch.float32, device=device)
-        self.dist = {r: torch.zeros(pop, **f32) for r in ROLES}
+        self.dist_all = torch.zeros(3, pop, **f32)                      # [role][individual], one tensor: the fitness
+        self.dist = {r: self.dist_all[i] for i, r in enumerate(ROLES)}  # all-gather packs / unpacks it in one copy
         self.div = {r: torch.zeros(1, **f32) for r in ROLES}
         self.fitness = {r: torch.zeros(pop, **f32) for r in ROLES}
         self.order = {r: torch.zeros(pop, dtype=torch.int32, device=device) for r in ROLES}
