@@ -8,6 +8,7 @@ shipped to the device slab.
 """
 from __future__ import annotations
 
+import math
 from collections import OrderedDict
 from itertools import chain
 
@@ -56,10 +57,13 @@ class FCNetwork:
             off += n
         # torch default init, consuming the global generator exactly like the three nn.Linear constructions of the
         # reference (MPE/fcnetwork.py:14-20); LayerNorm starts at gamma=1, beta=0 and draws nothing
+        # (drawn straight into the flat buffer with nn.Linear.reset_parameters' own calls and order - weight:
+        # kaiming_uniform_(a=sqrt(5)), bias: uniform_(-1/sqrt(fan_in), 1/sqrt(fan_in)) - instead of building a throw-away
+        # nn.Linear and copying: same generator stream, half the time; the weight-hash fixtures pin it)
         for prefix, (i, o) in (("fc1", (self.input_channels, H1)), ("fc2", (H1, H2)), ("output", (H2, self.n_actions))):
-            lin = torch.nn.Linear(i, o)
-            self._params[prefix + ".weight"].copy_(lin.weight.detach())
-            self._params[prefix + ".bias"].copy_(lin.bias.detach())
+            torch.nn.init.kaiming_uniform_(self._params[prefix + ".weight"], a=math.sqrt(5))
+            bound = 1.0 / math.sqrt(i) if i > 0 else 0.0
+            torch.nn.init.uniform_(self._params[prefix + ".bias"], -bound, bound)
         for ln in ("ln1", "ln2"):
             self._params[ln + ".weight"].fill_(1.0)
             self._params[ln + ".bias"].zero_()
