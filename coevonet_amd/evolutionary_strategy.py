@@ -71,7 +71,8 @@ class ESEngine:
         self.plan = RolloutPlan(np.array(games), net_off, net_D, device=device, heavy_rows=heavy_rows,
                                 n_cohorts=es_cohorts)
         self.ro = cls(self.plan, self.slab, env_seed=env_seed)
-        self.eval_plan = RolloutPlan(np.array(eval_games), net_off, net_D, device=device)
+        # the 10 evaluation games: three nets x 10 rows, as two 5-row streaming tasks per net (1.0 -> 0.5 ms)
+        self.eval_plan = RolloutPlan(np.array(eval_games), net_off, net_D, device=device, split_rows=5)
         self.eval_ro = cls(self.eval_plan, self.slab, env_seed=env_seed)
         f32 = dict(dtype=torch.float32, device=device)
         self.fitness = {r: torch.zeros(pop, **f32) for r in ROLES}

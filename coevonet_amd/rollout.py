@@ -32,7 +32,7 @@ class RolloutPlan:
     net_off / net_D: per net id, float offset inside the slab and observation width."""
 
     def __init__(self, game_nets, net_off, net_D, device="cuda", heavy_rows=HEAVY_ROWS, n_cohorts=1,
-                 game_cohort=None):
+                 game_cohort=None, split_rows=None):
         game_nets = np.asarray(game_nets, dtype=np.int64)
         self.n_games = int(game_nets.shape[0])
         by_net = {}
@@ -60,7 +60,14 @@ class RolloutPlan:
         light = [[] for _ in range(self.n_cohorts)]
         heavy = [[] for _ in range(self.n_cohorts)]
         for net, rows in by_net.items():
-            if len(rows) <= LIGHT_ROWS:
+            if split_rows is not None:
+                # a handful of nets with a few rows each (the 10 evaluation games of a trio): cut every net's rows into
+                # streaming-body tasks of <= split_rows rows instead of one matrix-core task - a lone small launch is
+                # bound by the body's latency, and the streaming body is the short one (one cohort only)
+                assert self.n_cohorts == 1 and 1 <= split_rows <= LIGHT_ROWS
+                for i in range(0, len(rows), split_rows):
+                    light[0].append((net, rows[i:i + split_rows]))
+            elif len(rows) <= LIGHT_ROWS:
                 light[int(cohort[rows[0][0]])].append((net, rows))   # all its games share one cohort by construction
             else:
                 for k in range(self.n_cohorts):
