@@ -291,12 +291,19 @@ __global__ __launch_bounds__(256) void es_update_kernel(float *theta, const floa
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     const float *pp = pert_slab + s0;
     int i = 0;
-    for (; i + 8 <= n; i += 8) {
-        float4 pv[8];
+    // the perturbed nets are read exactly once: non-temporal, and 16 rows in flight per lane (only stride/1024 = 137
+    // workgroups exist - the sum over i is sequential by definition - so the memory-level parallelism comes from depth)
+    typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+    constexpr int UE = 16;
+    for (; i + UE <= n; i += UE) {
+        float4 pv[UE];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) pv[u] = *reinterpret_cast<const float4 *>(pp + (int64_t)(i + u) * stride);
+        for (int u = 0; u < UE; ++u) {
+            const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt *>(pp + (int64_t)(i + u) * stride));
+            pv[u] = make_float4(v[0], v[1], v[2], v[3]);
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < UE; ++u) {
             const float f = fitness[i + u];
             acc[0] = __builtin_fmaf(f, pv[u].x - th[0], acc[0]);
             acc[1] = __builtin_fmaf(f, pv[u].y - th[1], acc[1]);
