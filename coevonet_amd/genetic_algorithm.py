@@ -784,14 +784,42 @@ class GATrainer:
         self.gen += 1
 
     def _collect_device_loop(self, gen):
-        eng, res, args = self.eng, self.res, self.args
-        eng.ro.check_status()
-        eng.ro.collect_stamps()
-        res.game_rewards.append(eng.rewards_host()[:eng.n_main].copy())
-        res.fitness.append([eng.fitness[r].cpu().numpy().tolist() for r in ROLES])
-        res.diversity.append([float(eng.div[r].item()) for r in ROLES])
-        res.elite_ids.append([eng.elite_ids()[r] for r in ROLES])
-        self._sync_history_from_device(upto=gen)  # evaluation means / sigmas of generations < gen are final
+        """Per-generation results (game rewards, fitness, diversity, elite ids, status word) without draining the
+        pipeline: asynchronous copies into one of two pinned host slots, enqueued behind generation `gen` on the caller's
+        stream (so before anything of generation gen+1 can overwrite the sources), and the PREVIOUS generation's slot -
+        long complete - is harvested into the result.  The result therefore lags one generation until finish()."""
+        eng = self.eng
+        if getattr(self, "_slots", None) is None:
+            pin = lambda *shape, dtype: torch.zeros(*shape, dtype=dtype).pin_memory()
+            self._slots = [{"rewards": pin(eng.n_main, 3, dtype=torch.float64),
+                            "fitness": pin(3, eng.pop, dtype=torch.float32), "div": pin(3, dtype=torch.float32),
+                            "elite": pin(3, eng.E, dtype=torch.int32), "status": pin(1, dtype=torch.int32),
+                            "event": torch.cuda.Event(), "gen": -1} for _ in range(2)]
+        slot = self._slots[gen % 2]
+        slot["rewards"].copy_(eng.ro.rewards[:eng.n_main], non_blocking=True)
+        for i, r in enumerate(ROLES):
+            slot["fitness"][i].copy_(eng.fitness[r], non_blocking=True)
+            slot["div"][i:i + 1].copy_(eng.div[r], non_blocking=True)
+            slot["elite"][i].copy_(eng.order[r][:eng.E], non_blocking=True)
+        slot["status"].copy_(eng.ro.status, non_blocking=True)
+        slot["event"].record()
+        slot["gen"] = gen
+        if gen > 0:
+            self._harvest(self._slots[(gen - 1) % 2])
+
+    def _harvest(self, slot):
+        if slot["gen"] < 0:
+            return
+        slot["event"].synchronize()
+        res = self.res
+        st = int(slot["status"][0])
+        if st:
+            L.raise_on_status(slot["status"])
+        res.game_rewards.append(slot["rewards"].numpy().copy())
+        res.fitness.append([slot["fitness"][i].numpy().tolist() for i in range(3)])
+        res.diversity.append([float(slot["div"][i]) for i in range(3)])
+        res.elite_ids.append([slot["elite"][i].numpy().astype(int).tolist() for i in range(3)])
+        slot["gen"] = -1
 
     def _sync_history_from_device(self, upto):
         """mirror the device-resident histories into the result and the (mutable, reference-style) args bag"""
@@ -812,6 +840,9 @@ class GATrainer:
                 self.eng.flush_breeding()
                 torch.cuda.synchronize()
                 self.eng.ro.check_status()
+                if self.collect and getattr(self, "_slots", None):  # the lagging last generation
+                    self._harvest(self._slots[(self.gen - 1) % 2])
+                self.eng.ro.collect_stamps()
                 self._sync_history_from_device(upto=self.gen - 1)
             _finish_generation(self.args, self.gen - 1, self.eng.eval_only(self.gen - 1), self.res)
         if hasattr(self.env, "n_resets"):
