@@ -300,11 +300,11 @@ def evolution_strategy_train(env, args, output_dir, rng=None, env_mode=None, col
     save = bool(getattr(args, "save", False)) and output_dir is not None
     for _ in range(args.generations):
         go_on = tr.step()
-        if save:  # evolutionary_strategy.py:357-360
+        if not go_on:  # evolutionary_strategy.py:343-354: the reference breaks BEFORE save_model (:357-360), so the
+            break      # stopping generation's update is never written
+        if save:
             for a, r in zip(tr.base_agents(), ROLES):
                 save_model(a, os.path.join(output_dir, ES_FILES[r]))
-        if not go_on:
-            break
     res = tr.finish()
     res.engine = tr.eng
     agents = tr.base_agents()

@@ -64,6 +64,13 @@ def adapt_mutation_power(args, gen, hist):
         args.mutation_power_adversary = max(args.mutation_power_adversary * 0.95, args.min_mutation_power)
 
 
+def cohort_partition(n_local, K):
+    """The ONE partition of a rank's individuals into K contiguous cohorts that the rollout plan, the breeding and the
+    resets all use: -> (bounds [K+1], cohort of each individual [n_local])."""
+    bounds = np.array([k * n_local // K for k in range(K + 1)], dtype=np.int64)
+    return bounds, np.searchsorted(bounds[1:], np.arange(n_local), side="right").astype(np.int32)
+
+
 DEFAULT_COHORTS = 1       # independent game cohorts per rollout (rollout.RolloutPlan._assign_cohorts); see DESIGN.md
 DEVICE_LOOP_COHORTS = 2   # ... in the host-free loop, where their launches are enqueued eagerly and do overlap
 
@@ -83,6 +90,9 @@ class GAEngine:
         self.device = device
         self.rank, self.world = shard
         self.gather = gather
+        if self.world > 1 and pop % self.world:
+            # the fitness all-gather (dist.allgather_shards) moves equal shards: unequal ones would hang RCCL
+            raise ValueError(f"population {pop} is not divisible by the number of ranks {self.world}")
         self.lo = self.rank * pop // self.world
         self.hi = (self.rank + 1) * pop // self.world
         self.n_local = self.hi - self.lo
@@ -134,15 +144,19 @@ class GAEngine:
         # cohorts = contiguous ranges of this rank's individuals (so that offspring can be bred cohort by cohort and a
         # cohort's chain can start while the next cohort is still being bred); the evaluation games go with the last
         self.K = max(1, min(int(cohorts), self.n_local)) if env == "device" else 1
+        self._set_cohort_bounds()
         game_cohort = None
         if self.K > 1:
-            per_ind = np.repeat((np.arange(self.n_local) * self.K) // self.n_local, self.hof)
+            # ONE partition for the rollout plan, the breeding and the resets: individual i of this rank belongs to the
+            # cohort whose [bounds[k], bounds[k+1]) holds it
+            per_ind = np.repeat(cohort_partition(self.n_local, self.K)[1], self.hof)
             game_cohort = np.concatenate([per_ind, per_ind, per_ind, np.full(N_EVAL, self.K - 1)]).astype(np.int32)
         try:
             self.plan = RolloutPlan(np.array(games), net_off, net_D, device=device, heavy_rows=heavy_rows,
                                     n_cohorts=self.K, game_cohort=game_cohort)
         except ValueError:  # tiny populations: the shared opponents have so few rows that they tie all games together
             self.K = 1
+            self._set_cohort_bounds()
             self.plan = RolloutPlan(np.array(games), net_off, net_D, device=device, heavy_rows=heavy_rows)
         if env == "device":
             self.ro = DeviceRollout(self.plan, self.slab, env_seed=env_seed, timing_pairs=timing_pairs)
@@ -431,8 +445,11 @@ class GAEngine:
         L.call("coevo_counter_add", g, 1)
 
     # ------------------------------------------------------------------ pipelined generation (cohort by cohort)
+    def _set_cohort_bounds(self):
+        self.cohort_bounds = cohort_partition(self.n_local, self.K)[0]
+
     def _cohort_individuals(self, k):
-        return self.lo + k * self.n_local // self.K, self.lo + (k + 1) * self.n_local // self.K
+        return self.lo + int(self.cohort_bounds[k]), self.lo + int(self.cohort_bounds[k + 1])
 
     def _breed_cohort(self, k, noise_gen):
         """children of the individuals of cohort k (child c = individual c + 1; individual 0 is the unchanged best),

@@ -13,7 +13,7 @@ Follows (file:line under /root/reference):
   diversity                    utils/game_logic_functions.py:12-37
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
-Parity status: PINNED by tests/golden/{ga_cfg1,ga_hof2,es_small,es_fs,play_game,fc_forward}.json.
+Parity status: PINNED by tests/golden/{ga_cfg1,ga_hof2,ga_long,es_small,es_fs,es_long,es_stop,play_game,fc_forward}.json.
 """
 from __future__ import annotations
 
@@ -197,12 +197,8 @@ def mutate_philox(flat, D, sigma, seed, stream_lo, stream_hi, skip_layernorm=Fal
     return out
 
 
-def ga_train(args, max_cycles=25, log=None, noise="torch", philox_seed=0):
-    """genetic_algorithm_train restated. args: attribute bag (mutated in place when adaptive).
-    noise="torch": the reference's own RNG calls; noise="philox": the build's device_philox offspring rule
-    (child c of role ri in generation g uses stream (c, 4g+ri); no torch draws after initialisation)."""
-    stream = Stream()
-    pop, hof_n, E = args.population, args.hof_size, args.elites_number
+def ga_initial(pop, hof_n):
+    """initial HoF and population in the reference's creation order (the torch generator is consumed in it)"""
     D = ROLE_D
     # genetic_algorithm.py:63-68 - creation order and (swapped) roles matter for the torch RNG
     hof = {"agent_1": [init_net(10) for _ in range(hof_n)]}
@@ -215,6 +211,28 @@ def ga_train(args, max_cycles=25, log=None, noise="torch", philox_seed=0):
     for _ in range(pop):  # :110-117 interleaved
         for r in ROLES:
             popu[r].append(init_net(D[r]))
+    return hof, popu
+
+
+def ga_game_nets(role, popu_i, hof, k, hof_n):
+    """(agent_0, agent_1, adversary) nets of HoF game k of an individual of `role` (genetic_algorithm.py:136-142,
+    168-174, 201-207; Q4: the adversary phase seats hof_agent_0 twice)"""
+    j = hof_n - 1 - k
+    if role == "agent_0":
+        return popu_i, hof["agent_1"][j], hof["adversary_0"][j]
+    if role == "agent_1":
+        return hof["agent_0"][j], popu_i, hof["adversary_0"][j]
+    return hof["agent_0"][j], hof["agent_0"][j], popu_i
+
+
+def ga_train(args, max_cycles=25, log=None, noise="torch", philox_seed=0):
+    """genetic_algorithm_train restated. args: attribute bag (mutated in place when adaptive).
+    noise="torch": the reference's own RNG calls; noise="philox": the build's device_philox offspring rule
+    (child c of role ri in generation g uses stream (c, 4g+ri); no torch draws after initialisation)."""
+    stream = Stream()
+    pop, hof_n, E = args.population, args.hof_size, args.elites_number
+    D = ROLE_D
+    hof, popu = ga_initial(pop, hof_n)
     stale = {r: popu[r][-1] for r in ROLES}  # Q3: objects left over from the init loop
     sig_attr = {"agent_0": "mutation_power_agent_0", "agent_1": "mutation_power_agent_1",
                 "adversary_0": "mutation_power_adversary"}
@@ -256,6 +274,7 @@ def ga_train(args, max_cycles=25, log=None, noise="torch", philox_seed=0):
             hof[r].append(best[r])
             hof[r].pop(0)
         new_pop = {}
+        rec["sigma_before"] = [getattr(args, sig_attr[r]) for r in ROLES]   # what this generation's children get
         for ri, r in enumerate(ROLES):  # mutate_elites: clone() builds a fresh net first (burns init draws)
             sigma = getattr(args, sig_attr[r])
             children = []
@@ -349,6 +368,8 @@ def es_train(args, max_cycles=25, noise="numpy", philox_seed=0):
     sig_attr = {"agent_0": "mutation_power_agent_0", "agent_1": "mutation_power_agent_1",
                 "adversary_0": "mutation_power_adversary"}
     hist = {r: [] for r in ROLES}
+    best = {r: -float("inf") for r in ROLES}       # evolutionary_strategy.py:211-219
+    no_improve = {r: 0 for r in ROLES}
     out = []
     for gen in range(args.generations):
         rec = {"games": []}
@@ -419,6 +440,15 @@ def es_train(args, max_cycles=25, noise="numpy", philox_seed=0):
                               args.mutation_power_adversary]
         rec["base"] = {r: base[r].copy() for r in ROLES}
         out.append(rec)
+        if getattr(args, "early_stopping", False):  # evolutionary_strategy.py:320-354: all three counters first,
+            for s, r in enumerate(ROLES):           # then the patience checks in role order; break before saving
+                if ev[s] > best[r] + args.min_delta:
+                    best[r], no_improve[r] = ev[s], 0
+                else:
+                    no_improve[r] += 1
+            if any(no_improve[r] >= args.patience for r in ROLES):
+                rec["stopped"] = True
+                break
     return out
 
 

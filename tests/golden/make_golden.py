@@ -278,6 +278,12 @@ def run_ga(cfg):
             "sigma_after": [plots[0]["mutation_power_history"][-1], plots[1]["mutation_power_history"][-1],
                             plots[2]["mutation_power_history"][-1]],
         })
+    if cfg.get("compact"):  # long runs: rewards + margins only, weight checksums of the last generation only
+        for g, rec_g in enumerate(gens_out):
+            rec_g["games"] = [{"rewards": x["rewards"], "min_margin": x["min_margin"], "steps": x["steps"]}
+                              for x in rec_g["games"]]
+            if g < gens - 1:
+                rec_g["saves"] = []
     return {"config": cfg, "env_resets": env.n_resets, "generations": gens_out,
             "final_args": {"mutation_power_agent_0": args.mutation_power_agent_0,
                            "mutation_power_agent_1": args.mutation_power_agent_1,
@@ -302,6 +308,15 @@ def run_es(cfg):
                              "mutation_power_history": None if mutation_power_history is None
                              else [float(m) for m in mutation_power_history]})
 
+    evals = []
+    _orig_eval = ref_es.evaluate_current_weights
+
+    def eval_hook(*a, **k):
+        out = _orig_eval(*a, **k)
+        evals.append([float(x) for x in out])
+        return out
+
+    ref_es.evaluate_current_weights = eval_hook
     ref_es.play_game = _logged_play_game
     ref_es.save_model = save_hook
     ref_es.plot_experiment_metrics = plot_hook
@@ -313,20 +328,28 @@ def run_es(cfg):
             agents = ref_es.evolution_strategy_train(env, args, td)
         finally:
             os.chdir(cwd)
-    pop, gens = args.population, args.generations
+            ref_es.evaluate_current_weights = _orig_eval
+    pop = args.population
     per_gen = 3 * pop + 10
+    gens = len(evals)                      # generations that ran (early stopping breaks before save / plot)
+    stopped_at = gens - 1 if len(rec["plots"]) // 3 < gens else None
     gens_out = []
     for g in range(gens):
         plots = rec["plots"][g * 3:(g + 1) * 3]
+        games = LOG.games[g * per_gen:(g + 1) * per_gen]
+        if cfg.get("compact"):
+            games = [{"rewards": x["rewards"], "min_margin": x["min_margin"], "steps": x["steps"]} for x in games]
         gens_out.append({
-            "games": LOG.games[g * per_gen:(g + 1) * per_gen],
-            "saves": rec["saves"][g * 3:(g + 1) * 3],
-            "eval_rewards": [p["rewards"][-1] for p in plots],
-            "diversity": [None if p["diversity"] is None else p["diversity"][-1] for p in plots],
-            "sigma_after": [p["mutation_power_history"][-1] for p in plots],
+            "games": games,
+            "saves": [] if cfg.get("compact") and g < gens - 1 else rec["saves"][g * 3:(g + 1) * 3],
+            "eval_rewards": evals[g],
+            "diversity": [None if p["diversity"] is None else p["diversity"][-1] for p in plots] if plots else None,
+            # the stopping generation is never plotted: its sigma is what the args bag holds at the end
+            "sigma_after": [p["mutation_power_history"][-1] for p in plots] if plots else
+            [args.mutation_power_agent_0, args.mutation_power_agent_1, args.mutation_power_adversary],
         })
     final = [flat_all_params(a.model) for a in agents]
-    return {"config": cfg, "env_resets": env.n_resets, "generations": gens_out,
+    return {"config": cfg, "env_resets": env.n_resets, "stopped_at": stopped_at, "generations": gens_out,
             "final_weights": [{"sha256": hashlib.sha256(w.tobytes()).hexdigest(),
                                "sum": float(np.sum(w.astype(np.float64))),
                                "l2": float(np.sqrt(np.sum(w.astype(np.float64) ** 2)))} for w in final]}
@@ -339,6 +362,13 @@ GA_CONFIGS = {
     # HoF>1, elites 3, fitness sharing on, no step limit (75-step cap), 3 generations
     "ga_hof2.json": {"seed": 7, "args": dict(generations=3, population=6, hof_size=2, elites_number=3,
                                               fitness_sharing=True, mutation_power_agent_0=0.005)},
+    # long horizon at tiny size: the gen > 10 branches of the adaptive mutation power (genetic_algorithm.py:323-345,
+    # quirk Q5: agent_0's increase starts from agent_1's sigma) both fire; h[-20:-10] is partial for gens 11..18
+    "ga_long.json": {"seed": 21, "compact": True,
+                     "args": dict(generations=26, population=4, hof_size=1, elites_number=2,
+                                  max_timesteps_per_episode=9, max_evaluation_steps=9, fitness_sharing=True,
+                                  mutation_power_agent_0=0.05, mutation_power_agent_1=0.08,
+                                  mutation_power_adversary=0.03, max_mutation_power=0.1, min_mutation_power=0.02)},
 }
 ES_CONFIGS = {
     "es_small.json": {"seed": 3, "args": dict(generations=2, population=6, hof_size=1, learning_rate=0.1,
@@ -346,6 +376,17 @@ ES_CONFIGS = {
     "es_fs.json": {"seed": 4, "args": dict(generations=2, population=5, hof_size=1, learning_rate=0.1,
                                             fitness_sharing=True, max_timesteps_per_episode=30,
                                             max_evaluation_steps=45)},
+    # long horizon: adaptive sigma past generation 10 (evolutionary_strategy.py:292-316)
+    "es_long.json": {"seed": 22, "compact": True,
+                     "args": dict(generations=26, population=4, hof_size=1, learning_rate=0.1,
+                                  max_timesteps_per_episode=9, max_evaluation_steps=9,
+                                  mutation_power_agent_0=0.05, mutation_power_agent_1=0.08,
+                                  mutation_power_adversary=0.03, max_mutation_power=0.1, min_mutation_power=0.02)},
+    # early stopping (evolutionary_strategy.py:320-354): breaks before save_model of the stopping generation
+    "es_stop.json": {"seed": 23, "compact": True,
+                     "args": dict(generations=12, population=4, hof_size=1, learning_rate=0.1,
+                                  max_timesteps_per_episode=9, max_evaluation_steps=9, early_stopping=True,
+                                  patience=3, min_delta=0.05)},
 }
 
 if __name__ == "__main__":

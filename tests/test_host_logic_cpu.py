@@ -168,3 +168,20 @@ def test_rollout_plan_cohorts_partition_games():
     tied = RolloutPlan(np.array([(40, i, 41) for i in range(6)]), {**{i: i for i in range(6)}, 40: 100, 41: 200},
                        {**{i: 10 for i in range(6)}, 40: 8, 41: 10}, device=None, n_cohorts=3)
     assert tied.n_cohorts == 1
+
+
+@pytest.mark.parametrize("n_local,K", [(9, 2), (201, 2), (200, 3), (11, 3), (10, 2), (7, 7), (5, 1)])
+def test_cohort_partition_is_one_consistent_partition(n_local, K):
+    """the rollout plan's game -> cohort map and the breeding / reset ranges come from the same boundaries (odd
+    per-rank populations used to disagree: a data race between the cohort streams)"""
+    from coevonet_amd.genetic_algorithm import cohort_partition
+    bounds, of = cohort_partition(n_local, K)
+    assert bounds[0] == 0 and bounds[-1] == n_local and np.all(np.diff(bounds) >= 1)
+    for k in range(K):
+        assert np.array_equal(np.nonzero(of == k)[0], np.arange(bounds[k], bounds[k + 1]))
+
+
+def test_unequal_shards_are_rejected():
+    from coevonet_amd.genetic_algorithm import GAEngine
+    with pytest.raises(ValueError, match="not divisible"):
+        GAEngine(pop=7, hof=1, elites=1, shard=(0, 2), device="cpu")

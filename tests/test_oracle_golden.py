@@ -107,6 +107,67 @@ def test_es_generations(name):
             np.testing.assert_allclose(got["diversity"], ref["diversity"], rtol=1e-5)
 
 
+def _safe_rewards(got_games, ref_games):
+    """compact fixtures (no action lists): fp64 reward triples bit for bit on margin-safe games"""
+    n_safe = 0
+    for got, ref in zip(got_games, ref_games):
+        assert got["steps"] == ref["steps"]
+        if ref["min_margin"] > SAFE_MARGIN:
+            assert got["rewards"] == ref["rewards"]
+            n_safe += 1
+    return n_safe
+
+
+def test_ga_long_horizon():
+    """26 generations at tiny size: the gen > 10 branches of the adaptive mutation power, quirk Q5 included, elite ids
+    and the final HoF / elite weights (genetic_algorithm.py:323-345)"""
+    fx = load_golden("ga_long.json")
+    cfg = fx["config"]
+    torch.manual_seed(cfg["seed"])
+    np.random.seed(cfg["seed"])
+    args = Bag(algorithm="GA", **cfg["args"])
+    out = rp.ga_train(args)
+    ups = 0
+    prev = None
+    for g, (got, ref) in enumerate(zip(out, fx["generations"])):
+        assert _safe_rewards(got["games"], ref["games"]) >= 0.9 * len(ref["games"])
+        assert got["elite_ids"] == ref["elite_ids"], f"gen {g}"
+        np.testing.assert_allclose(got["eval_rewards"], ref["eval_rewards"], rtol=1e-12)
+        assert got["sigma_after"] == ref["sigma_after"], f"gen {g}"
+        if prev is not None:
+            ups += sum(a > b for a, b in zip(ref["sigma_after"], prev))
+        prev = ref["sigma_after"]
+    assert len(out) == 26 and ups >= 10          # the fixture does take the increase branch
+    saves = {s["file"]: s["agents"] for s in fx["generations"][-1]["saves"]}
+    assert [sha(w) for w in out[-1]["hof"]["agent_0"]] == [a["sha256"] for a in saves["hall_of_fame_agent_0.pth"]]
+    assert [sha(w) for w in out[-1]["elites"]["adversary_0"]] == [a["sha256"] for a in saves["elite_weights_adversary.pth"]]
+
+
+@pytest.mark.parametrize("name", ["es_long.json", "es_stop.json"])
+def test_es_long_horizon_and_early_stopping(name):
+    """every generation's games against the reference fixture (exact on margin-safe games: the fp32 GEMV order of the
+    update moves weights by ~1 ulp, actions only at near-ties), sigma past generation 10, early stopping
+    (evolutionary_strategy.py:292-354)"""
+    fx = load_golden(name)
+    cfg = fx["config"]
+    torch.manual_seed(cfg["seed"])
+    np.random.seed(cfg["seed"])
+    args = Bag(algorithm="ES", **cfg["args"])
+    out = rp.es_train(args)
+    assert len(out) == len(fx["generations"])
+    assert (fx["stopped_at"] is not None) == bool(out[-1].get("stopped"))
+    if name == "es_stop.json":
+        assert fx["stopped_at"] == len(out) - 1 < cfg["args"]["generations"] - 1
+    exact = True  # until an evaluation game at a near-tie could have gone the other way on this host's BLAS
+    for g, (got, ref) in enumerate(zip(out, fx["generations"])):
+        assert _safe_rewards(got["games"], ref["games"]) >= 0.8 * len(ref["games"]), f"gen {g}"
+        exact = exact and all(x["min_margin"] > SAFE_MARGIN for x in ref["games"][-10:])
+        if exact:
+            np.testing.assert_allclose(got["eval_rewards"], ref["eval_rewards"], rtol=1e-12)
+            assert got["sigma_after"] == ref["sigma_after"], f"gen {g}"
+    assert exact or name == "es_long.json"
+
+
 def test_deepqn_forward_vectors():
     """oracle DeepQN.forward vs the logits the reference's DeepQN produced (train-mode BatchNorm at batch 1 =
     per-sample spatial statistics).  Tolerance = fp32 summation-order noise of 3136-term dot products."""
