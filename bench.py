@@ -119,6 +119,18 @@ def main():
                     "engine's DEFAULT_COHORTS)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks as fresh child processes (one per GPU, torch.distributed.run)
+        # BEFORE this process touches the GPU, forward their output (rank 0 prints the JSON line) and their exit code
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     from coevonet_amd import lib as L
     from coevonet_amd.dist import DistContext
     from coevonet_amd.game_logic import initialize_env
@@ -182,6 +194,8 @@ def main():
         "value": gens_per_s * steps_per_gen, "unit": "env-steps/s", "gens_per_sec": gens_per_s,
         "n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "dist_backend": (torch.distributed.get_backend() if ctx.world > 1 else None),
+        "rccl_ranks": (torch.distributed.get_world_size() if ctx.world > 1 else 1),
         "config": {"workload": f"Co-GA simple_adversary_v3 pop={pop} ({a.pop_per_gpu}/GPU) HoF={a.hof} "
                                f"elites={a.elites} T={a.limit} (env max_cycles={a.max_cycles} caps a game at "
                                f"{3 * a.max_cycles} agent-steps" + (", as in the reference" if a.max_cycles == 25 else

@@ -137,6 +137,13 @@ __global__ __launch_bounds__(256) void fc_perturb_kernel(const float *parent_sla
     __shared__ double scratch[4];
     if (gen_dev) stream_hi += 4u * (uint32_t)(*gen_dev);  // generation-indexed noise stream without a host argument
     const int c = blockIdx.y;
+    // flags: bit 0 = leave LayerNorm affine untouched (ES), bit 1 = antithetic pairs (extension mode): individuals 2m and
+    // 2m+1 share noise stream m, the odd one takes -eps
+    const bool antithetic = (skip_layernorm & 2) != 0;
+    skip_layernorm &= 1;
+    const uint32_t ind = stream_lo_first + (uint32_t)c;
+    const uint32_t slo = antithetic ? (ind >> 1) : ind;
+    const bool negate = antithetic && (ind & 1u);
     const int64_t stride = fc_stride(D), P = fc_params(D);
     const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     double d2 = 0.0;
@@ -154,11 +161,11 @@ __global__ __launch_bounds__(256) void fc_perturb_kernel(const float *parent_sla
             const int32_t t = s32 - o_w2;
             const int32_t l = (t >> 2) & 63, kq = (t >> 8) & 127, jb = t >> 15;
             const int32_t p0 = o_w2 + (jb * 64 + l) * H1 + kq * 4;  // multiple of 4
-            philox_normal4(seed, stream_lo_first + (uint32_t)c, stream_hi, (uint32_t)(p0 >> 2), z);
+            philox_normal4(seed, slo, stream_hi, (uint32_t)(p0 >> 2), z);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { keep[i] = false; in_dist[i] = true; }
         } else {
-            slab_quad_normals(seed, stream_lo_first + (uint32_t)c, stream_hi, s0, D, P, z);
+            slab_quad_normals(seed, slo, stream_hi, s0, D, P, z);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int64_t s = s0 + i;
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(256) void fc_perturb_kernel(const float *parent_sla
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float noise = sigma * z[i];  // rounded first, then added (agent.py:28-29)
-            out[i] = keep[i] ? in[i] : in[i] + noise;
+            out[i] = keep[i] ? in[i] : in[i] + (negate ? -noise : noise);
         }
         *reinterpret_cast<float4 *>(ch + s0) = make_float4(out[0], out[1], out[2], out[3]);
         if (dist_partial) {  // fitness-sharing distance of the new child to a reference net, while it is in registers
@@ -328,6 +335,82 @@ __global__ __launch_bounds__(256) void es_update_kernel(float *theta, const floa
     *reinterpret_cast<float4 *>(theta + s0) = make_float4(out[0], out[1], out[2], out[3]);
 }
 
+// K5 in two steps.  Step 1: partial[c][p] = sum over the individuals i of chunk c (global chunk gc = chunk_first + c
+// covers [gc*n/C, (gc+1)*n/C)), i ascending, of fitness[i] * (pert_i[p] - theta[p]), one fmaf per term starting from
+// 0.  grid (stride/1024, n_chunks): C times the workgroups of the sequential form (137 of them fill half the chip), and
+// a population shard computes exactly its own chunks.  Step 2 (es_apply_kernel): theta += scale * (((p_0 + p_1) + p_2)
+// + ...).  chunks_total = 1 is the sequential sum of es_update_kernel, bit for bit.
+__global__ __launch_bounds__(256) void es_partial_kernel(const float *theta, const float *pert_slab, int ind_first,
+                                                          int D, const float *fitness_all, int n_total,
+                                                          int chunks_total, int chunk_first, float *partial)
+{
+    const int64_t stride = fc_stride(D);
+    const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (s0 >= stride) return;
+    const int gc = chunk_first + blockIdx.y;
+    const int i_lo = (int)((int64_t)gc * n_total / chunks_total), i_hi = (int)((int64_t)(gc + 1) * n_total / chunks_total);
+    const float4 tv = *reinterpret_cast<const float4 *>(theta + s0);
+    const float th[4] = {tv.x, tv.y, tv.z, tv.w};
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float *pp = pert_slab + s0 - (int64_t)ind_first * stride;  // indexed by the GLOBAL individual
+    typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+    constexpr int UE = 16;
+    int i = i_lo;
+    for (; i + UE <= i_hi; i += UE) {
+        float4 pv[UE];
+#pragma unroll
+        for (int u = 0; u < UE; ++u) {
+            const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt *>(pp + (int64_t)(i + u) * stride));
+            pv[u] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+#pragma unroll
+        for (int u = 0; u < UE; ++u) {
+            const float f = fitness_all[i + u];
+            acc[0] = __builtin_fmaf(f, pv[u].x - th[0], acc[0]);
+            acc[1] = __builtin_fmaf(f, pv[u].y - th[1], acc[1]);
+            acc[2] = __builtin_fmaf(f, pv[u].z - th[2], acc[2]);
+            acc[3] = __builtin_fmaf(f, pv[u].w - th[3], acc[3]);
+        }
+    }
+    for (; i < i_hi; ++i) {
+        const float4 pv = *reinterpret_cast<const float4 *>(pp + (int64_t)i * stride);
+        const float f = fitness_all[i];
+        acc[0] = __builtin_fmaf(f, pv.x - th[0], acc[0]);
+        acc[1] = __builtin_fmaf(f, pv.y - th[1], acc[1]);
+        acc[2] = __builtin_fmaf(f, pv.z - th[2], acc[2]);
+        acc[3] = __builtin_fmaf(f, pv.w - th[3], acc[3]);
+    }
+    *reinterpret_cast<float4 *>(partial + (int64_t)blockIdx.y * stride + s0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+// partial of global chunk c lives at partials + (c / chunks_per_block) * block_stride + (c % chunks_per_block) * stride
+// (one block per rank after the all-gather; a single block on one GPU)
+__global__ __launch_bounds__(256) void es_apply_kernel(float *theta, const float *partials, int chunks_total,
+                                                        int chunks_per_block, int64_t block_stride, int D, int n_total,
+                                                        const float *sigma_dev, float lr)
+{
+    const int64_t stride = fc_stride(D), P = fc_params(D);
+    const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (s0 >= stride) return;
+    const float sigma = *sigma_dev;
+    const float scale = lr / ((float)n_total * sigma);
+    float4 tot = *reinterpret_cast<const float4 *>(partials + s0);
+    for (int c = 1; c < chunks_total; ++c) {
+        const float4 v = *reinterpret_cast<const float4 *>(partials + (int64_t)(c / chunks_per_block) * block_stride +
+                                                           (int64_t)(c % chunks_per_block) * stride + s0);
+        tot.x = tot.x + v.x; tot.y = tot.y + v.y; tot.z = tot.z + v.z; tot.w = tot.w + v.w;
+    }
+    const float4 tv = *reinterpret_cast<const float4 *>(theta + s0);
+    const float th[4] = {tv.x, tv.y, tv.z, tv.w}, ac[4] = {tot.x, tot.y, tot.z, tot.w};
+    float out[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int64_t s = s0 + c;
+        out[c] = (s < P && !fc_slab_is_layernorm(s, D)) ? th[c] + scale * ac[c] : th[c];
+    }
+    *reinterpret_cast<float4 *>(theta + s0) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
 __global__ __launch_bounds__(256) void fc_pack_kernel(const float *flat, float *slab, int D, bool to_slab)
 {
     const int net = blockIdx.y;
@@ -391,6 +474,15 @@ extern "C" int coevo_fc_perturb_gen(const float *parent_slab, const int32_t *par
                                  stream_lo_first, stream_hi, skip_layernorm, gen_dev, nullptr, nullptr, stream);
 }
 
+extern "C" int coevo_fc_perturb_flags(const float *parent_slab, const int32_t *parent_idx, float *child_slab,
+                                      int child_first, int n_children, int D, const float *sigma_dev, uint64_t seed,
+                                      uint32_t stream_lo_first, uint32_t stream_hi, int flags, void *stream)
+{
+    if (flags < 0 || flags > 3) return COEVO_ERR_ARG;
+    return coevo_fc_perturb_dist(parent_slab, parent_idx, child_slab, child_first, n_children, D, sigma_dev, seed,
+                                 stream_lo_first, stream_hi, flags, nullptr, nullptr, nullptr, stream);
+}
+
 extern "C" int64_t coevo_fc_perturb_blocks(int D) { return fc_dim_ok(D) ? (fc_stride(D) / 4 + 255) / 256 : COEVO_ERR_ARG; }
 
 extern "C" int coevo_fc_perturb_dist(const float *parent_slab, const int32_t *parent_idx, float *child_slab,
@@ -400,7 +492,8 @@ extern "C" int coevo_fc_perturb_dist(const float *parent_slab, const int32_t *pa
 {
     if ((dist_ref == nullptr) != (dist_partial == nullptr)) return COEVO_ERR_ARG;
     if (!parent_slab || !parent_idx || !child_slab || !sigma_dev || !fc_dim_ok(D)) return COEVO_ERR_ARG;
-    if (n_children < 0 || child_first < 0 || n_children > 65535) return COEVO_ERR_ARG;
+    if (n_children < 0 || child_first < 0 || n_children > 65535 || skip_layernorm < 0 || skip_layernorm > 3)
+        return COEVO_ERR_ARG;
     if (n_children == 0) return COEVO_OK;
     const dim3 grid((unsigned)((fc_stride(D) / 4 + 255) / 256), (unsigned)n_children);
     hipLaunchKernelGGL(fc_perturb_kernel, grid, dim3(256), 0, (hipStream_t)stream, parent_slab, parent_idx,
@@ -463,6 +556,37 @@ extern "C" int coevo_es_update(float *theta_slab_net, const float *pert_slab, in
     const dim3 grid((unsigned)((fc_stride(D) / 4 + 255) / 256));
     hipLaunchKernelGGL(es_update_kernel, grid, dim3(256), 0, (hipStream_t)stream, theta_slab_net, pert_slab, D,
                        fitness, n, sigma_dev, lr);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_es_partial(const float *theta_net, const float *pert_slab_local, int ind_first, int D,
+                                const float *fitness_all, int n_total, int chunks_total, int chunk_first, int n_chunks,
+                                float *partial, void *stream)
+{
+    if (!theta_net || !pert_slab_local || !fitness_all || !partial || !fc_dim_ok(D)) return COEVO_ERR_ARG;
+    if (n_total <= 0 || chunks_total <= 0 || chunk_first < 0 || n_chunks <= 0 || chunk_first + n_chunks > chunks_total ||
+        n_chunks > 65535 || ind_first < 0)
+        return COEVO_ERR_ARG;
+    // the caller's nets must start exactly where its first chunk starts
+    if ((int64_t)chunk_first * n_total / chunks_total != ind_first) return COEVO_ERR_ARG;
+    const dim3 grid((unsigned)((fc_stride(D) / 4 + 255) / 256), (unsigned)n_chunks);
+    hipLaunchKernelGGL(es_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, theta_net, pert_slab_local, ind_first,
+                       D, fitness_all, n_total, chunks_total, chunk_first, partial);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_es_apply(float *theta_net, const float *partials, int chunks_total, int chunks_per_block,
+                              int64_t block_stride_floats, int D, int n_total, const float *sigma_dev, float lr,
+                              void *stream)
+{
+    if (!theta_net || !partials || !sigma_dev || !fc_dim_ok(D) || n_total <= 0 || chunks_total <= 0 ||
+        chunks_per_block <= 0 || block_stride_floats < 0 || (block_stride_floats & 3))
+        return COEVO_ERR_ARG;
+    const dim3 grid((unsigned)((fc_stride(D) / 4 + 255) / 256));
+    hipLaunchKernelGGL(es_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, theta_net, partials, chunks_total,
+                       chunks_per_block, block_stride_floats, D, n_total, sigma_dev, lr);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

@@ -219,6 +219,22 @@ __global__ void ga_adapt_kernel(const double *rewards, int eval_first, const int
     for (int s = 0; s < 3; ++s) sigma32[s] = (float)sigma64[s];
 }
 
+// cfg 3 extension mode (NOT in the reference, which has its normalisation commented out at
+// evolutionary_strategy.py:133-135): centered ranks u_i = rank_i / (n-1) - 0.5, rank_i = number of individuals that sort
+// before i in a stable ascending sort (ties: lower index first).  One thread per individual, any n.
+__global__ __launch_bounds__(256) void centered_rank_kernel(const float *f, int n, float *out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float fi = f[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+        const float fj = f[j];
+        rank += (fj < fi || (fj == fi && j < i)) ? 1 : 0;
+    }
+    out[i] = (n > 1) ? (float)rank / (float)(n - 1) - 0.5f : 0.0f;
+}
+
 __global__ void counter_add_kernel(int32_t *p, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += v; }
 
 }  // namespace coevo
@@ -233,6 +249,14 @@ extern "C" int coevo_ga_adapt_sigma(const double *rewards, int eval_first_game, 
         return COEVO_ERR_ARG;
     hipLaunchKernelGGL(ga_adapt_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rewards, eval_first_game, gen_dev,
                        hist, sig_hist, cap, sigma64, sigma32, sig_min, sig_max, adaptive);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_centered_ranks(const float *fitness, int n, float *out, void *stream)
+{
+    if (!fitness || !out || n <= 0 || fitness == out) return COEVO_ERR_ARG;
+    hipLaunchKernelGGL(centered_rank_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, fitness, n, out);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

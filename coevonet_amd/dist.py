@@ -56,6 +56,21 @@ class DistContext:
         eng.last_reward.copy_(full[:, :, :3])
         eng.dist_all.copy_(full[:, :, 3])               # back to fp32 (exact: they were fp32 values)
 
+    def gather_es(self, eng, what):
+        """Co-ES exchanges (evolutionary_strategy.ESEngine.update_device): "stats" = per role and individual the reward
+        in the role's slot + the distance to the base net (fp64 pairs, 16 bytes per individual and role); "partials" =
+        this rank's chunk partial sums of the update (fp32, chunks/world * P per role), rank-major in eng.partials"""
+        if what == "stats":
+            full = allgather_shards(eng.stats[:, eng.lo:eng.hi].contiguous(), self.world)
+            eng.stats.copy_(full)
+        else:
+            blk = eng.part_block
+            mine = eng.partials[eng.rank * blk:(eng.rank + 1) * blk]
+            src = mine.cpu() if dist.get_backend() == "gloo" else mine.clone()
+            out = torch.empty(self.world * blk, dtype=src.dtype, device=src.device)
+            dist.all_gather_into_tensor(out, src)
+            eng.partials.copy_(out)
+
     def barrier(self):
         if self.world > 1:
             dist.barrier()

@@ -8,6 +8,15 @@ current base nets, in the interleaved order agent_0, agent_1, adversary_0 (game 
 sum_i f_i eps_i; optional fitness sharing f/(1+D); 10 evaluation games of the updated trio; adaptive sigma (Q5);
 early stopping.  hof_size is unused, as in the reference (Q12).
 
+Two things beyond the reference, both optional and labelled wherever they are reported:
+  * the cfg 3 EXTENSION mode of BASELINE.json configs[2] (``args.coevo_antithetic``, ``args.coevo_centered_rank``;
+    device_philox only): antithetic pairs (individuals 2m / 2m+1 share one noise stream with opposite signs) and the
+    centered-rank transform where the reference has its own normalisation commented out (:133-135).  OFF by default.
+  * population sharding over several GPUs: rank r perturbs, plays and partially sums individuals
+    [lo, hi); one all-gather of (reward, distance) per individual, one all-gather of the chunk partial sums (the
+    update is defined as ES_CHUNKS chunk sums added left to right, so N ranks reproduce one rank bit for bit); the 10
+    evaluation games are replicated.
+
 rng modes
   "host_reference"  noise from the global numpy generator in the reference's call order, perturbed nets and the update
                     computed on the host exactly as the reference does (fp64 noise, fp32 GEMV) and uploaded - parity;
@@ -29,10 +38,26 @@ from .mpe.simple_adversary import ENV_SEED
 from .rollout import DeviceRollout, HostEnvRollout, RolloutPlan, effective_steps
 
 
+ES_CHUNKS = 8   # the canonical ES summation: this many chunk sums, added left to right (include/coevo.h, K5)
+
+
 class ESEngine:
     def __init__(self, pop, limit_train=None, limit_eval=None, max_cycles=25, device="cuda", env_seed=ENV_SEED,
-                 rng="device_philox", philox_seed=0, env="device", first_ordinal=1):
+                 rng="device_philox", philox_seed=0, env="device", first_ordinal=1, shard=(0, 1), gather=None,
+                 antithetic=False, centered_rank=False, chunks=ES_CHUNKS):
         self.pop, self.rng_mode, self.philox_seed, self.env_mode, self.device = pop, rng, int(philox_seed), env, device
+        self.rank, self.world = shard
+        self.gather = gather
+        self.antithetic, self.centered_rank, self.chunks = bool(antithetic), bool(centered_rank), int(chunks)
+        if self.world > 1 and (pop % self.world or self.chunks % self.world):
+            raise ValueError(f"population {pop} and the {self.chunks} update chunks must both be divisible by the "
+                             f"number of ranks {self.world}")
+        if (self.antithetic or self.centered_rank or self.world > 1) and rng != "device_philox":
+            raise ValueError("the extension mode and the sharded run need device_philox offspring")
+        if self.antithetic and pop % 2:
+            raise ValueError("antithetic pairs need an even population")
+        self.lo, self.hi = self.rank * pop // self.world, (self.rank + 1) * pop // self.world
+        self.n_local = self.hi - self.lo
         self.T_train = effective_steps(limit_train, max_cycles)
         self.T_eval = effective_steps(limit_eval, max_cycles)
         self.n_cycles = (max(self.T_train, self.T_eval) + 2) // 3
@@ -42,7 +67,7 @@ class ESEngine:
         self.base, off = {}, 0
         for r in ROLES:
             self.base[r] = {"base": off, "pert": off + self.stride[r]}
-            off += (1 + pop) * self.stride[r]
+            off += (1 + self.n_local) * self.stride[r]
         self.slab = torch.zeros(off, dtype=torch.float32, device=device)
         net_off, net_D, ids = [], [], {}
 
@@ -55,7 +80,7 @@ class ESEngine:
             return ids[key]
 
         games = []
-        for j in range(pop):  # evolutionary_strategy.py:236-251: mutate_weights for agent_0, agent_1, adversary_0
+        for j in range(self.n_local):  # evolutionary_strategy.py:236-251: mutate_weights for agent_0, agent_1, adversary_0
             for r in ROLES:
                 seat = {q: net("base", q) for q in ROLES}
                 seat[r] = net("pert", r, j)
@@ -76,11 +101,23 @@ class ESEngine:
         self.eval_ro = cls(self.eval_plan, self.slab, env_seed=env_seed)
         f32 = dict(dtype=torch.float32, device=device)
         self.fitness = {r: torch.zeros(pop, **f32) for r in ROLES}
-        self.dist = {r: torch.zeros(pop, **f32) for r in ROLES}
+        self.raw = {r: torch.zeros(pop, **f32) for r in ROLES}
+        self.dist_local = {r: torch.zeros(max(self.n_local, 1), **f32) for r in ROLES}
         self.div = {r: torch.zeros(1, **f32) for r in ROLES}
         self.sigma = {r: torch.zeros(1, **f32) for r in ROLES}
-        self.zero_idx = torch.zeros(pop, dtype=torch.int32, device=device)
-        self.game_idx = {r: torch.arange(pop, device=device) * 3 + ri for ri, r in enumerate(ROLES)}
+        self.zero_idx = torch.zeros(max(self.n_local, 1), dtype=torch.int32, device=device)
+        self.game_idx = torch.stack([torch.arange(self.n_local, device=device) * 3 + ri for ri in range(3)])
+        self.ret_slot = torch.tensor([RET_SLOT[r] for r in ROLES], device=device)
+        # per individual (reward in the role's slot, distance to the base net), all roles: what the ranks exchange
+        self.stats = torch.zeros(3, pop, 2, dtype=torch.float64, device=device)
+        # chunk partial sums of the update, rank-major: [world][role][chunks/world][stride_role]
+        self.chunks_local = self.chunks // self.world
+        self.part_off, o = {}, 0
+        for r in ROLES:
+            self.part_off[r] = o
+            o += self.chunks_local * self.stride[r]
+        self.part_block = o
+        self.partials = torch.zeros(self.world * self.part_block, **f32)
         self.steps_per_generation = 3 * pop * self.T_train + N_EVAL * self.T_eval
 
     def _ptr(self, role, region, i=0):
@@ -100,19 +137,22 @@ class ESEngine:
         return self.first_ordinal + gen * (3 * self.pop + N_EVAL)
 
     def perturb_device(self, gen, sigmas):
+        """this rank's perturbed nets: individual j (global index) of role ri takes noise stream (j, 4*gen + ri)"""
+        flags = 1 | (2 if self.antithetic else 0)   # LayerNorm untouched; antithetic pairs in the extension mode
         for ri, r in enumerate(ROLES):
             self.sigma[r].fill_(float(sigmas[r]))
-            L.call("coevo_fc_perturb", self._ptr(r, "base"), L._p(self.zero_idx), self._ptr(r, "pert"), 0, self.pop,
-                   ROLE_D[r], L._p(self.sigma[r]), self.philox_seed, 0, gen * 4 + ri, 1)
+            L.call("coevo_fc_perturb_flags", self._ptr(r, "base"), L._p(self.zero_idx), self._ptr(r, "pert"), 0,
+                   self.n_local, ROLE_D[r], L._p(self.sigma[r]), self.philox_seed, self.lo, gen * 4 + ri, flags)
 
     def rollout(self, gen):
-        """the 3*pop training games of generation `gen` (game ordinal 3j + role in the seeded stream)"""
+        """this rank's 3*n_local training games of generation `gen` (game ordinal 3j + role in the seeded stream)"""
         ro = self.ro
         ro.set_limits(np.full(self.plan.n_games, self.T_train, dtype=np.int32))
+        first = self._ordinal_base(gen) + 3 * self.lo
         if self.env_mode == "device":
-            ro.reset(0, self.n_main, self._ordinal_base(gen))
+            ro.reset(0, self.n_main, first)
         else:
-            ro.reset_from_ordinals(self._ordinal_base(gen) + np.arange(self.n_main))
+            ro.reset_from_ordinals(first + np.arange(self.n_main))
         if getattr(ro, "n_cohorts", 1) > 1:
             ro.enqueue((self.T_train + 2) // 3)  # cohort chains overlap only when enqueued eagerly
         else:
@@ -141,17 +181,36 @@ class ESEngine:
         return r.cpu().numpy() if torch.is_tensor(r) else r
 
     def update_device(self, gen, lr, fitness_sharing):
-        """compute_weight_update (evolutionary_strategy.py:120-148) + base += update, on the device"""
+        """compute_weight_update (evolutionary_strategy.py:120-148) + base += update, on the device.  Sharded: the
+        (reward, distance) pairs and then the chunk partial sums are all-gathered; every rank applies the same update."""
         rew = self.ro.rewards if torch.is_tensor(self.ro.rewards) else torch.from_numpy(self.ro.rewards).to(self.device)
+        lo, hi = self.lo, self.hi
+        self.stats[:, lo:hi, 0] = rew[self.game_idx, self.ret_slot[:, None]]
+        if fitness_sharing:
+            for ri, r in enumerate(ROLES):
+                L.call("coevo_fc_distance", self._ptr(r, "base"), self._ptr(r, "pert"), self.n_local, ROLE_D[r],
+                       L._p(self.dist_local[r]))
+                self.stats[ri, lo:hi, 1] = self.dist_local[r][:self.n_local]
+        if self.world > 1:
+            self.gather(self, "stats")
         for ri, r in enumerate(ROLES):
-            f = rew[self.game_idx[r], RET_SLOT[r]].to(torch.float32)  # np.array(rewards, dtype=float32)
+            self.raw[r].copy_(self.stats[ri, :, 0])                  # np.array(rewards, dtype=float32)
             if fitness_sharing:
-                L.call("coevo_fc_diversity", self._ptr(r, "base"), self._ptr(r, "pert"), self.pop, ROLE_D[r],
-                       L._p(self.dist[r]), L._p(self.div[r]))
-                f = f / (1.0 + self.div[r])
-            self.fitness[r].copy_(f)
-            L.call("coevo_es_update", self._ptr(r, "base"), self._ptr(r, "pert"), ROLE_D[r], L._p(self.fitness[r]),
-                   self.pop, L._p(self.sigma[r]), L.C.c_float(lr))
+                d = self.stats[ri, :, 1].to(torch.float32).contiguous()
+                L.call("coevo_sharing_score", L._p(d), self.pop, L._p(self.div[r]))
+                self.raw[r].div_(1.0 + self.div[r])
+            if self.centered_rank:
+                L.call("coevo_centered_ranks", L._p(self.raw[r]), self.pop, L._p(self.fitness[r]))
+            else:
+                self.fitness[r].copy_(self.raw[r])
+            L.call("coevo_es_partial", self._ptr(r, "base"), self._ptr(r, "pert"), lo, ROLE_D[r],
+                   L._p(self.fitness[r]), self.pop, self.chunks, self.rank * self.chunks_local, self.chunks_local,
+                   self.partials.data_ptr() + 4 * (self.rank * self.part_block + self.part_off[r]))
+        if self.world > 1:
+            self.gather(self, "partials")
+        for ri, r in enumerate(ROLES):
+            L.call("coevo_es_apply", self._ptr(r, "base"), self.partials.data_ptr() + 4 * self.part_off[r], self.chunks,
+                   self.chunks_local, self.part_block, ROLE_D[r], self.pop, L._p(self.sigma[r]), L.C.c_float(lr))
 
 
 class ESResult:
@@ -171,17 +230,23 @@ def _linear_mask(D):
 
 
 class ESTrainer:
-    def __init__(self, env, args, rng=None, env_mode=None, collect=True):
+    def __init__(self, env, args, rng=None, env_mode=None, collect=True, dist_ctx=None):
         self.env, self.args, self.collect = env, args, collect
         self.rng = rng or getattr(args, "coevo_rng", "host_reference")
         env_mode = env_mode or getattr(args, "coevo_env", "device")
         self.first_ordinal = getattr(env, "n_resets", 1)
         agents = {r: create_agent(env, args, role=r) for r in ROLES}  # evolutionary_strategy.py:163-165
+        shard, gather = (0, 1), None
+        if dist_ctx is not None and dist_ctx.world > 1:
+            shard, gather = (dist_ctx.rank, dist_ctx.world), dist_ctx.gather_es
         self.eng = ESEngine(args.population, args.max_timesteps_per_episode, args.max_evaluation_steps,
                             max_cycles=getattr(env, "max_cycles", 25), rng=self.rng,
                             philox_seed=getattr(args, "coevo_seed", 0), env=env_mode,
                             first_ordinal=self.first_ordinal,
-                            env_seed=getattr(env, "seed_value", ENV_SEED) or ENV_SEED)
+                            env_seed=getattr(env, "seed_value", ENV_SEED) or ENV_SEED, shard=shard, gather=gather,
+                            antithetic=getattr(args, "coevo_antithetic", False),
+                            centered_rank=getattr(args, "coevo_centered_rank", False),
+                            chunks=getattr(args, "coevo_es_chunks", ES_CHUNKS))
         keep = [self.eng.upload(r, "base", 0, agents[r].model.flat()[None]) for r in ROLES]
         torch.cuda.current_stream().synchronize()
         self.base_flat = {r: agents[r].model.flat().copy() for r in ROLES}  # host copy (host_reference mode)
@@ -291,12 +356,13 @@ class ESTrainer:
         return tuple(out)
 
 
-def evolution_strategy_train(env, args, output_dir, rng=None, env_mode=None, collect=True, return_result=False):
+def evolution_strategy_train(env, args, output_dir, rng=None, env_mode=None, collect=True, return_result=False,
+                             dist_ctx=None):
     """Drop-in for evolutionary_strategy.py:151: returns (agent_0, agent_1, adversary) like the reference; with
     return_result=True also the ESResult history (what the reference only plots)."""
     import os
     from .io_utils import ES_FILES, MetricsWriter, save_model
-    tr = ESTrainer(env, args, rng=rng, env_mode=env_mode, collect=collect)
+    tr = ESTrainer(env, args, rng=rng, env_mode=env_mode, collect=collect, dist_ctx=dist_ctx)
     save = bool(getattr(args, "save", False)) and output_dir is not None
     for _ in range(args.generations):
         go_on = tr.step()

@@ -121,6 +121,13 @@ _SIGS = {
                                        C.c_void_p]),
     "coevo_fc_perturb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]),
+    "coevo_fc_perturb_flags": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]),
+    "coevo_es_partial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_void_p, C.c_void_p]),
+    "coevo_es_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_void_p,
+                                 C.c_float, C.c_void_p]),
+    "coevo_centered_ranks": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "coevo_fc_rebuild_elites": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64,
                                           C.c_uint32, C.c_void_p, C.c_void_p]),
     "coevo_fc_perturb_gen": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,

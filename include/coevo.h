@@ -230,6 +230,13 @@ int coevo_mpe_final_step(const double *state, int n_games, const int32_t *action
 int coevo_fc_perturb(const float *parent_slab, const int32_t *parent_idx, float *child_slab, int child_first,
                      int n_children, int D, const float *sigma_dev, uint64_t seed, uint32_t stream_lo_first,
                      uint32_t stream_hi, int skip_layernorm, void *stream);
+/* coevo_fc_perturb with flags: bit 0 = skip_layernorm, bit 1 = antithetic pairs (cfg 3 extension mode, NOT in the
+ * reference: individuals 2m and 2m+1, counted from stream_lo_first + c, share noise stream m; the odd one gets -eps) */
+#define COEVO_PERTURB_SKIP_LAYERNORM 1
+#define COEVO_PERTURB_ANTITHETIC 2
+int coevo_fc_perturb_flags(const float *parent_slab, const int32_t *parent_idx, float *child_slab, int child_first,
+                           int n_children, int D, const float *sigma_dev, uint64_t seed, uint32_t stream_lo_first,
+                           uint32_t stream_hi, int flags, void *stream);
 /* coevo_fc_perturb with the generation taken from a device counter: stream_hi_eff = stream_hi + 4 * (*gen_dev) */
 int coevo_fc_perturb_gen(const float *parent_slab, const int32_t *parent_idx, float *child_slab, int child_first,
                          int n_children, int D, const float *sigma_dev, uint64_t seed, uint32_t stream_lo_first,
@@ -289,6 +296,25 @@ int coevo_fc_gather(const float *src_slab, const int32_t *src_idx, float *dst_sl
  * theta is ONE net in slab layout, pert_slab the n perturbed nets coevo_fc_perturb materialised from it. */
 int coevo_es_update(float *theta_slab_net, const float *pert_slab, int D, const float *fitness, int n,
                     const float *sigma_dev, float lr, void *stream);
+
+/* K5 in two steps - the canonical ES summation of this build: the n individuals are cut into chunks_total chunks (chunk
+ * c = [c*n/C, (c+1)*n/C)), each chunk is summed i-ascending with one fmaf per term from 0 (coevo_es_partial), the chunk
+ * sums are added left to right and applied (coevo_es_apply).  chunks_total = 1 is coevo_es_update.  More workgroups on
+ * one GPU, and the unit a population shard owns on several (evolutionary_strategy.py:236-265 distributed as SURVEY 8e
+ * describes: a rank computes the partial sums of its own individuals, partials are all-gathered, every rank applies the
+ * identical update - N ranks give the bits of one).
+ *   pert_slab_local: the caller's perturbed nets, the first one being global individual ind_first (= start of chunk
+ *   chunk_first); fitness_all [n_total] indexed by the global individual; partial [n_chunks][slab stride]. */
+int coevo_es_partial(const float *theta_net, const float *pert_slab_local, int ind_first, int D,
+                     const float *fitness_all, int n_total, int chunks_total, int chunk_first, int n_chunks,
+                     float *partial, void *stream);
+/* partial of global chunk c at partials + (c / chunks_per_block) * block_stride_floats + (c % chunks_per_block) *
+ * stride: one block per rank after the all-gather (block_stride_floats = floats each rank contributed) */
+int coevo_es_apply(float *theta_net, const float *partials, int chunks_total, int chunks_per_block,
+                   int64_t block_stride_floats, int D, int n_total, const float *sigma_dev, float lr, void *stream);
+/* cfg 3 extension mode (BASELINE.json configs[2]; the reference's own normalisation is commented out at
+ * evolutionary_strategy.py:133-135): out[i] = rank_i / (n-1) - 0.5, stable ascending rank (ties: lower index first) */
+int coevo_centered_ranks(const float *fitness, int n, float *out, void *stream);
 
 /* ---------------------------------------------------------------- K6/K7: fitness, sharing, selection -------- */
 /* distances d[i] = || w_i - w_ref ||_2 over the Linear weights/biases (get_weights_ES default layers) and the

@@ -435,9 +435,10 @@ void oracle_philox_normal4(uint64_t seed, uint32_t stream_lo, uint32_t stream_hi
 /* child[p] = parent[p] + sigma*z[p]  (noise rounded first, then added - agent.py:28-29).
  * skip = list of [off,len) segments left untouched (LayerNorm affine for ES, agent.py:51-53 via
  * MPE/fcnetwork.py:185-199). */
+/* negate != 0: the antithetic partner, child = parent - sigma*eps (cfg 3 extension mode, not in the reference) */
 void oracle_perturb_philox(const float *parent, float *child, int P, float sigma, uint64_t seed,
                            uint32_t stream_lo, uint32_t stream_hi, const int *skip_off,
-                           const int *skip_len, int nskip)
+                           const int *skip_len, int nskip, int negate)
 {
     for (int q = 0; q * 4 < P; ++q) {
         float z[4];
@@ -446,24 +447,32 @@ void oracle_perturb_philox(const float *parent, float *child, int P, float sigma
             int p = q * 4 + i, skipped = 0;
             for (int g = 0; g < nskip; ++g)
                 if (p >= skip_off[g] && p < skip_off[g] + skip_len[g]) skipped = 1;
-            child[p] = skipped ? parent[p] : parent[p] + sigma * z[i];
+            const float noise = sigma * z[i];
+            child[p] = skipped ? parent[p] : parent[p] + (negate ? -noise : noise);
         }
     }
 }
 
 /* theta[p] += scale * sum_i fitness[i] * (pert_i[p] - theta[p]), i ascending, one fmaf per term, fp32
  * (evolutionary_strategy.py:144 with the perturbation read back from the perturbed nets).  pert = [n][P] flat. */
+/* chunks: the build's canonical ES summation (include/coevo.h, coevo_es_partial): chunk c = [c*n/C, (c+1)*n/C) summed
+ * i-ascending from 0, chunk sums added left to right; chunks = 1 is the plain sequential sum */
 void oracle_es_update_from_pert(float *theta, int P, const float *pert, const float *fitness, int n, float scale,
-                                const int *skip_off, const int *skip_len, int nskip)
+                                const int *skip_off, const int *skip_len, int nskip, int chunks)
 {
     for (int p = 0; p < P; ++p) {
         int skipped = 0;
         for (int g = 0; g < nskip; ++g)
             if (p >= skip_off[g] && p < skip_off[g] + skip_len[g]) skipped = 1;
         if (skipped) continue;
-        float acc = 0.0f;
-        for (int i = 0; i < n; ++i) acc = fmaf(fitness[i], pert[(size_t)i * P + p] - theta[p], acc);
-        theta[p] = theta[p] + scale * acc;
+        float tot = 0.0f;
+        for (int c = 0; c < chunks; ++c) {
+            const int lo = (int)((long long)c * n / chunks), hi = (int)((long long)(c + 1) * n / chunks);
+            float acc = 0.0f;
+            for (int i = lo; i < hi; ++i) acc = fmaf(fitness[i], pert[(size_t)i * P + p] - theta[p], acc);
+            tot = (c == 0) ? acc : tot + acc;
+        }
+        theta[p] = theta[p] + scale * tot;
     }
 }
 

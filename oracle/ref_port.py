@@ -63,8 +63,8 @@ def lib():
         L.oracle_diversity.argtypes = [fp, fp, C.c_int, C.c_size_t, ip, ip, C.c_int, fp]
         L.oracle_philox_normal4.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, fp]
         L.oracle_perturb_philox.argtypes = [fp, fp, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32,
-                                            ip, ip, C.c_int]
-        L.oracle_es_update_from_pert.argtypes = [fp, C.c_int, fp, fp, C.c_int, C.c_float, ip, ip, C.c_int]
+                                            ip, ip, C.c_int, C.c_int]
+        L.oracle_es_update_from_pert.argtypes = [fp, C.c_int, fp, fp, C.c_int, C.c_float, ip, ip, C.c_int, C.c_int]
         L.oracle_dqn_param_count.restype = C.c_long
         L.oracle_dqn_forward.restype = C.c_int
         L.oracle_dqn_forward.argtypes = [fp, C.c_int, C.c_int, C.c_void_p, fp]
@@ -185,16 +185,22 @@ def diversity(individual_es, population_es):
 
 
 # ------------------------------------------------------------------ Co-GA
-def mutate_philox(flat, D, sigma, seed, stream_lo, stream_hi, skip_layernorm=False):
-    """child = parent + sigma*eps with the build's counter-based noise (device_philox mode)"""
-    P = param_count(D)
-    out = np.zeros(P, dtype=np.float32)
-    segs = ln_segments(D) if skip_layernorm else []
-    so = np.array([s[0] for s in segs], dtype=np.int32)
-    sl = np.array([s[1] for s in segs], dtype=np.int32)
-    lib().oracle_perturb_philox(_fp(np.ascontiguousarray(flat)), _fp(out), P, float(sigma), int(seed), int(stream_lo),
-                                int(stream_hi), _ip(so), _ip(sl), len(segs))
+def perturb_philox_flat(flat, sigma, seed, stream_lo, stream_hi, skip_segments=(), negate=False):
+    """child = parent +- sigma*eps(seed, stream, canonical index) over any flat parameter vector (FCNetwork or DeepQN)"""
+    flat = np.ascontiguousarray(flat, dtype=np.float32)
+    out = np.zeros(len(flat), dtype=np.float32)
+    so = np.array([s[0] for s in skip_segments], dtype=np.int32)
+    sl = np.array([s[1] for s in skip_segments], dtype=np.int32)
+    lib().oracle_perturb_philox(_fp(flat), _fp(out), len(flat), float(sigma), int(seed), int(stream_lo),
+                                int(stream_hi), _ip(so), _ip(sl), len(skip_segments), 1 if negate else 0)
     return out
+
+
+def mutate_philox(flat, D, sigma, seed, stream_lo, stream_hi, skip_layernorm=False, negate=False):
+    """child = parent + sigma*eps with the build's counter-based noise (device_philox mode)"""
+    assert len(flat) == param_count(D)
+    return perturb_philox_flat(flat, sigma, seed, stream_lo, stream_hi, ln_segments(D) if skip_layernorm else (),
+                               negate)
 
 
 def ga_initial(pop, hof_n):
@@ -342,7 +348,21 @@ def set_perturbable(flat, D, vec):
     return out
 
 
-def es_update_from_pert(theta, D, pert, fitness, sigma, lr):
+ES_CHUNKS = 8   # the build's canonical ES summation: 8 chunk sums added left to right (coevo_es_partial / _apply)
+
+
+def centered_ranks(f):
+    """cfg 3 extension mode (not in the reference): u_i = rank_i/(n-1) - 0.5, stable ascending rank"""
+    f = np.asarray(f, dtype=np.float32)
+    n = len(f)
+    ranks = np.empty(n, dtype=np.int64)
+    ranks[np.argsort(f, kind="stable")] = np.arange(n)
+    if n == 1:
+        return np.zeros(1, dtype=np.float32)
+    return (ranks.astype(np.float32) / np.float32(n - 1) - np.float32(0.5)).astype(np.float32)
+
+
+def es_update_from_pert(theta, D, pert, fitness, sigma, lr, chunks=ES_CHUNKS):
     """theta += lr/(n*sigma) * sum_i f_i * (pert_i - theta) over the Linear entries (device_philox mode)"""
     P = param_count(D)
     out = np.ascontiguousarray(theta, dtype=np.float32).copy()
@@ -353,13 +373,18 @@ def es_update_from_pert(theta, D, pert, fitness, sigma, lr):
     pert = np.ascontiguousarray(pert, dtype=np.float32)
     n = len(f)
     scale = np.float32(lr) / (np.float32(n) * np.float32(sigma))
-    lib().oracle_es_update_from_pert(_fp(out), P, _fp(pert), _fp(f), n, float(scale), _ip(so), _ip(sl), len(segs))
+    lib().oracle_es_update_from_pert(_fp(out), P, _fp(pert), _fp(f), n, float(scale), _ip(so), _ip(sl), len(segs),
+                                     int(chunks))
     return out
 
 
-def es_train(args, max_cycles=25, noise="numpy", philox_seed=0):
+def es_train(args, max_cycles=25, noise="numpy", philox_seed=0, antithetic=False, centered_rank=False):
     """evolution_strategy_train restated; noise="numpy": the reference's own RNG calls; noise="philox": the build's
-    device_philox rule (perturbed net j of role ri in generation g uses stream (j, 4g+ri), fp32 noise, fp32 update)."""
+    device_philox rule (perturbed net j of role ri in generation g uses stream (j, 4g+ri), fp32 noise, fp32 update).
+    antithetic / centered_rank (philox only): the cfg 3 EXTENSION mode of BASELINE.json configs[2], not in the reference:
+    individuals 2m, 2m+1 share stream m with opposite signs; fitness -> centered ranks where the reference has its
+    normalisation commented out (evolutionary_strategy.py:133-135)."""
+    assert noise == "philox" or not (antithetic or centered_rank)
     mode = noise
     stream = Stream()
     D = ROLE_D
@@ -381,8 +406,8 @@ def es_train(args, max_cycles=25, noise="numpy", philox_seed=0):
             for s, r in enumerate(ROLES):
                 sigma = getattr(args, sig_attr[r])
                 if mode == "philox":
-                    mutated = mutate_philox(base[r], D[r], np.float32(sigma), philox_seed, _, gen * 4 + s,
-                                            skip_layernorm=True)
+                    mutated = mutate_philox(base[r], D[r], np.float32(sigma), philox_seed, (_ >> 1) if antithetic else _,
+                                            gen * 4 + s, skip_layernorm=True, negate=bool(antithetic and (_ & 1)))
                     nets = {q: base[q] for q in ROLES}
                     nets[r] = mutated
                     g = play_game(stream, nets["agent_0"], nets["agent_1"], nets["adversary_0"],
@@ -412,6 +437,8 @@ def es_train(args, max_cycles=25, noise="numpy", philox_seed=0):
                 div = diversity(base_w[r], pop_w[r])
                 f = f / (1 + div)
             sigma = getattr(args, sig_attr[r])
+            if centered_rank:
+                f = centered_ranks(f)
             if mode == "philox":
                 base[r] = es_update_from_pert(base[r], D[r], np.stack(pert_full[r]), f, sigma, args.learning_rate)
                 base_w[r] = perturbable(base[r], D[r])

@@ -39,3 +39,50 @@ def test_allgather_shards_world2_gloo():
 def test_allgather_single_process_is_identity():
     x = torch.rand(3, 5, 4, dtype=torch.float64)
     assert allgather_shards(x, 1) is x
+
+
+class _FakeESEngine:
+    """the fields DistContext.gather_es touches (evolutionary_strategy.ESEngine), on the CPU"""
+
+    def __init__(self, rank, world, pop, blk):
+        self.rank, self.world = rank, world
+        self.lo, self.hi = rank * pop // world, (rank + 1) * pop // world
+        self.stats = torch.zeros(3, pop, 2, dtype=torch.float64)
+        self.part_block = blk
+        self.partials = torch.zeros(world * blk, dtype=torch.float32)
+
+
+def _worker_es(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from coevonet_amd.dist import DistContext
+    ctx = DistContext(backend="gloo")
+    pop, blk = 12, 40
+    full_stats = torch.arange(3 * pop * 2, dtype=torch.float64).reshape(3, pop, 2) / 7
+    full_parts = torch.arange(world * blk, dtype=torch.float32) * 0.25
+    eng = _FakeESEngine(rank, world, pop, blk)
+    eng.stats[:, eng.lo:eng.hi] = full_stats[:, eng.lo:eng.hi]
+    eng.partials[rank * blk:(rank + 1) * blk] = full_parts[rank * blk:(rank + 1) * blk]
+    ctx.gather_es(eng, "stats")
+    ctx.gather_es(eng, "partials")
+    ret[rank] = bool(torch.equal(eng.stats, full_stats) and torch.equal(eng.partials, full_parts))
+    ctx.shutdown()
+
+
+def test_gather_es_world2_gloo():
+    """the two Co-ES exchanges: (reward, distance) pairs by individual, chunk partial sums rank-major"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_es, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_es_engine_rejects_unaligned_shards():
+    import pytest
+    from coevonet_amd.evolutionary_strategy import ESEngine
+    with pytest.raises(ValueError, match="divisible"):
+        ESEngine(pop=9, shard=(0, 2), device="cpu")
+    with pytest.raises(ValueError, match="divisible"):
+        ESEngine(pop=12, shard=(0, 3), device="cpu")     # 8 chunks over 3 ranks
+    with pytest.raises(ValueError, match="even"):
+        ESEngine(pop=9, antithetic=True, device="cpu")

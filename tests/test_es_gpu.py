@@ -94,3 +94,27 @@ def test_es_device_philox_without_sharing_is_bit_exact():
     for a, r in zip(agents, ROLES):
         assert sha(a.model.flat()) == sha(want[-1]["base"][r])
     assert [res.rewards[r][-1] for r in ROLES] == want[-1]["eval_rewards"]
+
+
+def test_es_extension_mode_matches_oracle_port():
+    """BASELINE configs[2] wording (antithetic pairs + centered ranks, on-device rank): NOT the reference's algorithm,
+    a labelled extension - bit for bit the oracle port's statement of it"""
+    cfg = {"seed": 6, "args": dict(generations=3, population=8, hof_size=1, learning_rate=0.1,
+                                   max_timesteps_per_episode=30, max_evaluation_steps=30, coevo_antithetic=True,
+                                   coevo_centered_rank=True)}
+    args, env, agents, res = _run(cfg, "device_philox")
+    torch.manual_seed(cfg["seed"])
+    np.random.seed(cfg["seed"])
+    oa = {k: v for k, v in cfg["args"].items() if not k.startswith("coevo_")}
+    want = rp.es_train(Bag(algorithm="ES", **oa), noise="philox", philox_seed=0, antithetic=True, centered_rank=True)
+    for g, w in enumerate(want):
+        for i in range(3 * args.population):
+            assert list(res.game_rewards[g][i]) == w["games"][i]["rewards"], (g, i)
+        assert [res.rewards[r][g] for r in ROLES] == w["eval_rewards"]
+    for a, r in zip(agents, ROLES):
+        assert sha(a.model.flat()) == sha(want[-1]["base"][r])
+    # and it is a different algorithm from reference_exact
+    torch.manual_seed(cfg["seed"])
+    np.random.seed(cfg["seed"])
+    plain = rp.es_train(Bag(algorithm="ES", **oa), noise="philox", philox_seed=0)
+    assert sha(plain[-1]["base"]["agent_0"]) != sha(want[-1]["base"]["agent_0"])

@@ -41,6 +41,56 @@ def _worker(rank, world, port, ret):
     ctx.shutdown()
 
 
+ES_CFG = dict(generations=3, population=8, hof_size=1, learning_rate=0.1, fitness_sharing=True,
+              max_timesteps_per_episode=40, max_evaluation_steps=60)
+
+
+def _train_es(dist_ctx, extension):
+    from coevonet_amd import evolutionary_strategy as es
+    from coevonet_amd.game_logic import initialize_env
+    torch.manual_seed(9)
+    np.random.seed(9)
+    args = Bag(algorithm="ES", coevo_antithetic=extension, coevo_centered_rank=extension, **ES_CFG)
+    env = initialize_env(args)
+    agents, res = es.evolution_strategy_train(env, args, None, rng="device_philox", return_result=True,
+                                              dist_ctx=dist_ctx)
+    return {"base": [sha(a.model.flat()) for a in agents], "eval": [res.rewards[r] for r in ("agent_0", "agent_1", "adversary_0")],
+            "sigma": res.sigma_after, "games": [g.tolist() for g in res.game_rewards], "div": res.diversity,
+            "shard": (res.engine.lo, res.engine.hi)}
+
+
+def _worker_es(rank, world, port, extension, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", COEVO_DIST_BACKEND="gloo")
+    from coevonet_amd.dist import DistContext
+    ctx = DistContext(backend="gloo")
+    ret[rank] = _train_es(ctx, extension)
+    ctx.shutdown()
+
+
+@pytest.mark.parametrize("extension", [False, True])
+def test_es_two_ranks_equal_one_rank(extension):
+    """population-sharded Co-ES (rank r perturbs / plays / partially sums individuals [lo, hi), all-gathers rewards +
+    distances and the chunk partial sums): the trained nets of 2 ranks == those of 1 rank, bit for bit"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_es, args=(2, port, extension, ret), nprocs=2, join=True)
+    single = _train_es(None, extension)
+    pop = ES_CFG["population"]
+    for rank in (0, 1):
+        got = ret[rank]
+        for k in ("base", "eval", "sigma", "div"):
+            assert got[k] == single[k], (rank, k)
+        lo, hi = got["shard"]
+        assert (lo, hi) == (rank * pop // 2, (rank + 1) * pop // 2)
+        for g, games in enumerate(got["games"]):
+            assert games == single["games"][g][3 * lo:3 * hi]
+
+
 def test_two_ranks_equal_one_rank():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

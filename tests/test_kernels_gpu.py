@@ -332,17 +332,47 @@ def test_perturb_bit_exact_vs_oracle(D, skip_ln):
     L.call("coevo_fc_unpack", L._p(child), L._p(back), 1 + n_children, D)
     got = back.cpu().numpy()
     segs = rp.ln_segments(D) if skip_ln else []
-    so = np.array([s[0] for s in segs], dtype=np.int32)
-    sl = np.array([s[1] for s in segs], dtype=np.int32)
     for c in range(n_children):
-        want = np.zeros(P, dtype=np.float32)
-        rp.lib().oracle_perturb_philox(rp._fp(parents[pidx[c]]), rp._fp(want), P, C.c_float(0.05), seed, slo + c, shi,
-                                       rp._ip(so), rp._ip(sl), len(segs))
+        want = rp.perturb_philox_flat(parents[pidx[c]], np.float32(0.05), seed, slo + c, shi, segs)
         assert np.array_equal(got[1 + c].view(np.uint32), want.view(np.uint32)), c
     noise = got[1] - parents[2]
     if not skip_ln:
         assert abs(noise.mean()) < 1e-3 and abs(noise.std() - 0.05) < 1e-3  # it is N(0, sigma)
     assert not got[0].any()  # slot 0 untouched
+
+
+def test_antithetic_perturb_and_centered_ranks_vs_oracle():
+    """the cfg 3 extension mode's two kernels: antithetic pairs share a stream with opposite signs; centered ranks"""
+    D, n = 10, 6
+    P = L.fc_param_count(D)
+    parent = make_nets(1, D, seed=13)
+    slab = to_slab(parent, D)
+    child = torch.zeros(n, L.fc_slab_stride(D), dtype=torch.float32, device=DEV)
+    sigma = torch.tensor([0.05], dtype=torch.float32, device=DEV)
+    zero = torch.zeros(n, dtype=torch.int32, device=DEV)
+    first = 10   # global index of the first individual of this call (a shard boundary is always even)
+    L.call("coevo_fc_perturb_flags", L._p(slab), L._p(zero), L._p(child), 0, n, D, L._p(sigma), 77, first, 5, 3)
+    back = torch.zeros(n, P, dtype=torch.float32, device=DEV)
+    L.call("coevo_fc_unpack", L._p(child), L._p(back), n, D)
+    got = back.cpu().numpy()
+    for c in range(n):
+        j = first + c
+        want = rp.mutate_philox(parent[0], D, np.float32(0.05), 77, j >> 1, 5, skip_layernorm=True, negate=bool(j & 1))
+        assert np.array_equal(got[c].view(np.uint32), want.view(np.uint32)), c
+    lin = np.ones(P, dtype=bool)
+    for o, ln_n in rp.ln_segments(D):
+        lin[o:o + ln_n] = False
+    assert np.array_equal((got[0] - parent[0])[lin], -(got[1] - parent[0])[lin])  # opposite noise, up to the add's rounding
+    g = np.random.Generator(np.random.PCG64(3))
+    for m in (1, 2, 7, 1000, 5000):
+        f = g.normal(size=m).astype(np.float32)
+        if m > 5:
+            f[3] = f[1]
+            f[m - 1] = f[1]
+        d_f = torch.from_numpy(f).to(DEV)
+        out = torch.zeros(m, dtype=torch.float32, device=DEV)
+        L.call("coevo_centered_ranks", L._p(d_f), m, L._p(out))
+        assert np.array_equal(out.cpu().numpy(), rp.centered_ranks(f)), m
 
 
 def test_es_update_bit_exact_vs_oracle():
@@ -364,9 +394,24 @@ def test_es_update_bit_exact_vs_oracle():
     L.call("coevo_es_update", L._p(slab), slab.data_ptr() + 4 * stride, D, L._p(d_fit), n, L._p(d_sigma), C.c_float(lr))
     back = torch.zeros(1, P, dtype=torch.float32, device=DEV)
     L.call("coevo_fc_unpack", L._p(slab), L._p(back), 1, D)
-    want = rp.es_update_from_pert(theta[0], D, pert.cpu().numpy(), fit, sigma, lr)
+    want = rp.es_update_from_pert(theta[0], D, pert.cpu().numpy(), fit, sigma, lr, chunks=1)
     assert np.array_equal(back.cpu().numpy()[0].view(np.uint32), want.view(np.uint32))
     assert np.abs(want - theta[0]).max() > 0  # it moved
+    # the chunked form (coevo_es_partial + coevo_es_apply): the canonical summation of the engine, also computed in two
+    # "rank" halves into a rank-major partial buffer as the sharded run does
+    for chunks, world in [(1, 1), (8, 1), (8, 2), (6, 3), (64, 1)]:
+        slab[0] = to_slab(theta, D)[0]
+        cl = chunks // world
+        parts = torch.full((world * cl * stride + 5,), float("nan"), dtype=torch.float32, device=DEV)
+        for rank in range(world):
+            lo = rank * cl * n // chunks
+            L.call("coevo_es_partial", L._p(slab), slab.data_ptr() + 4 * stride * (1 + lo), lo, D, L._p(d_fit), n, chunks,
+                   rank * cl, cl, parts.data_ptr() + 4 * rank * cl * stride)
+        L.call("coevo_es_apply", L._p(slab), L._p(parts), chunks, cl, cl * stride, D, n, L._p(d_sigma), C.c_float(lr))
+        L.call("coevo_fc_unpack", L._p(slab), L._p(back), 1, D)
+        want_c = rp.es_update_from_pert(theta[0], D, pert.cpu().numpy(), fit, sigma, lr, chunks=chunks)
+        assert np.array_equal(back.cpu().numpy()[0].view(np.uint32), want_c.view(np.uint32)), (chunks, world)
+    assert not np.array_equal(want_c, want)  # a different summation order, not a no-op
     ln = np.zeros(P, dtype=bool)
     for o, ln_n in rp.ln_segments(D):
         ln[o:o + ln_n] = True
