@@ -15,67 +15,12 @@
 //   dqn_out_kernel    512 -> n logits, first-max action.
 // fp32 arithmetic follows the canonical order of oracle/coevo_oracle.c (taps in (ci,ky,kx) order, sequential-k fc
 // chains), so logits equal the oracle's bit for bit.
-#include "coevo_common.hip.h"
+#include "dqn_common.hip.h"
 
 namespace coevo {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int DQ_FC1_IN = 3136, DQ_FC1_OUT = 512;
-
-struct DqnLayout {
-    int64_t w1, b1, w2, b2, w3, b3, wf, bf, wo, bo, total, stride;
-};
-
-__host__ __device__ inline DqnLayout dqn_layout(int C, int n)
-{
-    DqnLayout L;
-    L.w1 = 0;
-    L.b1 = (int64_t)C * 64 * 32;          // b1, g1, be1 (32 each)
-    L.w2 = L.b1 + 96;
-    L.b2 = L.w2 + 512 * 64;               // b2, g2, be2 (64 each)
-    L.w3 = L.b2 + 192;
-    L.b3 = L.w3 + 576 * 64;
-    L.wf = L.b3 + 192;                     // [8][784][64][4]
-    L.bf = L.wf + (int64_t)DQ_FC1_OUT * DQ_FC1_IN;
-    L.wo = L.bf + DQ_FC1_OUT;              // [n][512]
-    L.bo = L.wo + (int64_t)n * DQ_FC1_OUT;
-    L.total = L.bo + n;
-    L.stride = (L.total + 63) / 64 * 64;
-    return L;
-}
-
-__host__ __device__ inline int64_t dqn_param_count(int C, int n)
-{
-    return 32LL * C * 64 + 32 + 64LL * 512 + 64 + 64LL * 576 + 64 + 512LL * DQ_FC1_IN + 512 + 512LL * n + n + 320;
-}
-
-// slab position -> canonical flat index (parameters() order: conv1.w conv1.b conv2.w conv2.b conv3.w conv3.b fc1.w
-// fc1.b output.w output.b vbn1.w vbn1.b vbn2.w vbn2.b vbn3.w vbn3.b); -1 for padding
-__host__ __device__ inline int64_t dqn_slab_to_flat(int64_t s, int C, int n)
-{
-    const DqnLayout L = dqn_layout(C, n);
-    const int64_t T1 = (int64_t)C * 64;
-    const int64_t F_w1 = 0, F_b1 = 32 * T1, F_w2 = F_b1 + 32, F_b2 = F_w2 + 64 * 512, F_w3 = F_b2 + 64,
-                  F_b3 = F_w3 + 64 * 576, F_wf = F_b3 + 64, F_bf = F_wf + 512LL * DQ_FC1_IN, F_wo = F_bf + 512,
-                  F_bo = F_wo + 512LL * n, F_g1 = F_bo + n, F_be1 = F_g1 + 32, F_g2 = F_be1 + 32, F_be2 = F_g2 + 64,
-                  F_g3 = F_be2 + 64, F_be3 = F_g3 + 64;
-    if (s >= L.total) return -1;
-    if (s < L.b1) { const int64_t t = s / 32, co = s % 32; return F_w1 + co * T1 + t; }
-    if (s < L.w2) { const int64_t i = s - L.b1; return i < 32 ? F_b1 + i : (i < 64 ? F_g1 + i - 32 : F_be1 + i - 64); }
-    if (s < L.b2) { const int64_t i = s - L.w2, t = i / 64, co = i % 64; return F_w2 + co * 512 + t; }
-    if (s < L.w3) { const int64_t i = s - L.b2; return i < 64 ? F_b2 + i : (i < 128 ? F_g2 + i - 64 : F_be2 + i - 128); }
-    if (s < L.b3) { const int64_t i = s - L.w3, t = i / 64, co = i % 64; return F_w3 + co * 576 + t; }
-    if (s < L.wf) { const int64_t i = s - L.b3; return i < 64 ? F_b3 + i : (i < 128 ? F_g3 + i - 64 : F_be3 + i - 128); }
-    if (s < L.bf) {  // wfq[ob][kq][l][c] = fc1.w[64 ob + l][4 kq + c]
-        const int64_t i = s - L.wf, c = i & 3, l = (i >> 2) & 63, kq = (i >> 8) % 784, ob = (i >> 8) / 784;
-        return F_wf + (ob * 64 + l) * DQ_FC1_IN + kq * 4 + c;
-    }
-    if (s < L.wo) return F_bf + (s - L.bf);
-    if (s < L.bo) return F_wo + (s - L.wo);
-    return F_bo + (s - L.bo);
-}
 
 __global__ __launch_bounds__(256) void dqn_pack_kernel(const float *flat, float *slab, int C, int n)
 {

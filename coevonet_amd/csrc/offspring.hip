@@ -10,95 +10,10 @@
 // Box-Muller transform whose log / sincos are fmaf-only polynomials (bit-identical with oracle/coevo_oracle.c).
 // A child is one streaming pass: read parent (L2/Infinity-Cache resident elite), write child once.
 #include "coevo_common.hip.h"
+#include "dqn_common.hip.h"
+#include "philox.hip.h"
 
 namespace coevo {
-
-struct u32x4 { uint32_t v[4]; };
-
-__device__ inline u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
-{
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return u32x4{{c0, c1, c2, c3}};
-}
-
-// ln(x), x a normal float in (0,1): exponent by bit ops, cephes logf polynomial evaluated with fmaf only
-__device__ inline float canon_logf(float x)
-{
-    const uint32_t b = __float_as_uint(x);
-    int e = (int)((b >> 23) & 0xff) - 126;
-    float m = __uint_as_float((b & 0x007fffffu) | 0x3f000000u);
-    if (m < 0.707106781186547524f) { e -= 1; m = (m + m) - 1.0f; } else { m = m - 1.0f; }
-    const float z = m * m;
-    float y = 7.0376836292E-2f;
-    y = __builtin_fmaf(y, m, -1.1514610310E-1f);
-    y = __builtin_fmaf(y, m, 1.1676998740E-1f);
-    y = __builtin_fmaf(y, m, -1.2420140846E-1f);
-    y = __builtin_fmaf(y, m, 1.4249322787E-1f);
-    y = __builtin_fmaf(y, m, -1.6668057665E-1f);
-    y = __builtin_fmaf(y, m, 2.0000714765E-1f);
-    y = __builtin_fmaf(y, m, -2.4999993993E-1f);
-    y = __builtin_fmaf(y, m, 3.3333331174E-1f);
-    y = (y * m) * z;
-    const float fe = (float)e;
-    y = __builtin_fmaf(-2.12194440e-4f, fe, y);
-    y = __builtin_fmaf(-0.5f, z, y);
-    float r = m + y;
-    r = __builtin_fmaf(0.693359375f, fe, r);
-    return r;
-}
-
-// (cos, sin)(2*pi*u), u = k/2^24: exact quadrant split, cephes polynomials on [0, pi/4], fmaf only
-__device__ inline void canon_sincos2pi(float u, float &c_out, float &s_out)
-{
-    const float t = u * 4.0f;
-    const float qf = __builtin_floorf(t);
-    const int q = (int)qf;
-    float f = t - qf;
-    const bool swap = f > 0.5f;
-    if (swap) f = 1.0f - f;
-    const float x = f * 1.57079632679489661923f;
-    const float z = x * x;
-    float sp = -1.9515295891E-4f;
-    sp = __builtin_fmaf(sp, z, 8.3321608736E-3f);
-    sp = __builtin_fmaf(sp, z, -1.6666654611E-1f);
-    float s = __builtin_fmaf(sp * z, x, x);
-    float cp = 2.443315711809948E-005f;
-    cp = __builtin_fmaf(cp, z, -1.388731625493765E-003f);
-    cp = __builtin_fmaf(cp, z, 4.166664568298827E-002f);
-    float c = __builtin_fmaf(cp * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
-    if (swap) { const float tmp = s; s = c; c = tmp; }
-    switch (q & 3) {
-    case 0: c_out = c; s_out = s; break;
-    case 1: c_out = -s; s_out = c; break;
-    case 2: c_out = -c; s_out = -s; break;
-    default: c_out = s; s_out = -c; break;
-    }
-}
-
-__device__ inline void box_muller(uint32_t a, uint32_t b, float &z0, float &z1)
-{
-    const float u1 = (float)(2u * (a >> 9) + 1u) * 5.9604644775390625e-08f;
-    const float u2 = (float)(b >> 8) * 5.9604644775390625e-08f;
-    const float r = __builtin_sqrtf(-2.0f * canon_logf(u1));
-    float c, s;
-    canon_sincos2pi(u2, c, s);
-    z0 = r * c;
-    z1 = r * s;
-}
-
-__device__ inline void philox_normal4(uint64_t seed, uint32_t stream_lo, uint32_t stream_hi, uint32_t q, float z[4])
-{
-    const u32x4 o = philox4x32_10(q, stream_lo, stream_hi, 0x636f6576u, (uint32_t)seed, (uint32_t)(seed >> 32));
-    box_muller(o.v[0], o.v[1], z[0], z[1]);
-    box_muller(o.v[2], o.v[3], z[2], z[3]);
-}
 
 // is slab position s a LayerNorm affine parameter?
 __device__ inline bool fc_slab_is_layernorm(int64_t s, int D)
@@ -341,10 +256,9 @@ __global__ __launch_bounds__(256) void es_update_kernel(float *theta, const floa
 // a population shard computes exactly its own chunks.  Step 2 (es_apply_kernel): theta += scale * (((p_0 + p_1) + p_2)
 // + ...).  chunks_total = 1 is the sequential sum of es_update_kernel, bit for bit.
 __global__ __launch_bounds__(256) void es_partial_kernel(const float *theta, const float *pert_slab, int ind_first,
-                                                          int D, const float *fitness_all, int n_total,
+                                                          int64_t stride, const float *fitness_all, int n_total,
                                                           int chunks_total, int chunk_first, float *partial)
 {
-    const int64_t stride = fc_stride(D);
     const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (s0 >= stride) return;
     const int gc = chunk_first + blockIdx.y;
@@ -385,11 +299,19 @@ __global__ __launch_bounds__(256) void es_partial_kernel(const float *theta, con
 
 // partial of global chunk c lives at partials + (c / chunks_per_block) * block_stride + (c % chunks_per_block) * stride
 // (one block per rank after the all-gather; a single block on one GPU)
+// which slab positions an ES update leaves alone: padding (>= total) and up to three normalisation-affine ranges
+struct SlabSkip {
+    int64_t total, a0, b0, a1, b1, a2, b2;
+    __host__ __device__ bool operator()(int64_t s) const
+    {
+        return s >= total || (s >= a0 && s < b0) || (s >= a1 && s < b1) || (s >= a2 && s < b2);
+    }
+};
+
 __global__ __launch_bounds__(256) void es_apply_kernel(float *theta, const float *partials, int chunks_total,
-                                                        int chunks_per_block, int64_t block_stride, int D, int n_total,
-                                                        const float *sigma_dev, float lr)
+                                                        int chunks_per_block, int64_t block_stride, int64_t stride,
+                                                        SlabSkip skip, int n_total, const float *sigma_dev, float lr)
 {
-    const int64_t stride = fc_stride(D), P = fc_params(D);
     const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (s0 >= stride) return;
     const float sigma = *sigma_dev;
@@ -406,7 +328,7 @@ __global__ __launch_bounds__(256) void es_apply_kernel(float *theta, const float
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int64_t s = s0 + c;
-        out[c] = (s < P && !fc_slab_is_layernorm(s, D)) ? th[c] + scale * ac[c] : th[c];
+        out[c] = skip(s) ? th[c] : th[c] + scale * ac[c];
     }
     *reinterpret_cast<float4 *>(theta + s0) = make_float4(out[0], out[1], out[2], out[3]);
 }
@@ -560,33 +482,90 @@ extern "C" int coevo_es_update(float *theta_slab_net, const float *pert_slab, in
     return COEVO_OK;
 }
 
-extern "C" int coevo_es_partial(const float *theta_net, const float *pert_slab_local, int ind_first, int D,
-                                const float *fitness_all, int n_total, int chunks_total, int chunk_first, int n_chunks,
-                                float *partial, void *stream)
+static int es_partial_launch(const float *theta_net, const float *pert_slab_local, int ind_first, int64_t stride,
+                             const float *fitness_all, int n_total, int chunks_total, int chunk_first, int n_chunks,
+                             float *partial, void *stream)
 {
-    if (!theta_net || !pert_slab_local || !fitness_all || !partial || !fc_dim_ok(D)) return COEVO_ERR_ARG;
+    if (!theta_net || !pert_slab_local || !fitness_all || !partial) return COEVO_ERR_ARG;
     if (n_total <= 0 || chunks_total <= 0 || chunk_first < 0 || n_chunks <= 0 || chunk_first + n_chunks > chunks_total ||
         n_chunks > 65535 || ind_first < 0)
         return COEVO_ERR_ARG;
     // the caller's nets must start exactly where its first chunk starts
     if ((int64_t)chunk_first * n_total / chunks_total != ind_first) return COEVO_ERR_ARG;
-    const dim3 grid((unsigned)((fc_stride(D) / 4 + 255) / 256), (unsigned)n_chunks);
+    const dim3 grid((unsigned)((stride / 4 + 255) / 256), (unsigned)n_chunks);
     hipLaunchKernelGGL(es_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, theta_net, pert_slab_local, ind_first,
-                       D, fitness_all, n_total, chunks_total, chunk_first, partial);
+                       stride, fitness_all, n_total, chunks_total, chunk_first, partial);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
+}
+
+static int es_apply_launch(float *theta_net, const float *partials, int chunks_total, int chunks_per_block,
+                           int64_t block_stride_floats, int64_t stride, SlabSkip skip, int n_total,
+                           const float *sigma_dev, float lr, void *stream)
+{
+    if (!theta_net || !partials || !sigma_dev || n_total <= 0 || chunks_total <= 0 || chunks_per_block <= 0 ||
+        block_stride_floats < 0 || (block_stride_floats & 3))
+        return COEVO_ERR_ARG;
+    const dim3 grid((unsigned)((stride / 4 + 255) / 256));
+    hipLaunchKernelGGL(es_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, theta_net, partials, chunks_total,
+                       chunks_per_block, block_stride_floats, stride, skip, n_total, sigma_dev, lr);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_es_partial(const float *theta_net, const float *pert_slab_local, int ind_first, int D,
+                                const float *fitness_all, int n_total, int chunks_total, int chunk_first, int n_chunks,
+                                float *partial, void *stream)
+{
+    if (!fc_dim_ok(D)) return COEVO_ERR_ARG;
+    return es_partial_launch(theta_net, pert_slab_local, ind_first, fc_stride(D), fitness_all, n_total, chunks_total,
+                             chunk_first, n_chunks, partial, stream);
 }
 
 extern "C" int coevo_es_apply(float *theta_net, const float *partials, int chunks_total, int chunks_per_block,
                               int64_t block_stride_floats, int D, int n_total, const float *sigma_dev, float lr,
                               void *stream)
 {
-    if (!theta_net || !partials || !sigma_dev || !fc_dim_ok(D) || n_total <= 0 || chunks_total <= 0 ||
-        chunks_per_block <= 0 || block_stride_floats < 0 || (block_stride_floats & 3))
+    if (!fc_dim_ok(D)) return COEVO_ERR_ARG;
+    const int64_t g1 = fc_off_b1(D) + H1, g2 = fc_off_b2(D) + H2;  // LayerNorm affine: never perturbed, never updated
+    const SlabSkip skip{fc_params(D), g1, g1 + 2 * H1, g2, g2 + 2 * H2, 0, 0};
+    return es_apply_launch(theta_net, partials, chunks_total, chunks_per_block, block_stride_floats, fc_stride(D), skip,
+                           n_total, sigma_dev, lr, stream);
+}
+
+static bool dqn_ok(int C, int n) { return C >= 1 && C <= 6 && n >= 1 && n <= COEVO_DQN_LOGIT_STRIDE; }
+
+extern "C" int coevo_dqn_es_partial(const float *theta_net, const float *pert_slab_local, int ind_first, int C,
+                                    int n_actions, const float *fitness_all, int n_total, int chunks_total,
+                                    int chunk_first, int n_chunks, float *partial, void *stream)
+{
+    if (!dqn_ok(C, n_actions)) return COEVO_ERR_ARG;
+    return es_partial_launch(theta_net, pert_slab_local, ind_first, dqn_layout(C, n_actions).stride, fitness_all,
+                             n_total, chunks_total, chunk_first, n_chunks, partial, stream);
+}
+
+extern "C" int coevo_dqn_es_apply(float *theta_net, const float *partials, int chunks_total, int chunks_per_block,
+                                  int64_t block_stride_floats, int C, int n_actions, int n_total,
+                                  const float *sigma_dev, float lr, void *stream)
+{
+    if (!dqn_ok(C, n_actions)) return COEVO_ERR_ARG;
+    const DqnLayout L = dqn_layout(C, n_actions);  // BatchNorm affine is not perturbable (Atari/deepqn.py:158-171)
+    const SlabSkip skip{L.total, L.b1 + 32, L.w2, L.b2 + 64, L.w3, L.b3 + 64, L.wf};
+    return es_apply_launch(theta_net, partials, chunks_total, chunks_per_block, block_stride_floats, L.stride, skip,
+                           n_total, sigma_dev, lr, stream);
+}
+
+/* dst[dst_first + i] = src[src_idx[i]] for nets of any layout (stride floats apart, a multiple of 4) */
+extern "C" int coevo_net_gather(const float *src_slab, const int32_t *src_idx, float *dst_slab, int dst_first, int n,
+                                int64_t stride_floats, void *stream)
+{
+    if (!src_slab || !src_idx || !dst_slab || n < 0 || dst_first < 0 || n > 65535 || stride_floats <= 0 ||
+        (stride_floats & 3))
         return COEVO_ERR_ARG;
-    const dim3 grid((unsigned)((fc_stride(D) / 4 + 255) / 256));
-    hipLaunchKernelGGL(es_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, theta_net, partials, chunks_total,
-                       chunks_per_block, block_stride_floats, D, n_total, sigma_dev, lr);
+    if (n == 0) return COEVO_OK;
+    const dim3 grid((unsigned)((stride_floats / 4 + 255) / 256), (unsigned)n);
+    hipLaunchKernelGGL(fc_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, src_slab, src_idx, dst_slab,
+                       dst_first, stride_floats);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

@@ -56,6 +56,16 @@ class DistContext:
         eng.last_reward.copy_(full[:, :, :3])
         eng.dist_all.copy_(full[:, :, 3])               # back to fp32 (exact: they were fp32 values)
 
+    def gather_ga2(self, eng):
+        """the same exchange for the two-role DeepQN engine (dqn_population.DQNGAEngine)"""
+        lo, hi = eng.lo, eng.hi
+        local = torch.empty(2, hi - lo, 4, dtype=torch.float64, device=eng.last_reward.device)
+        local[:, :, :3] = eng.last_reward[:, lo:hi]
+        local[:, :, 3] = eng.dist_all[:, lo:hi]
+        full = allgather_shards(local, self.world)
+        eng.last_reward.copy_(full[:, :, :3])
+        eng.dist_all.copy_(full[:, :, 3])
+
     def gather_es(self, eng, what):
         """Co-ES exchanges (evolutionary_strategy.ESEngine.update_device): "stats" = per role and individual the reward
         in the role's slot + the distance to the base net (fp64 pairs, 16 bytes per individual and role); "partials" =

@@ -361,6 +361,9 @@ def evolution_strategy_train(env, args, output_dir, rng=None, env_mode=None, col
     """Drop-in for evolutionary_strategy.py:151: returns (agent_0, agent_1, adversary) like the reference; with
     return_result=True also the ESResult history (what the reference only plots)."""
     import os
+    if getattr(args, "game", "simple_adversary_v3") != "simple_adversary_v3":   # the two-player Atari games
+        from .dqn_population import dqn_evolution_strategy_train
+        return dqn_evolution_strategy_train(env, args, output_dir, collect=collect, dist_ctx=dist_ctx)
     from .io_utils import ES_FILES, MetricsWriter, save_model
     tr = ESTrainer(env, args, rng=rng, env_mode=env_mode, collect=collect, dist_ctx=dist_ctx)
     save = bool(getattr(args, "save", False)) and output_dir is not None

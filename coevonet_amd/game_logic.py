@@ -13,6 +13,7 @@ import torch
 
 from . import lib as L
 from .agent import MPEAgent
+from .atari_synthetic import ATARI_GAMES, SyntheticAtariAEC
 from .mpe.simple_adversary import ENV_SEED, SimpleAdversaryAEC
 from .rollout import DeviceRollout, RolloutPlan, effective_steps
 
@@ -21,9 +22,13 @@ def initialize_env(args):
     """utils/game_logic_functions.py:41-55 - build the env and do the ONE seeded reset."""
     if args.game == "simple_adversary_v3":
         env = SimpleAdversaryAEC(render_mode="human" if getattr(args, "render", False) else None)
+    elif args.game in ATARI_GAMES:
+        # ALE / its ROMs are not part of this build (and the reference's Atari loop does not run, SURVEY 2.3): the
+        # two-player games are served by a SYNTHETIC env of the same AEC shape (coevonet_amd.atari_synthetic).
+        # channels: 4 = BASELINE.json's 84x84x4 frames; the reference's wrapper stack (:50-52) would yield 6.
+        env = SyntheticAtariAEC(args.game, channels=getattr(args, "coevo_channels", 4))
     else:
-        raise ValueError(f"Unsupported game type: {args.game} (the Atari emulator is not part of this build; "
-                         "only the DeepQN policy kernel is, see coevonet_amd.deepqn)")
+        raise ValueError(f"Unsupported game type: {args.game}")
     env.reset(seed=ENV_SEED)
     return env
 
@@ -31,6 +36,9 @@ def initialize_env(args):
 def create_agent(env, args, role=None):
     if args.game == "simple_adversary_v3":
         return MPEAgent(env, args, role)
+    if args.game in ATARI_GAMES:   # utils/game_logic_functions.py:61-62
+        from .deepqn import AtariAgent
+        return AtariAgent(env, args)
     raise ValueError(f"Unsupported game type: {args.game}")
 
 
@@ -95,6 +103,51 @@ def _play_mpe_device(env, player1, player2, adversary, args, eval):
     return float(r[0]), float(r[1]), float(r[2])
 
 
+def _play_atari_aec(env, player1, player2, args, eval):
+    """play_atari (:84-119) with the signature the call site at :227 uses; forwards on the GPU one step at a time"""
+    rewards = {"first_0": 0, "second_0": 0}
+    timesteps = 0
+    limit = args.max_evaluation_steps if eval else args.max_timesteps_per_episode
+    for agent in env.agent_iter():
+        obs = env.observe(agent)   # uint8 [84, 84, C]; the HWC -> CHW permute of :78 is folded into the kernel's load
+        if agent == "first_0":
+            action = player1.determine_action(obs, args)
+        elif agent == "second_0":
+            action = player2.determine_action(obs, args)
+        else:
+            raise ValueError(f"Unknown Agent during play_game: {agent}")
+        env.step(action)
+        _, reward, termination, truncation, _ = env.last()
+        rewards[agent] += reward
+        timesteps += 1
+        if limit is not None and timesteps >= limit:
+            break
+        if termination or truncation:
+            break
+    return rewards["first_0"], rewards["second_0"]
+
+
+def _play_atari_device(env, player1, player2, args, eval):
+    """one whole synthetic-env episode on the device (coevo_synth_step + coevo_dqn_forward_argmax per agent-step)"""
+    from .dqn_population import SynthRollout
+    dev = "cuda"
+    C, n = env.C, env.n_actions
+    stride = int(L.load().coevo_dqn_slab_stride(C, n))
+    slab = torch.zeros(2 * stride, dtype=torch.float32, device=dev)
+    flat = torch.from_numpy(np.stack([player1.flat(), player2.flat()])).to(dev)
+    L.call("coevo_dqn_pack", L._p(flat), L._p(slab), 2, C, n)
+    limit = args.max_evaluation_steps if eval else args.max_timesteps_per_episode
+    if limit is None:
+        raise ValueError("the synthetic Atari env never terminates: a step limit is required")
+    ro = SynthRollout([(0, 1)], [0, stride], [env.ordinal], C, n, slab, env.seed_value, 0, dev)
+    ro.set_limits([int(limit)])
+    ro.enqueue(int(limit), None)
+    torch.cuda.synchronize()
+    L.raise_on_status(ro.status)
+    r = ro.acc.cpu().numpy()[0]
+    return float(r[0]), float(r[1])
+
+
 def play_game(env, player1, player2, adversary=None, args=None, eval=False):
     """utils/game_logic_functions.py:215-228"""
     env.reset()
@@ -107,4 +160,10 @@ def play_game(env, player1, player2, adversary=None, args=None, eval=False):
         if ours:
             return _play_mpe_device(env, player1, player2, adversary, args, eval)
         return _play_mpe_aec(env, player1, player2, adversary, args, eval)
+    if args.game in ATARI_GAMES:
+        from .deepqn import DeepQN
+        if isinstance(env, SyntheticAtariAEC) and isinstance(player1, DeepQN) and isinstance(player2, DeepQN) \
+                and not getattr(args, "coevo_host_aec", False):
+            return _play_atari_device(env, player1, player2, args, eval)
+        return _play_atari_aec(env, player1, player2, args, eval)
     raise ValueError(f"Unsupported game type: {args.game}")

@@ -873,6 +873,9 @@ def genetic_algorithm_train(env, agent, args, output_dir, rng=None, env_mode=Non
 
     rng: "host_reference" (default) reproduces the reference's torch RNG stream bit for bit;
          "device_philox" builds offspring on the device (args.coevo_rng may select it as well)."""
+    if getattr(args, "game", "simple_adversary_v3") != "simple_adversary_v3":   # the two-player Atari games
+        from .dqn_population import dqn_genetic_algorithm_train
+        return dqn_genetic_algorithm_train(env, agent, args, output_dir, collect=collect, dist_ctx=dist_ctx)
     from .io_utils import GA_FILES, MetricsWriter, agents_from_flat, save_model
     tr = GATrainer(env, args, rng=rng, env_mode=env_mode, collect=collect, dist_ctx=dist_ctx)
     save = bool(getattr(args, "save", False)) and output_dir is not None

@@ -370,6 +370,60 @@ int coevo_dqn_forward_argmax(const float *slab, const coevo_dqn_task *tasks, int
                              int n_rows_total, int C, int n_actions, const uint8_t *frames, int32_t *actions,
                              float *logits, int32_t *status, void *workspace, void *stream);
 
+int coevo_dqn_unpack(const float *slab, float *flat, int n, int C, int n_actions, void *stream);
+
+/* ---------------------------------------------------------------- DeepQN population engine (cfg 4 / cfg 5) ---------- */
+/* Offspring of the DeepQN layout on the device: child = parent +- sigma * eps(seed, stream, p), p = canonical flat index
+ * (the order above), same Philox / Box-Muller as coevo_fc_perturb.  Replaces AtariAgent.clone + Agent.mutate
+ * (Atari/atari_agent.py:27-30, agent.py:25-29: every parameter, BatchNorm affine included) and the ES perturbation of the
+ * perturbable layers (Atari/deepqn.py:158-171: BatchNorm excluded).
+ *   flags  COEVO_DQP_SKIP_BN     BatchNorm affine untouched (ES)
+ *          COEVO_DQP_ANTITHETIC  individuals 2m / 2m+1 (counted from stream_lo_first + c) share stream m, odd one -eps
+ *          COEVO_DQP_FROM_ORDER  elite rebuild (multi-GPU Co-GA, as coevo_fc_rebuild_elites): parent_idx is this
+ *                                generation's ranking; child e = individual id = parent_idx[e] of the population bred
+ *                                from the E nets of parent_slab: id 0 -> parent 0 unchanged, else parent (id-1) % E +
+ *                                noise stream id-1; child_slab must not alias parent_slab
+ *          COEVO_DQP_COPY        no noise: child = parent (child_slab may be NULL: distance only)
+ *   gen_dev != NULL: stream_hi_eff = stream_hi + 4 * (*gen_dev + gen_bias)
+ *   dist_ref / dist_partial (both or neither): squared L2 distance of every child to the net dist_ref over ALL parameters
+ *   (DeepQN.get_weights_ES() default = self.layers, which holds the BatchNorm layers too, Atari/deepqn.py:14-37), as
+ *   fp64 partial sums [n_children][coevo_dqn_perturb_blocks]; coevo_fc_distance_finalize turns them into distances. */
+#define COEVO_DQP_SKIP_BN 1
+#define COEVO_DQP_ANTITHETIC 2
+#define COEVO_DQP_FROM_ORDER 4
+#define COEVO_DQP_COPY 8
+int64_t coevo_dqn_perturb_blocks(int C, int n_actions);
+int coevo_dqn_perturb(const float *parent_slab, const int32_t *parent_idx, float *child_slab, int child_first,
+                      int n_children, int C, int n_actions, const float *sigma_dev, uint64_t seed,
+                      uint32_t stream_lo_first, uint32_t stream_hi, int flags, int E, const int32_t *gen_dev,
+                      int gen_bias, const float *dist_ref, double *dist_partial, void *stream);
+/* K5 for the DeepQN layout (see coevo_es_partial / coevo_es_apply): BatchNorm affine is never updated */
+int coevo_dqn_es_partial(const float *theta_net, const float *pert_slab_local, int ind_first, int C, int n_actions,
+                         const float *fitness_all, int n_total, int chunks_total, int chunk_first, int n_chunks,
+                         float *partial, void *stream);
+int coevo_dqn_es_apply(float *theta_net, const float *partials, int chunks_total, int chunks_per_block,
+                       int64_t block_stride_floats, int C, int n_actions, int n_total, const float *sigma_dev, float lr,
+                       void *stream);
+/* dst[dst_first + i] = src[src_idx[i]] for nets of any slab layout, stride_floats apart (elites, HoF FIFO, best) */
+int coevo_net_gather(const float *src_slab, const int32_t *src_idx, float *dst_slab, int dst_first, int n,
+                     int64_t stride_floats, void *stream);
+
+/* Synthetic two-player env in the shape of pettingzoo.atari pong_v3 / boxing_v2 (ALE is not in the image, SURVEY 8d cfg
+ * 4/5): agents first_0 / second_0 alternate, the frame of agent-step t is uint8 [84][84][C] noise keyed by (seed, the
+ * game's reset ordinal, t, the action of step t-1) - no game dynamics, but a real dependency chain from step to step.
+ * hit(t) = [action_t == target(seed, ordinal, t)]; zero-sum rewards with PettingZoo's AEC bookkeeping, and play_atari's
+ * crediting (utils/game_logic_functions.py:104-108: the actor receives what env.last() returns after env.step, i.e. the
+ * NEXT agent's cumulative reward): credited(t) = hit(t-1) - hit(t) to actor t & 1.
+ * One call = the env side of agent-step t for every game: books the action of step t-1 (read through row_prev /
+ * actions_prev) and writes the frame of step t at frames[row_cur[g]] (frames == NULL: bookkeeping only, the closing call
+ * with t = T).  t = 0 resets.  ordinal(g) = game_ordinal0[g] + *gen_dev * ordinals_per_gen; negative = disabled.
+ *   game_state [n_games][4] int32, acc [n_games][3] fp64 = play_game's (first_0, second_0) returns + one unused slot,
+ *   limit [n_games] = agent-step limit per game (max_timesteps_per_episode / max_evaluation_steps). */
+int coevo_synth_step(int32_t *game_state, double *acc, int n_games, const int64_t *game_ordinal0, const int32_t *gen_dev,
+                     int64_t ordinals_per_gen, int t, const int32_t *limit, const int32_t *row_prev,
+                     const int32_t *actions_prev, const int32_t *row_cur, uint8_t *frames, int C, int n_actions,
+                     uint64_t seed, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -556,4 +556,57 @@ int oracle_dqn_forward(const float *p, int C, int n, const unsigned char *frame,
     return best;
 }
 
+/* ------------------------------------------------------------------ synthetic Atari-shaped env + play_atari ------
+ * The build's stand-in for pettingzoo.atari (no ALE in the image): see include/coevo.h, coevo_synth_step.  Stated here
+ * literally - an AEC env with PettingZoo's _cumulative_rewards bookkeeping driven by the loop of play_atari
+ * (utils/game_logic_functions.py:84-119) - so that the kernel's closed form credited(t) = hit(t-1) - hit(t) is checked
+ * against the statement it was derived from. */
+uint32_t oracle_synth_target(uint64_t seed, int64_t ordinal, int t, int n_actions)
+{
+    uint32_t o[4];
+    philox4x32_10(0xFFFFFFFFu, (uint32_t)t, (uint32_t)ordinal, (uint32_t)((uint64_t)ordinal >> 32) ^ 0x74617267u,
+                  (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    return o[0] % (uint32_t)n_actions;
+}
+
+void oracle_synth_frame(uint64_t seed, int64_t ordinal, int t, int last_action, int C, unsigned char *frame)
+{
+    const int nbytes = 84 * 84 * C;
+    for (int i = 0; i < nbytes / 16; ++i) {
+        uint32_t o[4];
+        philox4x32_10((uint32_t)i, (uint32_t)t | ((uint32_t)last_action << 16), (uint32_t)ordinal,
+                      (uint32_t)((uint64_t)ordinal >> 32) ^ 0x66726d65u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+        memcpy(frame + 16 * (size_t)i, o, 16);   /* little endian words, as the device stores them */
+    }
+}
+
+/* play_atari: returns the number of agent-steps; rewards[0] = first_0, rewards[1] = second_0 */
+int oracle_dqn_play_game(const float *net_first, const float *net_second, int C, int n_actions, uint64_t seed,
+                         int64_t ordinal, int limit, double rewards[2], int *actions_out)
+{
+    unsigned char *frame = (unsigned char *)malloc((size_t)84 * 84 * C);
+    float logits[64];
+    double cum[2] = {0.0, 0.0};           /* env._cumulative_rewards */
+    int last = 0xFF, timesteps = 0;
+    rewards[0] = rewards[1] = 0.0;
+    for (int t = 0;; ++t) {                /* for agent in env.agent_iter(): the synthetic env never terminates */
+        const int agent = t & 1, other = agent ^ 1;
+        oracle_synth_frame(seed, ordinal, t, last, C, frame);                     /* env.observe(agent) */
+        const int action = oracle_dqn_forward(agent ? net_second : net_first, C, n_actions, frame, logits);
+        if (actions_out) actions_out[t] = action;
+        /* env.step(action) */
+        cum[agent] = 0.0;
+        const double hit = ((uint32_t)action == oracle_synth_target(seed, ordinal, t, n_actions)) ? 1.0 : 0.0;
+        cum[agent] += hit;
+        cum[other] += -hit;
+        last = action;
+        /* _, reward, ... = env.last(): agent_selection has advanced to `other` */
+        rewards[agent] += cum[other];
+        timesteps += 1;
+        if (limit >= 0 && timesteps >= limit) break;
+    }
+    free(frame);
+    return timesteps;
+}
+
 int oracle_version(void) { return 1; }

@@ -24,6 +24,7 @@ import subprocess
 import numpy as np
 import torch
 
+_ct = C   # (functions below that take the channel count name it C, like the reference's DeepQN)
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "_build", "liboracle.so")
 ENV_SEED = 1870300
@@ -68,6 +69,12 @@ def lib():
         L.oracle_dqn_param_count.restype = C.c_long
         L.oracle_dqn_forward.restype = C.c_int
         L.oracle_dqn_forward.argtypes = [fp, C.c_int, C.c_int, C.c_void_p, fp]
+        L.oracle_synth_target.restype = C.c_uint32
+        L.oracle_synth_target.argtypes = [C.c_uint64, C.c_int64, C.c_int, C.c_int]
+        L.oracle_synth_frame.argtypes = [C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_dqn_play_game.restype = C.c_int
+        L.oracle_dqn_play_game.argtypes = [fp, fp, C.c_int, C.c_int, C.c_uint64, C.c_int64, C.c_int,
+                                           C.POINTER(C.c_double), ip]
         _lib = L
     return _lib
 
@@ -507,3 +514,189 @@ def dqn_forward(flat, C, n_actions, frame_u8):
     f = np.ascontiguousarray(frame_u8, dtype=np.uint8)
     a = lib().oracle_dqn_forward(_fp(np.ascontiguousarray(flat, dtype=np.float32)), C, n_actions, f.ctypes.data, _fp(logits))
     return a, logits
+
+
+# ------------------------------------------------------------------ DeepQN population loops (cfg 4 / cfg 5)
+# The reference's Atari loop does not run, so this is the BUILD's definition: the 2-role restriction of the
+# Co-GA / Co-ES generation bodies (genetic_algorithm.py:119-290, evolutionary_strategy.py:222-265) over the synthetic env
+# of include/coevo.h.  "Loop parity unpinned, forward pinned" (SURVEY 8c): DeepQN.forward is pinned by
+# tests/golden/deepqn_forward.json, everything below is checked HIP-vs-this-port only.
+DQN_ROLES = ("first_0", "second_0")
+DQN_BN_SEGMENT_NAMES = ("vbn1.w", "vbn1.b", "vbn2.w", "vbn2.b", "vbn3.w", "vbn3.b")
+
+
+def dqn_bn_segments(C, n_actions):
+    """(offset, length) of the BatchNorm affine entries in the canonical flat order (they come last)"""
+    P = lib().oracle_dqn_param_count(C, n_actions)
+    return [(P - 320, 320)]
+
+
+def synth_frame(seed, ordinal, t, last_action, C):
+    out = np.zeros((84, 84, C), dtype=np.uint8)
+    lib().oracle_synth_frame(int(seed), int(ordinal), int(t), int(last_action), int(C), out.ctypes.data)
+    return out
+
+
+def dqn_play_game(net_first, net_second, C, n_actions, seed, ordinal, limit):
+    """play_atari over the synthetic env -> dict(rewards=[first_0, second_0], steps, actions)"""
+    rewards = (_ct.c_double * 2)()
+    actions = np.zeros(max(int(limit), 1), dtype=np.int32)
+    steps = lib().oracle_dqn_play_game(_fp(np.ascontiguousarray(net_first, dtype=np.float32)),
+                                       _fp(np.ascontiguousarray(net_second, dtype=np.float32)), C, n_actions, int(seed),
+                                       int(ordinal), int(limit), rewards, _ip(actions))
+    return {"rewards": [rewards[0], rewards[1]], "steps": steps, "actions": actions[:steps].tolist()}
+
+
+def dqn_diversity(individual, population):
+    """diversity_penalty on DeepQN.get_weights_ES() = ALL parameters (self.layers includes the BatchNorm layers)"""
+    return diversity(individual, population)
+
+
+def dqn_ga_train(args, C, n_actions, env_seed=0, philox_seed=0):
+    """2-role Co-GA: per role phase (first_0, second_0), individual i, k < hof: one game against hof_other[hof-1-k];
+    fitness = last game's reward in the role's slot / hof / (1 + diversity vs the stale agent) (Q2, Q3 kept);
+    argsort()[::-1] elites; HoF FIFO; population = [best] + children(elite[c % E] + sigma*eps(stream (c, 4g+ri)));
+    10 evaluation games of the best pair; adaptive sigma (first_0 plays agent_0's part in Q5, second_0 agent_1's)."""
+    pop, hof_n, E = args.population, args.hof_size, args.elites_number
+    T, T_eval = args.max_timesteps_per_episode, args.max_evaluation_steps
+    hof = {"second_0": [dqn_init(C, n_actions)[0] for _ in range(hof_n)]}   # creation order mirrors ga_initial
+    hof["first_0"] = [dqn_init(C, n_actions)[0] for _ in range(hof_n)]
+    popu = {r: [] for r in DQN_ROLES}
+    for _ in range(pop):
+        for r in DQN_ROLES:
+            popu[r].append(dqn_init(C, n_actions)[0])
+    stale = {r: popu[r][-1] for r in DQN_ROLES}
+    sig_attr = {"first_0": "mutation_power_agent_0", "second_0": "mutation_power_agent_1"}
+    hist = {"agent_0": [], "agent_1": [], "adversary_0": []}
+    per_gen = 2 * pop * hof_n + 10
+    out = []
+    for gen in range(args.generations):
+        rec = {"games": [], "fitness": [], "diversity": [], "elite_ids": []}
+        fitness = {}
+        for ph, role in enumerate(DQN_ROLES):
+            div = dqn_diversity(stale[role], popu[role])
+            fit = []
+            for i in range(pop):
+                last = None
+                for k in range(hof_n):
+                    opp = hof[DQN_ROLES[1 - ph]][hof_n - 1 - k]
+                    nets = (popu[role][i], opp) if ph == 0 else (opp, popu[role][i])
+                    g = dqn_play_game(nets[0], nets[1], C, n_actions, env_seed,
+                                      1 + gen * per_gen + ph * pop * hof_n + i * hof_n + k, T)
+                    rec["games"].append(g)
+                    last = g["rewards"][ph]
+                fit.append(last / hof_n / (1 + div))
+            fitness[role] = fit
+            rec["fitness"].append([float(f) for f in fit])
+            rec["diversity"].append(float(div))
+        elites = {}
+        for role in DQN_ROLES:
+            # integer hit counts tie often: the build's tie-break is the stable ascending sort reversed (higher index
+            # first), which is what np.argsort's default gives for the small n the reference's own tests could use
+            ids = [int(x) for x in np.argsort(fitness[role], kind="stable")[::-1][:E]]
+            rec["elite_ids"].append(ids)
+            elites[role] = [popu[role][i] for i in ids]
+        for r in DQN_ROLES:
+            hof[r].append(elites[r][0])
+            hof[r].pop(0)
+        rec["sigma_before"] = [getattr(args, sig_attr[r]) for r in DQN_ROLES]
+        new_pop = {}
+        for ri, r in enumerate(DQN_ROLES):
+            sigma = np.float32(getattr(args, sig_attr[r]))
+            new_pop[r] = [elites[r][0]] + [perturb_philox_flat(elites[r][c % E], sigma, philox_seed, c, gen * 4 + ri)
+                                           for c in range(pop - 1)]
+        popu = new_pop
+        rec["hof"] = {r: list(hof[r]) for r in DQN_ROLES}
+        rec["elites"] = elites
+        rec["pop"] = popu
+        ev = [0.0, 0.0]
+        for j in range(10):
+            g = dqn_play_game(elites["first_0"][0], elites["second_0"][0], C, n_actions, env_seed,
+                              1 + gen * per_gen + 2 * pop * hof_n + j, T_eval)
+            rec["games"].append(g)
+            for s in range(2):
+                ev[s] += g["rewards"][s]
+        ev = [e / 10 for e in ev]
+        rec["eval_rewards"] = ev
+        hist["agent_0"].append(ev[0])
+        hist["agent_1"].append(ev[1])
+        hist["adversary_0"].append(0.0)
+        if args.adaptive:
+            adapt_sigma(args, gen, hist)
+        rec["sigma_after"] = [args.mutation_power_agent_0, args.mutation_power_agent_1]
+        out.append(rec)
+    return out
+
+
+def dqn_es_update_from_pert(theta, pert, fitness, sigma, lr, C, n_actions, chunks=ES_CHUNKS):
+    P = len(theta)
+    out = np.ascontiguousarray(theta, dtype=np.float32).copy()
+    segs = dqn_bn_segments(C, n_actions)
+    so = np.array([s[0] for s in segs], dtype=np.int32)
+    sl = np.array([s[1] for s in segs], dtype=np.int32)
+    f = np.ascontiguousarray(fitness, dtype=np.float32)
+    pert = np.ascontiguousarray(pert, dtype=np.float32)
+    scale = np.float32(lr) / (np.float32(len(f)) * np.float32(sigma))
+    lib().oracle_es_update_from_pert(_fp(out), P, _fp(pert), _fp(f), len(f), float(scale), _ip(so), _ip(sl), len(segs),
+                                     int(chunks))
+    return out
+
+
+def dqn_es_train(args, C, n_actions, env_seed=0, philox_seed=0, antithetic=False, centered_rank=False):
+    """2-role Co-ES: per iteration j and role ri one game of the perturbed net (BatchNorm untouched) against the other
+    role's current base net (game ordinal 2j + ri); raw reward (or centered rank) fitness, optional sharing; chunked
+    canonical update; 10 evaluation games; adaptive sigma."""
+    pop = args.population
+    T, T_eval = args.max_timesteps_per_episode, args.max_evaluation_steps
+    base = {r: dqn_init(C, n_actions)[0] for r in DQN_ROLES}
+    bn = dqn_bn_segments(C, n_actions)
+    sig_attr = {"first_0": "mutation_power_agent_0", "second_0": "mutation_power_agent_1"}
+    hist = {"agent_0": [], "agent_1": [], "adversary_0": []}
+    per_gen = 2 * pop + 10
+    out = []
+    for gen in range(args.generations):
+        rec = {"games": [], "diversity": []}
+        pert = {r: [] for r in DQN_ROLES}
+        rew = {r: [] for r in DQN_ROLES}
+        for j in range(pop):
+            for ri, r in enumerate(DQN_ROLES):
+                sigma = np.float32(getattr(args, sig_attr[r]))
+                m = perturb_philox_flat(base[r], sigma, philox_seed, (j >> 1) if antithetic else j, gen * 4 + ri, bn,
+                                        negate=bool(antithetic and (j & 1)))
+                nets = (m, base["second_0"]) if ri == 0 else (base["first_0"], m)
+                g = dqn_play_game(nets[0], nets[1], C, n_actions, env_seed, 1 + gen * per_gen + 2 * j + ri, T)
+                rec["games"].append(g)
+                pert[r].append(m)
+                rew[r].append(g["rewards"][ri])
+        new = {}
+        for ri, r in enumerate(DQN_ROLES):
+            f = np.array(rew[r], dtype=np.float32)
+            if args.fitness_sharing:
+                div = dqn_diversity(base[r], pert[r])
+                f = f / (1 + div)
+                rec["diversity"].append(float(div))
+            else:
+                rec["diversity"].append(None)
+            if centered_rank:
+                f = centered_ranks(f)
+            new[r] = dqn_es_update_from_pert(base[r], np.stack(pert[r]), f, getattr(args, sig_attr[r]),
+                                             args.learning_rate, C, n_actions)
+        base = new
+        ev = [0.0, 0.0]
+        for j in range(10):
+            g = dqn_play_game(base["first_0"], base["second_0"], C, n_actions, env_seed,
+                              1 + gen * per_gen + 2 * pop + j, T_eval)
+            rec["games"].append(g)
+            for s in range(2):
+                ev[s] += g["rewards"][s]
+        ev = [e / 10 for e in ev]
+        rec["eval_rewards"] = ev
+        hist["agent_0"].append(ev[0])
+        hist["agent_1"].append(ev[1])
+        hist["adversary_0"].append(0.0)
+        if args.adaptive:
+            adapt_sigma(args, gen, hist)
+        rec["sigma_after"] = [args.mutation_power_agent_0, args.mutation_power_agent_1]
+        rec["base"] = {r: base[r].copy() for r in DQN_ROLES}
+        out.append(rec)
+    return out
