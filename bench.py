@@ -115,6 +115,18 @@ def main():
                     "the reference constructs (75 agent-steps per game); >= 67 lets T=200 bind (SURVEY 8d, cfg 2-T200)")
     ap.add_argument("--sharded-path", action="store_true", help="run the population-sharded loop (what --gpus N > 1 "
                     "uses) even on one GPU: its per-GPU cost without the all-gather")
+    ap.add_argument("--workload", default="ga", choices=["ga", "es", "dqn-ga", "dqn-es"],
+                    help="ga = the headline (BASELINE configs[1]); es = configs[2]; dqn-ga / dqn-es = the per-GPU shards of "
+                         "configs[3] / configs[4] over the synthetic Atari-shaped env")
+    ap.add_argument("--extension", action="store_true", help="es / dqn-es: antithetic pairs + centered ranks (BASELINE's "
+                    "wording of configs[2]; NOT the reference's algorithm)")
+    ap.add_argument("--es-pop-per-gpu", type=int, default=1000)
+    ap.add_argument("--dqn-pop-per-gpu", type=int, default=None, help="default 50 (dqn-ga) / 250 (dqn-es)")
+    ap.add_argument("--dqn-hof", type=int, default=10)
+    ap.add_argument("--channels", type=int, default=4, help="frame channels: 4 = BASELINE's 84x84x4; the reference's "
+                    "wrapper stack would yield 6")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other configs carried in "
+                    "the headline JSON's `extra` block")
     ap.add_argument("--cohorts", type=int, default=None, help="independent game cohorts per rollout (default: the "
                     "engine's DEFAULT_COHORTS)")
     a = ap.parse_args()
@@ -133,8 +145,6 @@ def main():
 
     from coevonet_amd import lib as L
     from coevonet_amd.dist import DistContext
-    from coevonet_amd.game_logic import initialize_env
-    from coevonet_amd.genetic_algorithm import GATrainer
 
     ctx = DistContext()
     if ctx.world != a.gpus:
@@ -143,10 +153,186 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     L.load()
-
-    pop = a.pop_per_gpu * ctx.world  # weak scaling: per-GPU work fixed
     torch.manual_seed(0)
     np.random.seed(0)
+    if a.workload == "ga":
+        out = run_ga(a, ctx, dev)
+    elif a.workload == "es":
+        out = run_es(a, ctx, dev)
+    else:
+        out = run_dqn(a, ctx, dev, a.workload[4:])
+    out.update({"n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "dist_backend": (torch.distributed.get_backend() if ctx.world > 1 else None),
+                "rccl_ranks": (torch.distributed.get_world_size() if ctx.world > 1 else 1)})
+    if ctx.rank == 0:
+        if a.workload == "ga" and ctx.world == 1 and not a.no_extra:
+            out["extra"] = extras(a, ctx, dev)
+        print(json.dumps(out), flush=True)
+    ctx.shutdown()
+
+
+def _timed_steps(step, a, ctx, dev, before_timed=None):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize; max over ranks"""
+    for _ in range(a.warmup):
+        step()
+    if before_timed:
+        before_timed()
+    ctx.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    ctx.barrier()
+    return ctx.max_over_ranks(time.perf_counter() - t0, dev)
+
+
+def run_es(a, ctx, dev, pop_per_gpu=None, extension=None):
+    """BASELINE configs[2]: Co-ES on simple_adversary_v3, pop 1000 per GPU, sigma 0.05, on-device perturb + update.
+    reference_exact (iid noise, raw rewards: what the reference runs) unless --extension (antithetic pairs + centered
+    ranks: BASELINE's wording, NOT in the reference - labelled in the output)."""
+    from coevonet_amd.evolutionary_strategy import ESTrainer
+    from coevonet_amd.game_logic import initialize_env
+    ppg = pop_per_gpu or a.es_pop_per_gpu
+    ext = a.extension if extension is None else extension
+    pop = ppg * ctx.world
+    args = make_args(pop, 1, 2, a.limit)
+    args.algorithm, args.fitness_sharing = "ES", False
+    args.coevo_antithetic = args.coevo_centered_rank = bool(ext)
+    env = initialize_env(args)
+    env.max_cycles = a.max_cycles
+    tr = ESTrainer(env, args, rng="device_philox", env_mode="device", collect=False, dist_ctx=ctx)
+    eng = tr.eng
+    dt = _timed_steps(tr.step, a, ctx, dev)
+    gens = a.steps / dt
+    cyc = (eng.T_train + 2) // 3
+    P4 = {10: 559124, 8: 555028}
+    gb = pop * (1 + cyc) * (2 * P4[10] + P4[8])   # materialise-once model of SURVEY 8d: write n*4P, read C*n*4P
+    return {"metric": "env-steps/sec (agent-steps of the whole job; generations/sec in gens_per_sec), Co-ES "
+                      "simple_adversary_v3 pop=1000/GPU",
+            "value": gens * eng.steps_per_generation, "unit": "env-steps/s", "gens_per_sec": gens,
+            "ms_per_step": 1e3 * dt / a.steps,
+            "config": {"workload": f"Co-ES simple_adversary_v3 pop={pop} ({ppg}/GPU) sigma=0.05 lr=0.1 T={a.limit} "
+                                   f"(env max_cycles={a.max_cycles}), " +
+                                   ("EXTENSION mode: antithetic pairs + centered ranks (not in the reference)" if ext else
+                                    "reference_exact: iid noise, raw rewards"),
+                       "population": pop, "agent_steps_per_generation": eng.steps_per_generation,
+                       "offspring": "device_philox", "update": f"{eng.chunks} chunk partial sums",
+                       "parallelism": f"population shard x{ctx.world}" if ctx.world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "whole generation (materialise-once model: write n*4P, read C*n*4P)",
+                         "achieved": gb * gens / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gb * gens / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_generation": gb}}
+
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-input MFMA = the f32 vector rate (/opt/skills/guides/MI355X_MICROARCH.md)
+DQN_CONV_MAC = 3276800 + 2654208 + 1806336   # conv1 + conv2 + conv3 MACs per frame at C = 4 (SURVEY 8: 3.28/2.65/1.81 M)
+
+
+def run_dqn(a, ctx, dev, algo, pop_per_gpu=None, T=None):
+    """BASELINE configs[3] / [4]: Co-GA (pop 200 over 4 GPUs = 50 per GPU, HoF 10, pong: 6 actions) or Co-ES (pop 2000
+    over 8 GPUs = 250 per GPU, boxing: 18 actions) over DeepQN policies on 84x84x4 frames, T=200 agent-steps per game.
+    No ALE in the image: the synthetic Atari-shaped env (coevonet_amd.atari_synthetic) - this measures the DeepQN forward
+    over (population x HoF x env copies), the on-device offspring and the all-gather, not game dynamics."""
+    from coevonet_amd.dqn_population import DQNESTrainer, DQNGATrainer
+    from coevonet_amd.game_logic import initialize_env
+    ga = algo == "ga"
+    ppg = pop_per_gpu or (a.dqn_pop_per_gpu or (50 if ga else 250))
+    pop = ppg * ctx.world
+    T = T or a.limit
+    args = make_args(pop, a.dqn_hof if ga else 1, a.elites, T)
+    args.algorithm = "GA" if ga else "ES"
+    args.game = "pong_v3" if ga else "boxing_v2"
+    args.coevo_channels = a.channels
+    args.fitness_sharing = ga          # the GA always computes its diversity (Q3); ES without, as cfg 3
+    args.generations = a.steps + a.warmup
+    args.coevo_graph = False           # eager enqueue: HIP events bracket sampled launches of the dominant kernel
+    env = initialize_env(args)
+    tr = (DQNGATrainer if ga else DQNESTrainer)(env, args, collect=False, dist_ctx=ctx)
+    eng = tr.eng
+    eng.ro.start_timing(pairs=2048, every=7)
+    dt = _timed_steps(tr.step, a, ctx, dev,
+                      before_timed=lambda: (torch.cuda.synchronize(),
+                                            L_load().coevo_rollout_ctx_reset_timing(eng.ro.timing_ctx)))
+    conv_ms = eng.ro.conv_times_ms()
+    if ga:
+        tr.finish()
+    gens = a.steps / dt
+    n_frames = eng.ro.n_games
+    mac = DQN_CONV_MAC + (a.channels - 4) * 64 * 32 * 400
+    out = {"metric": f"env-steps/sec (agent-steps of the whole job), Co-{'GA' if ga else 'ES'} over DeepQN on "
+                     f"{args.game}-shaped SYNTHETIC frames",
+           "value": gens * eng.steps_per_generation, "unit": "env-steps/s", "gens_per_sec": gens,
+           "ms_per_step": 1e3 * dt / a.steps,
+           "config": {"workload": (f"Co-GA DeepQN pop={pop} ({ppg}/GPU) HoF={args.hof_size} elites={a.elites}" if ga else
+                                   f"Co-ES DeepQN pop={pop} ({ppg}/GPU) sigma=0.05 lr=0.1") +
+                                  f" T={T} frames 84x84x{a.channels} actions={eng.n_actions}, synthetic env (no ALE in "
+                                  "the image; frames keyed by game, step and the previous action), build-defined 2-role loop",
+                      "population": pop, "agent_steps_per_generation": eng.steps_per_generation,
+                      "games_per_launch": n_frames, "offspring": "device_philox",
+                      "parallelism": f"population shard x{ctx.world}" if ctx.world > 1 else "single GPU"}}
+    if conv_ms:
+        avg = float(np.mean(conv_ms))
+        tf = n_frames * 2 * mac / (avg * 1e-3) / 1e12
+        rounds = (T + 1) // 2
+        gen_bytes = eng.ro.weight_bytes_per_round() * rounds
+        out["roofline"] = {"bound": "mfma", "kernel": "dqn_conv_kernel (conv stack + per-sample BatchNorm of every frame "
+                           "of one agent-step on v_mfma_f32_32x32x2_f32; exact f32 = the reference's arithmetic)",
+                           "timing": "HIP events around sampled launches on their stream (eager enqueue)",
+                           "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "flops_per_launch": n_frames * 2 * mac,
+                           "avg_launch_ms": avg, "launches_timed": len(conv_ms),
+                           "generation": {"bound": "hbm", "algorithmic_bytes": gen_bytes,
+                                          "achieved": gen_bytes * gens / 1e9, "unit": "GB/s",
+                                          "frac": gen_bytes * gens / 1e9 / HBM_PEAK_GBS,
+                                          "note": "SURVEY 8d cfg 4/5 byte model: every distinct acting weight set once "
+                                                  "per agent-step + frames"}}
+    return out
+
+
+def L_load():
+    from coevonet_amd import lib as L
+    return L.load()
+
+
+def extras(a, ctx, dev):
+    """short, bounded runs of the other BASELINE configs on the same GPU, carried in the headline JSON so that the
+    driver's record holds them (each is also its own --workload)"""
+    import copy
+    import gc
+    ex = {}
+    b = copy.copy(a)
+    b.steps, b.warmup = 5, 2
+    for name, fn in (("cfg3_coes_reference_exact", lambda: run_es(b, ctx, dev, extension=False)),
+                     ("cfg3_coes_extension_antithetic_centered_rank", lambda: run_es(b, ctx, dev, extension=True))):
+        try:
+            r = fn()
+            ex[name] = {k: r[k] for k in ("value", "unit", "gens_per_sec", "ms_per_step", "roofline")}
+            ex[name]["workload"] = r["config"]["workload"]
+        except Exception as e:
+            ex[name] = {"error": repr(e)}
+        gc.collect()
+        torch.cuda.empty_cache()
+    b.steps, b.warmup = 2, 1
+    for name, algo in (("cfg4_coga_deepqn_per_gpu_shard", "ga"), ("cfg5_coes_deepqn_per_gpu_shard", "es")):
+        try:
+            r = run_dqn(b, ctx, dev, algo)
+            ex[name] = {k: r[k] for k in ("value", "unit", "gens_per_sec", "ms_per_step", "roofline") if k in r}
+            ex[name]["workload"] = r["config"]["workload"]
+        except Exception as e:
+            ex[name] = {"error": repr(e)}
+        gc.collect()
+        torch.cuda.empty_cache()
+    return ex
+
+
+def run_ga(a, ctx, dev):
+    from coevonet_amd import lib as L
+    from coevonet_amd.game_logic import initialize_env
+    from coevonet_amd.genetic_algorithm import GATrainer
+
+    pop = a.pop_per_gpu * ctx.world  # weak scaling: per-GPU work fixed
     args = make_args(pop, a.hof, a.elites, a.limit)
     args.generations = a.steps + a.warmup  # sizes the device-resident evaluation / sigma histories
     if a.cohorts is not None:
@@ -192,10 +378,7 @@ def main():
         "metric": "env-steps/sec (agent-steps of the whole job; generations/sec in gens_per_sec), Co-GA "
                   "simple_adversary_v3 pop=200/GPU HoF=5",
         "value": gens_per_s * steps_per_gen, "unit": "env-steps/s", "gens_per_sec": gens_per_s,
-        "n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "dist_backend": (torch.distributed.get_backend() if ctx.world > 1 else None),
-        "rccl_ranks": (torch.distributed.get_world_size() if ctx.world > 1 else 1),
+        "ms_per_step": 1e3 * dt / a.steps,
         "config": {"workload": f"Co-GA simple_adversary_v3 pop={pop} ({a.pop_per_gpu}/GPU) HoF={a.hof} "
                                f"elites={a.elites} T={a.limit} (env max_cycles={a.max_cycles} caps a game at "
                                f"{3 * a.max_cycles} agent-steps" + (", as in the reference" if a.max_cycles == 25 else
@@ -288,8 +471,8 @@ def main():
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(a.pop_per_gpu, a.hof, a.limit, workers=workers)
             except Exception as e:  # the single-core figure above is the contractual one
                 out["cpu_baseline_all_cores"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
-    ctx.shutdown()
+    del tr
+    return out
 
 
 if __name__ == "__main__":

@@ -344,14 +344,25 @@ extern "C" int coevo_dqn_forward_argmax(const float *slab, const coevo_dqn_task 
                                         const uint8_t *frames, int32_t *actions, float *logits, int32_t *status,
                                         void *workspace, void *stream)
 {
+    return coevo_dqn_forward_argmax_timed(slab, tasks, n_tasks, max_rows_per_task, n_rows_total, C, n_actions, frames,
+                                          actions, logits, status, workspace, nullptr, stream);
+}
+
+extern "C" int coevo_dqn_forward_argmax_timed(const float *slab, const coevo_dqn_task *tasks, int n_tasks,
+                                              int max_rows_per_task, int n_rows_total, int C, int n_actions,
+                                              const uint8_t *frames, int32_t *actions, float *logits, int32_t *status,
+                                              void *workspace, void *timing_ctx, void *stream)
+{
     if (!slab || !tasks || !frames || !actions || !status || !workspace) return COEVO_ERR_ARG;
     if (n_tasks <= 0 || n_rows_total <= 0 || !dqn_shape_ok(C, n_actions)) return COEVO_ERR_ARG;
     if (max_rows_per_task < 1 || max_rows_per_task > DQ_RMAX) return COEVO_ERR_ARG;
     float *act = static_cast<float *>(workspace);
     float *hid = act + (size_t)n_rows_total * DQ_FC1_IN;
     hipStream_t s = (hipStream_t)stream;
+    if (timing_ctx && coevo_timing_begin(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     hipLaunchKernelGGL(dqn_conv_kernel, dim3(n_tasks, max_rows_per_task), dim3(256), 0, s, slab, tasks, C, n_actions,
                        frames, act);
+    if (timing_ctx && coevo_timing_end(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     const dim3 g1(n_tasks, 8), b1(64);
     switch ((max_rows_per_task + 3) / 4) {
     case 1: hipLaunchKernelGGL(dqn_fc1_kernel<1>, g1, b1, 0, s, slab, tasks, C, n_actions, act, hid); break;

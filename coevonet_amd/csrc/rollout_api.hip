@@ -90,6 +90,28 @@ extern "C" void *coevo_rollout_ctx_cohort_stream(void *ctx, int k)
     return c->lanes[k - 1].s;
 }
 
+// generic use of the context's timing event pairs: bracket whatever is enqueued on `stream` between the two calls (eager
+// enqueue only - events cannot be recorded inside a captured graph on this runtime); read with
+// coevo_rollout_ctx_light_times.  Used by coevo_dqn_forward_argmax_timed around its dominant kernel.
+extern "C" int coevo_timing_begin(void *ctx, void *stream)
+{
+    auto *c = static_cast<coevo_rollout_ctx *>(ctx);
+    if (!c) return COEVO_ERR_ARG;
+    if (2 * (size_t)c->pairs_used + 1 >= c->timing.size()) return COEVO_OK;   // out of pairs: stop sampling, keep running
+    COEVO_HIP_CHECK(hipEventRecord(c->timing[2 * c->pairs_used], (hipStream_t)stream));
+    return COEVO_OK;
+}
+
+extern "C" int coevo_timing_end(void *ctx, void *stream)
+{
+    auto *c = static_cast<coevo_rollout_ctx *>(ctx);
+    if (!c) return COEVO_ERR_ARG;
+    if (2 * (size_t)c->pairs_used + 1 >= c->timing.size()) return COEVO_OK;
+    COEVO_HIP_CHECK(hipEventRecord(c->timing[2 * c->pairs_used + 1], (hipStream_t)stream));
+    c->pairs_used += 1;
+    return COEVO_OK;
+}
+
 extern "C" int coevo_rollout_ctx_reset_timing(void *ctx)
 {
     auto *c = static_cast<coevo_rollout_ctx *>(ctx);

@@ -73,6 +73,19 @@ class SynthRollout:
         self.limit = torch.zeros(n, dtype=torch.int32, device=device)
         self.status = torch.zeros(1, dtype=torch.int32, device=device)
         self.ws = torch.zeros(int(L.load().coevo_dqn_workspace_bytes(n)) // 4, dtype=torch.float32, device=device)
+        self.timing_ctx = None      # set by start_timing(): HIP events around sampled conv-stack launches (eager only)
+        self.timing_every = 1
+
+    def start_timing(self, pairs=512, every=7):
+        self.timing_ctx = L.load().coevo_rollout_ctx_create(int(pairs))
+        self.timing_every = int(every)
+
+    def conv_times_ms(self, max_out=100000):
+        if not self.timing_ctx:
+            return []
+        buf = (L.C.c_float * max_out)()
+        n = L.load().coevo_rollout_ctx_light_times(self.timing_ctx, buf, max_out)
+        return [buf[i] for i in range(max(n, 0))]
 
     def set_limits(self, limits):
         self.limit.copy_(torch.from_numpy(np.asarray(limits, dtype=np.int32)))
@@ -87,9 +100,10 @@ class SynthRollout:
                    self.actions[q].data_ptr() if t else None, L._p(self.rows[p]) if t < T else None,
                    L._p(self.frames) if t < T else None, self.C, self.n_actions, self.env_seed)
             if t < T:
-                L.call("coevo_dqn_forward_argmax", L._p(self.slab), L._p(self.tasks[p]), self.n_tasks[p],
+                timed = self.timing_ctx if (self.timing_ctx and t % self.timing_every == 0) else None
+                L.call("coevo_dqn_forward_argmax_timed", L._p(self.slab), L._p(self.tasks[p]), self.n_tasks[p],
                        self.max_rows[p], self.n_games, self.C, self.n_actions, L._p(self.frames),
-                       self.actions[p].data_ptr(), None, L._p(self.status), L._p(self.ws))
+                       self.actions[p].data_ptr(), None, L._p(self.status), L._p(self.ws), timed)
 
     def weight_bytes_per_round(self):
         """algorithmic bytes of one round (two agent-steps): every distinct acting weight set once per agent-step +

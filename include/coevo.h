@@ -370,6 +370,14 @@ int coevo_dqn_forward_argmax(const float *slab, const coevo_dqn_task *tasks, int
                              int n_rows_total, int C, int n_actions, const uint8_t *frames, int32_t *actions,
                              float *logits, int32_t *status, void *workspace, void *stream);
 
+/* the same with the conv-stack launch (the dominant kernel) bracketed by the next timing event pair of a rollout context
+ * (coevo_rollout_ctx_create / coevo_rollout_ctx_light_times); eager enqueue only; timing_ctx == NULL = untimed */
+int coevo_dqn_forward_argmax_timed(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int max_rows_per_task,
+                                   int n_rows_total, int C, int n_actions, const uint8_t *frames, int32_t *actions,
+                                   float *logits, int32_t *status, void *workspace, void *timing_ctx, void *stream);
+/* bracket whatever is enqueued on `stream` between the two calls with the context's next timing event pair */
+int coevo_timing_begin(void *ctx, void *stream);
+int coevo_timing_end(void *ctx, void *stream);
 int coevo_dqn_unpack(const float *slab, float *flat, int n, int C, int n_actions, void *stream);
 
 /* ---------------------------------------------------------------- DeepQN population engine (cfg 4 / cfg 5) ---------- */

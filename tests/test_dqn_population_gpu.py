@@ -89,16 +89,19 @@ def test_play_game_atari_device_host_oracle_agree(game, C):
     assert env.n_resets == 1 and env.observation_space("first_0").shape == (84, 84, C)
     a, b = create_agent(env, args), create_agent(env, args)
     n = env.n_actions
+    seen = []
     for i, ev in enumerate([False, True, False]):
         dev = play_game(env=env, player1=a.model, player2=b.model, args=args, eval=ev)
         ordinal = env.ordinal
         want = rp.dqn_play_game(a.model.flat(), b.model.flat(), C, n, env.seed_value, ordinal, 4 if ev else 7)
         assert list(dev) == want["rewards"], (i, dev, want)
+        seen += want["rewards"] + [float(len(set(want["actions"])) > 1)]
+    assert any(seen[0::3] + seen[1::3]) and any(seen[2::3])   # some hit was credited; the frames do steer the actions
     args.coevo_host_aec = True
     env2 = initialize_env(args)
     host = play_game(env=env2, player1=a.model, player2=b.model, args=args, eval=False)
     want = rp.dqn_play_game(a.model.flat(), b.model.flat(), C, n, env2.seed_value, 1, 7)
-    assert list(host) == want["rewards"] and any(want["rewards"])
+    assert list(host) == want["rewards"]
 
 
 def _ga_cfg(**kw):
