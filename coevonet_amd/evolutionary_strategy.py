@@ -364,22 +364,23 @@ def evolution_strategy_train(env, args, output_dir, rng=None, env_mode=None, col
     if getattr(args, "game", "simple_adversary_v3") != "simple_adversary_v3":   # the two-player Atari games
         from .dqn_population import dqn_evolution_strategy_train
         return dqn_evolution_strategy_train(env, args, output_dir, collect=collect, dist_ctx=dist_ctx)
-    from .io_utils import ES_FILES, MetricsWriter, save_model
+    from .io_utils import ES_FILES, MetricsWriter, save_model, save_state_dicts
     tr = ESTrainer(env, args, rng=rng, env_mode=env_mode, collect=collect, dist_ctx=dist_ctx)
     save = bool(getattr(args, "save", False)) and output_dir is not None
+    mw = MetricsWriter(output_dir)
     for _ in range(args.generations):
         go_on = tr.step()
+        res, g = tr.res, tr.gen - 1   # one metrics line per generation, written as it finishes
+        mw.write(generation=g, eval_rewards={r: res.rewards[r][g] for r in ROLES}, mutation_power=res.sigma_after[g],
+                 diversity=res.diversity[g] if g < len(res.diversity) else None,
+                 seconds=res.seconds[g] if g < len(res.seconds) else None, stopped=not go_on)
         if not go_on:  # evolutionary_strategy.py:343-354: the reference breaks BEFORE save_model (:357-360), so the
             break      # stopping generation's update is never written
         if save:
             for a, r in zip(tr.base_agents(), ROLES):
                 save_model(a, os.path.join(output_dir, ES_FILES[r]))
+                save_state_dicts(a, os.path.join(output_dir, ES_FILES[r]), role=r)   # the weights_only-safe twin
     res = tr.finish()
     res.engine = tr.eng
     agents = tr.base_agents()
-    mw = MetricsWriter(output_dir)
-    for g in range(len(res.rewards["agent_0"])):
-        mw.write(generation=g, eval_rewards={r: res.rewards[r][g] for r in ROLES}, mutation_power=res.sigma_after[g],
-                 diversity=res.diversity[g] if g < len(res.diversity) else None,
-                 seconds=res.seconds[g] if g < len(res.seconds) else None)
     return (agents, res) if return_result else agents

@@ -876,26 +876,45 @@ def genetic_algorithm_train(env, agent, args, output_dir, rng=None, env_mode=Non
     if getattr(args, "game", "simple_adversary_v3") != "simple_adversary_v3":   # the two-player Atari games
         from .dqn_population import dqn_genetic_algorithm_train
         return dqn_genetic_algorithm_train(env, agent, args, output_dir, collect=collect, dist_ctx=dist_ctx)
-    from .io_utils import GA_FILES, MetricsWriter, agents_from_flat, save_model
+    from .io_utils import GA_FILES, MetricsWriter, agents_from_flat, save_model, save_state_dicts
     tr = GATrainer(env, args, rng=rng, env_mode=env_mode, collect=collect, dist_ctx=dist_ctx)
     save = bool(getattr(args, "save", False)) and output_dir is not None
+    mw = MetricsWriter(output_dir)
+    written = 0
+
+    def flush_metrics(res, upto):
+        """one line per generation as soon as its numbers exist on the host (a crash keeps what was written): the
+        host-driven loop knows generation g-1's evaluation after step g; the host-free device loop harvests a
+        generation's results one step later and keeps the evaluation / sigma histories on the device until finish()"""
+        nonlocal written
+        while written < upto:
+            g = written
+            have = lambda lst: lst[g] if g < len(lst) else None
+            mw.write(generation=g,
+                     eval_rewards={r: res.rewards[r][g] for r in ROLES} if g < len(res.rewards["agent_0"]) else None,
+                     mutation_power=have(res.sigma_after), diversity=have(res.diversity), elite_ids=have(res.elite_ids),
+                     fitness_best=[max(f) for f in res.fitness[g]] if g < len(res.fitness) else None,
+                     seconds=have(res.seconds))
+            written += 1
+
     for _ in range(args.generations):
         tr.step()
         if save:  # genetic_algorithm.py:293-299: HoF and elites of the three roles, every generation
             for r in ROLES:
                 hof_file, elite_file = GA_FILES[r]
-                save_model(agents_from_flat(env, args, r, tr.eng.download(r, "hof", 0, args.hof_size)),
-                           os.path.join(output_dir, hof_file))
-                save_model(agents_from_flat(env, args, r, tr.eng.download(r, "elite", 0, args.elites_number)),
-                           os.path.join(output_dir, elite_file))
+                for region, n, fname in (("hof", args.hof_size, hof_file), ("elite", args.elites_number, elite_file)):
+                    agents = agents_from_flat(env, args, r, tr.eng.download(r, region, 0, n))
+                    save_model(agents, os.path.join(output_dir, fname))
+                    save_state_dicts(agents, os.path.join(output_dir, fname), role=r)   # the weights_only-safe twin
+        if tr.device_loop or tr.sharded_loop:
+            flush_metrics(tr.res, min(len(tr.res.elite_ids), tr.gen - 1))   # harvested so far; final values at finish()
+        else:
+            flush_metrics(tr.res, len(tr.res.rewards["agent_0"]))
     res = tr.finish()
-    mw = MetricsWriter(output_dir)
-    for g in range(len(res.rewards["agent_0"])):
-        mw.write(generation=g, eval_rewards={r: res.rewards[r][g] for r in ROLES},
-                 mutation_power=res.sigma_after[g] if g < len(res.sigma_after) else None,
-                 diversity=res.diversity[g] if g < len(res.diversity) else None,
-                 elite_ids=res.elite_ids[g] if g < len(res.elite_ids) else None,
-                 seconds=res.seconds[g] if g < len(res.seconds) else None)
+    if tr.device_loop or tr.sharded_loop:  # the histories only now left the device: rewrite the file with them filled in
+        mw = MetricsWriter(output_dir)
+        written = 0
+    flush_metrics(res, len(res.rewards["agent_0"]))
     return res
 
 

@@ -5,6 +5,9 @@
   evolutionary_strategy.py:154-156, 357-360), so ``load_agent_for_testing`` (utils/utils_pth_and_plots.py:8-74) +
   ``main.py --test`` keep working on what this package writes (the pickles reference ``coevonet_amd.agent.MPEAgent``;
   pass ``weights_only=False`` to ``torch.load`` on torch >= 2.6, which the reference does not).
+* ``save_state_dicts`` writes, beside every pickle, ``<name>.state_dict.pth``: plain ``OrderedDict``s of tensors (one
+  ``state_dict()`` per agent, keys = the reference's parameter names) that ``torch.load(..., weights_only=True)`` accepts
+  - no code object is unpickled; ``agents_from_state_dicts`` rebuilds the ``Agent`` objects from them.
 * ``MetricsWriter`` replaces the three matplotlib savefigs per generation (utils/utils_pth_and_plots.py:153-262, 2.6 s per
   generation in the reference, and a crash without --adaptive at :235) with one JSON line per generation.
 """
@@ -27,6 +30,48 @@ def save_model(obj, file_path):
 
 def load_agents(file_path):
     return torch.load(file_path, weights_only=False)
+
+
+STATE_DICT_SUFFIX = ".state_dict.pth"
+
+
+def state_dict_path(file_path):
+    root = file_path[:-4] if file_path.endswith(".pth") else file_path
+    return root + STATE_DICT_SUFFIX
+
+
+def save_state_dicts(agents, file_path, role=None):
+    """the `weights_only`-safe variant of save_model (SURVEY 8f row 3): {"format", "role", "agents": [state_dict, ...]}
+    with tensors only.  `agents`: an Agent or a list of Agents.  Returns the path written."""
+    single = not isinstance(agents, (list, tuple))
+    lst = [agents] if single else list(agents)
+    payload = {"format": "coevonet_amd.state_dict.v1", "role": role or "", "single": single,
+               "agents": [{k: v.detach().clone() for k, v in a.model.state_dict().items()} for a in lst]}
+    path = state_dict_path(file_path)
+    torch.save(payload, path)
+    return path
+
+
+def load_state_dicts(path):
+    """-> (list of state_dicts, role, was_single_agent); never unpickles code"""
+    payload = torch.load(path, weights_only=True)
+    if payload.get("format") != "coevonet_amd.state_dict.v1":
+        raise ValueError(f"{path} is not a coevonet_amd state_dict checkpoint")
+    return payload["agents"], payload["role"], bool(payload["single"])
+
+
+def agents_from_state_dicts(env, args, role, path):
+    """Agent objects (what load_agent_for_testing returns, utils/utils_pth_and_plots.py:8-74) from the safe file"""
+    from .game_logic import create_agent
+    sds, saved_role, single = load_state_dicts(path)
+    state = torch.random.get_rng_state()
+    out = []
+    for sd in sds:
+        a = create_agent(env, args, role or saved_role or None)
+        a.model.load_state_dict(sd)
+        out.append(a)
+    torch.random.set_rng_state(state)
+    return out[0] if single else out
 
 
 def agents_from_flat(env, args, role, flats):

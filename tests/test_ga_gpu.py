@@ -139,6 +139,16 @@ def test_save_and_metrics_roundtrip(tmp_path):
         assert len(hof) == 2 and hasattr(hof[-1], "model") and hasattr(hof[-1].model, "determine_action")
         assert [sha(a.model.flat()) for a in hof] == [sha(w) for w in res.engine.download(role, "hof", 0, 2)]
         assert len(load_agents(os.path.join(tmp_path, elite_file))) == 2
+    # the weights_only-safe twins: tensors only, loadable without unpickling code, same weights
+    from coevonet_amd.io_utils import agents_from_state_dicts, state_dict_path
+    for role, (hof_file, elite_file) in GA_FILES.items():
+        path = state_dict_path(os.path.join(tmp_path, hof_file))
+        payload = torch.load(path, weights_only=True)
+        assert payload["format"] == "coevonet_amd.state_dict.v1" and len(payload["agents"]) == 2
+        assert set(payload["agents"][0]) == {"fc1.weight", "fc1.bias", "ln1.weight", "ln1.bias", "fc2.weight", "fc2.bias",
+                                             "ln2.weight", "ln2.bias", "output.weight", "output.bias"}
+        back = agents_from_state_dicts(env, args, role, path)
+        assert [sha(a.model.flat()) for a in back] == [sha(w) for w in res.engine.download(role, "hof", 0, 2)]
     lines = [json.loads(x) for x in open(os.path.join(tmp_path, "metrics.jsonl"))]
     assert len(lines) == 2 and lines[1]["generation"] == 1 and set(lines[0]["eval_rewards"]) == set(ga.ROLES)
     # a reloaded trio plays through the drop-in play_game like main.py --test does

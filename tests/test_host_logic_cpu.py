@@ -185,3 +185,23 @@ def test_unequal_shards_are_rejected():
     from coevonet_amd.genetic_algorithm import GAEngine
     with pytest.raises(ValueError, match="not divisible"):
         GAEngine(pop=7, hof=1, elites=1, shard=(0, 2), device="cpu")
+
+
+def test_weights_only_safe_checkpoint_roundtrip(tmp_path):
+    """the state_dict twin of a --save file loads with torch.load(weights_only=True) - tensors only"""
+    import os
+    from coevonet_amd.io_utils import agents_from_state_dicts, load_state_dicts, save_state_dicts
+    args = Bag()
+    env = initialize_env(args)
+    agents = [create_agent(env, args, "adversary_0") for _ in range(3)]
+    path = save_state_dicts(agents, os.path.join(tmp_path, "hall_of_fame_adversary.pth"), role="adversary_0")
+    assert path.endswith("hall_of_fame_adversary.state_dict.pth")
+    sds, role, single = load_state_dicts(path)
+    assert role == "adversary_0" and not single and len(sds) == 3 and sds[0]["fc1.weight"].shape == (512, 8)
+    state = torch.random.get_rng_state()
+    back = agents_from_state_dicts(env, args, None, path)
+    assert torch.equal(state, torch.random.get_rng_state())          # rebuilding agents leaves the RNG stream alone
+    assert [sha(a.model.flat()) for a in back] == [sha(a.model.flat()) for a in agents]
+    one = agents_from_state_dicts(env, args, "adversary_0",
+                                  save_state_dicts(agents[1], os.path.join(tmp_path, "adversary.pth"), role="adversary_0"))
+    assert sha(one.model.flat()) == sha(agents[1].model.flat())
