@@ -116,8 +116,23 @@ __device__ unsigned long long g_phase_stamps[4096 * 16];
             g_phase_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime();            \
         }                                                                                       \
     } while (0)
+// per-wave stamps (lane 0 of every wave): where do the waves of a workgroup wait for each other?
+__device__ unsigned long long g_wave_stamps[4096 * 4 * 16];
+#define COEVO_WSTAMP(i)                                                                                         \
+    do {                                                                                                        \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                                       \
+            g_wave_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+// shader-clock counter (s_memtime) next to the 100 MHz one: effective clock of a section = d(memtime) / d(memrealtime)
+#define COEVO_CSTAMP(i)                                                                                         \
+    do {                                                                                                        \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096)                                                       \
+            g_wave_stamps[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memtime();     \
+    } while (0)
 #else
 #define COEVO_STAMP(i) do { } while (0)
+#define COEVO_WSTAMP(i) do { } while (0)
+#define COEVO_CSTAMP(i) do { } while (0)
 #endif
 
 // One workgroup carries P nets (tasks first .. first+P-1).  P = 1 is the plain kernel.  P = 2 is used by the merged
@@ -431,6 +446,324 @@ __device__ __forceinline__ void fc_policy_body(const FcArgs &a, FcSmem<R, P> &sm
         if (a.logits) {
 #pragma unroll
             for (int o = 0; o < NACT; ++o) a.logits[(size_t)row * COEVO_LOGIT_STRIDE + o] = sm.logit[pw][l][o];
+        }
+    }
+    if (st) atomicOr(a.status, st);
+    COEVO_STAMP(6);
+}
+
+// =====================================================================================================
+// The per-individual body of the lean merged cycle kernel (COEVO_COMPACT, default), written for FEW ISSUED INSTRUCTIONS.
+// In a cycle launch all sixteen waves of a CU run the same phase at the same time, so everything outside the weight
+// stream is bound by the SIMDs' issue slots, not by latency: with fc1 / LayerNorm computed per thread for every row
+// (fc_policy_body: thread = feature, 6-level butterfly per value) a workgroup spends ~30 of its 67 us there
+// (tools/merged_wg_times.py).  Here a ROW belongs to ONE WAVE (rows w, w + 4): its fc1, both LayerNorm passes and the
+// normalisation need no barrier, and the eight 64-feature block sums of a row are reduced by ONE packed butterfly
+// (after each level the duplicate lanes are re-used for the next block: 30 instead of 88 instructions) - a third of the
+// issued instructions and four barriers less.  fc1's weights and the LayerNorm parameters are staged by LDS-DMA (no
+// registers held across the env step).  The arithmetic - every fmaf chain, every reduction tree, the left-to-right block
+// sums - is the canonical one, so the bits are those of fc_policy_body and of the oracle.
+template <int R>
+struct FcSmemC {
+    static constexpr int NG = (R + 3) / 4;   // row groups of four = v_mfma_f32_4x4x1 issues per k
+    static constexpr int RP = 4 * NG + 1;    // odd row pitch of the k-quad image (see FcSmem)
+    union {
+        float par[13 * H1];                  // W1t [D][512], fc1.bias, ln1.weight, ln1.bias: contiguous in the slab
+        float h1q[128][RP][4];               // A operands of fc2 (written once every wave is done with `par`)
+        struct { float h2[R][260]; float w3s[NACT][260]; float raw2[R][H2]; } tail;   // after the stream
+    };
+    float xs0[R][COEVO_OBS_STRIDE];
+    float logit[R][COEVO_LOGIT_STRIDE];
+};
+
+// true lane-xor exchanges (the packed butterfly needs partners that agree in the lower lane bits)
+__device__ __forceinline__ float lane_xor4(float v)
+{
+    int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xf, 0x5, false);   // row_shl:4 -> lanes 0-3, 8-11
+    x = __builtin_amdgcn_update_dpp(x, __float_as_int(v), 0x114, 0xf, 0xa, false);       // row_shr:4 -> lanes 4-7, 12-15
+    return __int_as_float(x);
+}
+__device__ __forceinline__ float add_xor16(float v)
+{
+    typedef unsigned u32x2_h __attribute__((ext_vector_type(2)));
+    const u32x2_h s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+__device__ __forceinline__ float add_xor32(float v)
+{
+    typedef unsigned u32x2_h __attribute__((ext_vector_type(2)));
+    const u32x2_h s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+
+// Reduce(NB * 64) of the canonical arithmetic for one row held by one wave: v[b] = the lane's element of block b.
+// Per block the balanced tree lane xor 1, 2, 4, 8, 16, 32; then the block sums left to right.  After level m the 2m lanes
+// of a group hold the same value, so two blocks share a register from there on (lane bit selects the block).
+template <int NB>
+__device__ __forceinline__ float row_blocks_total(const float (&v)[NB], int l)
+{
+    static_assert(NB == 8 || NB == 4, "LayerNorm(512) / LayerNorm(256)");
+    float p[NB / 2];
+#pragma unroll
+    for (int j = 0; j < NB / 2; ++j) {
+        const float a = v[2 * j] + dpp_move<0xB1>(v[2 * j]), b = v[2 * j + 1] + dpp_move<0xB1>(v[2 * j + 1]);   // xor 1
+        p[j] = (l & 1) ? b : a;
+    }
+    float q[NB / 4];
+#pragma unroll
+    for (int j = 0; j < NB / 4; ++j) {
+        const float a = p[2 * j] + dpp_move<0x4E>(p[2 * j]), b = p[2 * j + 1] + dpp_move<0x4E>(p[2 * j + 1]);   // xor 2
+        q[j] = (l & 2) ? b : a;
+    }
+    float s;
+    if constexpr (NB == 8) {
+        const float a = q[0] + lane_xor4(q[0]), b = q[1] + lane_xor4(q[1]);                                      // xor 4
+        s = (l & 4) ? b : a;
+    } else {
+        s = q[0] + lane_xor4(q[0]);
+    }
+    s = s + dpp_move<0x128>(s);   // xor 8: row_ror:8
+    s = add_xor16(s);
+    s = add_xor32(s);
+    // lane j (j < NB) holds the total of block j
+    float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 0));
+#pragma unroll
+    for (int b = 1; b < NB; ++b) tot = tot + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), b));
+    return tot;
+}
+
+template <int R, int MODE>
+__device__ __forceinline__ void fc_policy_body_c(const FcArgs &a, FcSmemC<R> &sm, const coevo_fc_task *tasks, int first,
+                                                 int n_tasks)
+{
+    static_assert(MODE == MODE_FUSED && R * NACT <= 64 && R <= 8, "the lean merged cycle kernel; rows w and w + 4 per wave");
+    COEVO_STAMP(0);
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    const bool active = first < n_tasks;
+    const coevo_fc_task task = tasks[active ? first : n_tasks - 1];
+    const int D = task.D, nrows = active ? task.n_rows : 0, row0 = task.row_begin;
+    const float *net = a.slab + task.net_off;
+    int st = 0;
+
+    // ---- W1t, fc1.bias and the LayerNorm(512) affine: (D + 3) * 512 contiguous floats, by LDS-DMA in 16-byte pieces (a
+    //      wave's 64 pieces land contiguously at its wave-uniform base; (D + 3) * 128 pieces are a multiple of 64) ------
+    const int n_pieces = (D + 3) * (H1 / 4);
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+        if (64 * w + 256 * j < n_pieces)   // wave-uniform
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(net + 4 * (t + 256 * j)),
+                                             (__attribute__((address_space(3))) void *)(&sm.par[4 * (64 * w + 256 * j)]),
+                                             16, 0, 0);
+    const float *b2p = net + fc_off_b2(D);
+    float w3r[5];
+    {
+        const float *W3 = net + fc_off_w3(D);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) w3r[j] = W3[t + 256 * j];
+    }
+    const float p_b2 = b2p[t];
+    float p_g2[4], p_be2[4];   // LayerNorm(256) affine of features 64 b + l (the row-owning wave's layout)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { p_g2[b] = b2p[H2 + 64 * b + l]; p_be2[b] = b2p[2 * H2 + 64 * b + l]; }
+    const float p_b3 = (w == 0 && l < R * NACT) ? net[fc_off_b3(D) + l % NACT] : 0.0f;
+
+    // ---- env step + observation: one lane per row (wave 0) ----------------------------------------------------
+    if (w == 0 && l < R) {
+        float o[COEVO_OBS_STRIDE];
+#pragma unroll
+        for (int k = 0; k < COEVO_OBS_STRIDE; ++k) o[k] = 0.0f;
+        if (l < nrows) {
+            const int row = row0 + l;
+            mpe_fused_observe<false>(a.state, a.state_next, a.act_prev, a.game_limit, a.n_games, a.row_game[row],
+                                     a.row_slot[row], a.cycle, a.pos_first, o);
+#pragma unroll
+            for (int k = 0; k < 10; ++k)
+                if (!__builtin_isfinite(o[k])) st |= COEVO_ST_BAD_INPUT;
+        }
+#pragma unroll
+        for (int k = 0; k < COEVO_OBS_STRIDE; ++k) sm.xs0[l][k] = o[k];
+    }
+    COEVO_WSTAMP(0);
+    __syncthreads();   // (waits for the LDS-DMA too: the fence counts it on vmcnt)
+    COEVO_WSTAMP(1);
+    COEVO_CSTAMP(10);
+    COEVO_STAMP(1);
+
+    // ---- fc1 + LayerNorm(512) + ReLU of rows w and w + 4, all inside this wave: lane l holds features 64 b + l --------
+    constexpr int NOWN = (R + 3) / 4;   // rows a wave may own
+    // which wave gets the extra row rotates with the workgroup: the waves w of the workgroups that share a CU sit on the
+    // same SIMD, and these phases are bound by the SIMDs' issue slots
+#ifndef COEVO_ROT_SHIFT
+#define COEVO_ROT_SHIFT 8
+#endif
+    const int wo = (w - (int)(blockIdx.x >> COEVO_ROT_SHIFT)) & 3;   // wave-uniform: this wave owns rows wo, wo + 4
+    float y1[NOWN][8];
+    const float *b1s = sm.par + D * H1, *g1s = b1s + H1, *be1s = g1s + H1;
+#pragma unroll
+    for (int i = 0; i < NOWN; ++i) {
+        const int r = wo + 4 * i;
+        if (r < R) {   // wave-uniform
+            float v[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) v[b] = b1s[64 * b + l];
+#pragma nounroll
+            for (int k = 0; k < D; ++k) {   // sequential-k chains from the bias
+                const float x = sm.xs0[r][k];
+                const float *wk = sm.par + k * H1 + l;
+#pragma unroll
+                for (int b = 0; b < 8; ++b) v[b] = __builtin_fmaf(wk[64 * b], x, v[b]);
+            }
+            const float mean = row_blocks_total<8>(v, l) * (1.0f / H1);
+            float sq[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) { v[b] = v[b] - mean; sq[b] = v[b] * v[b]; }
+            const float var = row_blocks_total<8>(sq, l) * (1.0f / H1);
+            const float rstd = 1.0f / __builtin_sqrtf(var + LN_EPS);
+            bool bad = false;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const float y = __builtin_fmaf(v[b] * rstd, g1s[64 * b + l], be1s[64 * b + l]);
+                bad = bad || bad_post_relu(y);
+                y1[i][b] = relu_keep_nan(y);
+            }
+            if (r < nrows && bad) st |= COEVO_ST_BAD_FC1;
+        }
+    }
+    COEVO_STAMP(8);
+    COEVO_CSTAMP(11);
+    COEVO_WSTAMP(2);
+    __syncthreads();   // every wave is done with `par`: the k-quad image may overwrite it
+    COEVO_WSTAMP(3);
+#pragma unroll
+    for (int i = 0; i < NOWN; ++i) {
+        const int r = wo + 4 * i;
+        if (r < R) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) sm.h1q[(64 * b + l) >> 2][r][l & 3] = y1[i][b];
+        }
+    }
+    COEVO_WSTAMP(6);
+    __syncthreads();
+    COEVO_WSTAMP(7);
+    COEVO_STAMP(2);
+
+    // ---- fc2 on the matrix cores, as in fc_policy_body; the ping-pong loop carries its own tail ------------------
+    typedef float f32x4_acc __attribute__((ext_vector_type(4)));
+    constexpr int NG = FcSmemC<R>::NG;
+    f32x4_acc acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[g][i] = p_b2;
+    {
+        const float4 *wp = reinterpret_cast<const float4 *>(net + fc_off_w2(D)) + (size_t)w * 128 * 64 + l;
+        constexpr int U = COEVO_LIGHT_U;
+        static_assert(128 % (2 * U) == 0, "the k-quads are consumed in pairs of buffers");
+        float4 bufA[U], bufB[U];
+        auto issue = [&](float4 (&buf)[U], int kq) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) buf[u] = load_stream16(wp + (size_t)(kq + u) * 64);
+        };
+        auto consume = [&](const float4 (&buf)[U], int kq) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float4 x[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) x[g] = *reinterpret_cast<const float4 *>(&sm.h1q[kq + u][4 * g + (l & 3)][0]);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].x, buf[u].x, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].y, buf[u].y, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].z, buf[u].z, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].w, buf[u].w, acc[g], 0, 0, 0);
+            }
+        };
+        issue(bufA, 0);
+#pragma nounroll
+        for (int kq = 0; kq < 128; kq += 2 * U) {
+            issue(bufB, kq + U);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(bufA, kq);
+            if (kq + 2 * U < 128) issue(bufA, kq + 2 * U);   // wave-uniform
+            __builtin_amdgcn_sched_barrier(0);
+            consume(bufB, kq + U);
+        }
+    }
+    COEVO_STAMP(3);
+    COEVO_WSTAMP(8);
+    COEVO_CSTAMP(12);
+    __syncthreads();   // every wave is done reading h1q: the tail image may overwrite it
+    // ---- fc2 results (thread = column) -> rows by wave through LDS; the output layer's weights ride along ----------
+#pragma unroll
+    for (int r = 0; r < R; ++r) sm.tail.raw2[r][t] = acc[r >> 2][r & 3];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) sm.tail.w3s[(t + 256 * j) >> 8][(t + 256 * j) & 255] = w3r[j];
+    __syncthreads();
+    // ---- LayerNorm(256) + ReLU of rows w and w + 4: lane l holds features 64 b + l, b < 4 --------------------------
+#pragma unroll
+    for (int i = 0; i < NOWN; ++i) {
+        const int r = wo + 4 * i;
+        if (r < R) {
+            float v[4], sq[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) v[b] = sm.tail.raw2[r][64 * b + l];
+            const float mean = row_blocks_total<4>(v, l) * (1.0f / H2);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { v[b] = v[b] - mean; sq[b] = v[b] * v[b]; }
+            const float rstd = 1.0f / __builtin_sqrtf(row_blocks_total<4>(sq, l) * (1.0f / H2) + LN_EPS);
+            bool bad = false;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float y = __builtin_fmaf(v[b] * rstd, p_g2[b], p_be2[b]);
+                bad = bad || bad_post_relu(y);
+                sm.tail.h2[r][64 * b + l] = relu_keep_nan(y);
+            }
+            if (r < nrows && bad) st |= COEVO_ST_BAD_FC2;
+        }
+    }
+    __syncthreads();
+    COEVO_STAMP(4);
+
+    // ---- output layer (one lane per (row, action), 256-long sequential chain out of LDS), first-max action: wave 0 ----
+    if (w == 0) {
+        if (l < R * NACT) {
+            const int r = l / NACT, o = l % NACT;
+            float y = p_b3;
+            const float4 *wr = reinterpret_cast<const float4 *>(&sm.tail.w3s[o][0]);
+            const float4 *xr = reinterpret_cast<const float4 *>(&sm.tail.h2[r][0]);
+#pragma unroll 4
+            for (int k = 0; k < H2 / 4; ++k) {
+                const float4 wv = wr[k], xv = xr[k];
+                y = __builtin_fmaf(wv.x, xv.x, y);
+                y = __builtin_fmaf(wv.y, xv.y, y);
+                y = __builtin_fmaf(wv.z, xv.z, y);
+                y = __builtin_fmaf(wv.w, xv.w, y);
+            }
+            sm.logit[r][o] = y;
+        }
+        COEVO_STAMP(5);
+        // the same wave wrote the logits: a wave-level fence orders its LDS accesses, no workgroup barrier needed
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (l < nrows) {   // strict '>' scan from -inf
+            int best = -1;
+            float cur = -__builtin_inff();
+#pragma unroll
+            for (int o = 0; o < NACT; ++o) {
+                const float v = sm.logit[l][o];
+                if (!__builtin_isfinite(v)) st |= COEVO_ST_BAD_OUT;
+                if (v > cur) { cur = v; best = o; }
+            }
+            if (best < 0) { st |= COEVO_ST_NO_ACTION; best = 0; }
+            const int row = row0 + l;
+            a.act_cur[3 * a.row_game[row] + a.row_slot[row]] = best;  // by (game, slot)
+            if (a.logits) {
+#pragma unroll
+                for (int o = 0; o < NACT; ++o) a.logits[(size_t)row * COEVO_LOGIT_STRIDE + o] = sm.logit[l][o];
+            }
         }
     }
     if (st) atomicOr(a.status, st);
@@ -1048,18 +1381,30 @@ __device__ __forceinline__ void fc_policy_mfma16_body(const FcArgs &a, FcMfma16S
 
 // The lean merged cycle launch: shared-opponent tasks of <= 16 rows (fc_policy_mfma16_body) + one per-individual net per
 // streaming workgroup, four workgroups per CU.
+#ifndef COEVO_COMPACT
+#define COEVO_COMPACT 1   // 0: the unrolled per-individual body (A/B runs)
+#endif
 template <int R>
 __global__ __launch_bounds__(256, 4) void fc_cycle16_kernel(FcArgs a)
 {
     __shared__ union Cycle16Smem {
         FcMfma16Smem heavy;
+#if COEVO_COMPACT
+        FcSmemC<R> light;
+#else
         FcSmem<R, 1> light;
+#endif
     } sm;
+    static_assert(sizeof(sm) <= 40960, "four workgroups per CU");
     stamp_begin(a.stamps);
     if ((int)blockIdx.x < a.n_heavy)  // workgroup-uniform
         fc_policy_mfma16_body<MODE_FUSED>(a, sm.heavy, a.tasks[blockIdx.x]);
     else
+#if COEVO_COMPACT
+        fc_policy_body_c<R, MODE_FUSED>(a, sm.light, a.light_tasks, (int)blockIdx.x - a.n_heavy, a.n_light);
+#else
         fc_policy_body<R, MODE_FUSED, 1>(a, sm.light, a.light_tasks, (int)blockIdx.x - a.n_heavy, a.n_light);
+#endif
     stamp_end(a.stamps);
 }
 
@@ -1231,6 +1576,12 @@ static int launch_fc(const FcArgs &a, int n_tasks, int max_rows, hipStream_t s)
 }  // namespace coevo
 
 #ifdef COEVO_PHASE_STAMPS
+extern "C" int coevo_debug_read_wave_stamps(unsigned long long *host_out, int n_words)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(coevo::g_wave_stamps), sizeof(unsigned long long) * n_words) ==
+                   hipSuccess ? 0 : -2;
+}
+
 extern "C" int coevo_debug_read_phase_stamps(unsigned long long *host_out, int n_words)
 {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(coevo::g_phase_stamps), sizeof(unsigned long long) * n_words) ==

@@ -64,3 +64,24 @@ if st[:, 14].max() > 0:   # persistent rollout kernel: the last cycle's wait
           f"body (stamp 0 -> 6) mean {np.mean(st[:, 6] - st[:, 0]) / 100.0:.1f} us")
     print("  spin exit spread (us):", round(float(st[:, 14].max() - st[:, 14].min()) / 100.0, 1),
           " body end spread:", round(float(st[:, 6].max() - st[:, 6].min()) / 100.0, 1))
+
+# per-wave stamps of the compact per-individual body: arrival at / release from each barrier of fc1 + LayerNorm(512)
+try:
+    dll.coevo_debug_read_wave_stamps.argtypes = [C.c_void_p, C.c_int]
+    wb = (C.c_ulonglong * (n * 4 * 16))()
+    assert dll.coevo_debug_read_wave_stamps(wb, n * 4 * 16) == 0
+    ws = np.frombuffer(wb, dtype=np.uint64).reshape(n, 4, 16).astype(np.int64)[light]
+    ws = (ws - st[light][:, None, 0:1]) / 100.0       # us since the workgroup's start
+    names = ["arrive B0 (params, obs)", "leave B0", "arrive B1 (loop1 sums)", "leave B1", "arrive B2 (loop2)", "leave B2",
+             "arrive B3 (loop3)", "leave B3", "stream done"]
+    for i, nm in enumerate(names):
+        v = ws[:, :, i]
+        print(f"  {nm:26s} mean {v.mean():6.2f}  first wave {v.min(axis=1).mean():6.2f}  last wave {v.max(axis=1).mean():6.2f}  per wave {np.round(v.mean(axis=0), 2)}")
+    raw = np.frombuffer(wb, dtype=np.uint64).reshape(n, 4, 16).astype(np.int64)[light]
+    for nm, (c0, c1, r0, r1) in (("fc1+LN1 section", (10, 11, 1, 2)), ("section + stream", (10, 12, 1, 8))):
+        dc = raw[:, :, c1] - raw[:, :, c0]
+        dr = (raw[:, :, r1] - raw[:, :, r0]) / 100.0
+        print(f"  {nm}: shader cycles per wave {np.round(dc.mean(axis=0))}, us {np.round(dr.mean(axis=0), 2)}, "
+              f"effective clock {dc.sum() / dr.sum():.0f} MHz")
+except Exception as e:
+    print("no wave stamps:", e)
