@@ -99,6 +99,84 @@ __device__ inline float wave_tree_sum(float v)
     return __uint_as_float(s[0]) + __uint_as_float(s[1]);
 }
 
+// ---- packed butterfly: the canonical Reduce for a ROW held by ONE wave ----------------------------------------------
+// true lane-xor exchanges (the packed butterfly needs partners that agree in the lower lane bits)
+__device__ __forceinline__ float lane_xor4(float v)
+{
+    int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xf, 0x5, false);   // row_shl:4 -> lanes 0-3, 8-11
+    x = __builtin_amdgcn_update_dpp(x, __float_as_int(v), 0x114, 0xf, 0xa, false);       // row_shr:4 -> lanes 4-7, 12-15
+    return __int_as_float(x);
+}
+__device__ __forceinline__ float add_xor16(float v)
+{
+    typedef unsigned u32x2_h __attribute__((ext_vector_type(2)));
+    const u32x2_h s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+__device__ __forceinline__ float add_xor32(float v)
+{
+    typedef unsigned u32x2_h __attribute__((ext_vector_type(2)));
+    const u32x2_h s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+
+// Reduce(NB * 64) for one row held by one wave: v[b] = the lane's element of block b (lane l = position l of the block).
+// Per block the balanced tree lane xor 1, 2, 4, 8, 16, 32; then the block sums left to right.  After level m the 2m lanes
+// of a group hold the same value, so two blocks share a register from there on (a lane bit selects the block): 30
+// instructions for eight blocks instead of 88.  NB = 1..8.
+template <int NB>
+__device__ __forceinline__ float row_blocks_total(const float (&v)[NB], int l)
+{
+    static_assert(NB >= 1 && NB <= 8, "up to eight 64-wide blocks");
+    constexpr int PB = NB <= 1 ? 1 : NB <= 2 ? 2 : NB <= 4 ? 4 : 8;   // blocks padded to a power of two (zeros)
+    float x[PB];
+#pragma unroll
+    for (int b = 0; b < PB; ++b) x[b] = (b < NB) ? v[b] : 0.0f;
+    // level 1 (xor 1), then pack pairs by lane bit 0
+    float p[(PB + 1) / 2];
+#pragma unroll
+    for (int j = 0; j < (PB + 1) / 2; ++j) {
+        const float a = x[2 * j] + dpp_move<0xB1>(x[2 * j]);
+        if constexpr (PB >= 2) {
+            const float b = x[2 * j + 1] + dpp_move<0xB1>(x[2 * j + 1]);
+            p[j] = (l & 1) ? b : a;
+        } else {
+            p[j] = a;
+        }
+    }
+    // level 2 (xor 2), pack by lane bit 1
+    float q[(PB + 3) / 4];
+#pragma unroll
+    for (int j = 0; j < (PB + 3) / 4; ++j) {
+        const float a = p[2 * j < (PB + 1) / 2 ? 2 * j : 0] + dpp_move<0x4E>(p[2 * j < (PB + 1) / 2 ? 2 * j : 0]);
+        if constexpr (PB >= 4) {
+            const float b = p[2 * j + 1] + dpp_move<0x4E>(p[2 * j + 1]);
+            q[j] = (l & 2) ? b : a;
+        } else {
+            q[j] = a;
+        }
+    }
+    // level 3 (xor 4), pack by lane bit 2
+    float s;
+    {
+        const float a = q[0] + lane_xor4(q[0]);
+        if constexpr (PB >= 8) {
+            const float b = q[1] + lane_xor4(q[1]);
+            s = (l & 4) ? b : a;
+        } else {
+            s = a;
+        }
+    }
+    s = s + dpp_move<0x128>(s);   // xor 8: row_ror:8
+    s = add_xor16(s);
+    s = add_xor32(s);
+    // lane j (j < NB) holds the total of block j
+    float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 0));
+#pragma unroll
+    for (int b = 1; b < NB; ++b) tot = tot + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), b));
+    return tot;
+}
+
 // ---- MPE observation element k of env slot `slot` from the fp64 struct-of-arrays game state -------------------
 // (PettingZoo simple_adversary.observation + SimpleEnv.observe's float32 cast; field indices in mpe_env.hip)
 __device__ inline float mpe_obs_element(const double *st, int n, int g, int slot, int k)

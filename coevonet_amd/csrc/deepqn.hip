@@ -4,11 +4,11 @@
 // per-sample, per-channel statistics over the spatial positions: batching must not mix samples.
 //
 // Three launches per env step:
-//   dqn_conv_kernel   one workgroup per frame: the uint8 HWC frame is staged in LDS once (coalesced 16-byte loads),
-//                     /255 through a 256-entry LDS table (exact fp32 quotients), the three convolutions run as implicit
-//                     GEMMs on v_mfma_f32_32x32x2_f32 (A = im2col gather out of LDS, B = weights [tap][cout] from L2),
-//                     BN statistics are reduced in the accumulator layout in the canonical tree order, activations stay
-//                     in LDS between layers; conv3's output goes to HBM as act[row][3136].
+//   dqn_conv_kernel   one workgroup (8 waves) per frame: the uint8 HWC frame is staged in LDS once (coalesced 16-byte
+//                     loads), /255 through a 256-entry LDS table (exact fp32 quotients), the three convolutions run as
+//                     implicit GEMMs on v_mfma_f32_16x16x4_f32 (A = im2col gather out of LDS, B = weights [tap][cout]
+//                     from L2), BatchNorm statistics are reduced channel by channel in the canonical tree order by packed
+//                     butterflies, activations stay in LDS between layers; conv3's output goes to HBM as act[row][3136].
 //   dqn_fc1_kernel    the 6.4 MB fc1 matrix of each net is streamed exactly once per task (<= 16 rows): a grouped GEMV
 //                     like fc2 of the MPE net, [8][784][64][4] tiling, lane = output, rows in groups of four on
 //                     v_mfma_f32_4x4x1_16B_f32 with the activations of a chunk staged in LDS.
@@ -19,8 +19,6 @@
 
 namespace coevo {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void dqn_pack_kernel(const float *flat, float *slab, int C, int n)
 {
@@ -33,172 +31,192 @@ __global__ __launch_bounds__(256) void dqn_pack_kernel(const float *flat, float 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// canonical sum over the 64 positions of one block, per output channel, from two 32x32 accumulator tiles.
-// position inside the block: i = 32*mt + (reg&3) + 8*(reg>>2) + 4*(lane>>5); tree = i xor 1, 2, 4, 8, 16, 32.
-__device__ inline float block_tree_from_acc(const f32x16 &t0, const f32x16 &t1)
+// One conv layer of one frame as an implicit GEMM on v_mfma_f32_16x16x4_f32 (bit-identical to the sequential-k fmaf chain
+// from the bias: tools/mfma16_chain_probe.hip; taps in the canonical (ci, ky, kx) order).  M = output positions in tiles
+// of 16, N = output channels in pairs of 16-wide tiles, K = taps, four per instruction.  A unit = (position tile, channel
+// tile pair): one LDS gather per lane feeds two MFMAs.  Unit u = w + 8 i belongs to wave w (8 waves, two per SIMD: one
+// wave's gathers hide behind the other's MFMAs), so all units of a wave share their channel pair and the pair's weight
+// operands are loaded once per k-step (8 k-steps ahead, from L2: the 16 frames of a task and every task of the same net
+// read the same 0.3 MB).  Tile padding: 400 = 25 x 16 positions (0 %), 81 -> 96 (16 %), 49 -> 64 (23 %); the 32 x 32 tiles
+// this replaces padded 400 -> 512, 81 -> 128, 49 -> 64 and left half of the waves idle in conv3.
+//   operands of one MFMA: lane (c = l % 16, kk = l / 16): A[position c of the tile][tap 4 q + kk], B[tap 4 q + kk][channel c];
+//   accumulator register r of lane (c, g = l / 16): position 4 g + r of the tile, channel c.
+// The raw sums go to LDS as out[channel][position] (odd pitch); BatchNorm + ReLU then runs over them channel by channel.
+typedef float f32x4_acc __attribute__((ext_vector_type(4)));
+
+// tap t = (ci, ky, kx) in the canonical order -> offset of that input element relative to the window's corner.  conv1 and
+// conv2 have power-of-two windows (shifts); conv3's 3 x 3 comes from a compile-time table in global memory (L1-resident,
+// requested a chunk ahead like the weights) - an LDS table would cost the 2.3 KB that keep two workgroups on a CU.
+struct Tap3Table { int v[576]; };
+constexpr Tap3Table make_tap3()
 {
-    float s[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const f32x16 &v = mt ? t1 : t0;
-        float a[8], b[4];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) a[q] = v[2 * q] + v[2 * q + 1];            // xor 1: reg bit 0
-#pragma unroll
-        for (int q = 0; q < 4; ++q) b[q] = a[2 * q] + a[2 * q + 1];            // xor 2: reg bit 1
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {                                          // xor 4: lane half
-            const u32x2 x = __builtin_amdgcn_permlane32_swap(__float_as_uint(b[q]), __float_as_uint(b[q]), false, false);
-            b[q] = __uint_as_float(x[0]) + __uint_as_float(x[1]);
-        }
-        s[mt] = (b[0] + b[1]) + (b[2] + b[3]);                                  // xor 8, 16: reg bits 2, 3
-    }
-    return s[0] + s[1];                                                         // xor 32: the two row tiles
+    Tap3Table t{};
+    for (int i = 0; i < 576; ++i) t.v[i] = (i / 9) * 81 + ((i % 9) / 3) * 9 + (i % 3);   // ci * DQ_P2 + ky * 9 + kx
+    return t;
+}
+__device__ const Tap3Table g_tap3 = make_tap3();
+
+template <int KS, int HIN, bool U8IN, int IN_PITCH>
+__device__ __forceinline__ int tap_offset(int t, int cin)
+{
+    if constexpr (KS == 8) return U8IN ? (((t >> 3) & 7) * HIN + (t & 7)) * cin + (t >> 6) : (t >> 6) * IN_PITCH + ((t >> 3) & 7) * HIN + (t & 7);
+    else if constexpr (KS == 4) return (t >> 4) * IN_PITCH + ((t >> 2) & 3) * HIN + (t & 3);
+    else return g_tap3.v[t];
 }
 
-struct ConvGeom { int cin, ks, stride, hin, hout, cout; };
-
-// One conv + BN(train, batch 1) + ReLU layer of one frame on the matrix cores.
-//   UNITS_PER_WAVE: (position block, column tile) work units a wave owns (conv1: 2, conv2/3: 1); unit u of wave w is
-//   global unit w + 4*u; unit -> (block = unit / NT, nt = unit % NT).
-template <int TAPS_MAX, int KS, int STRIDE, int HIN, int HOUT, int COUT, int UNITS, bool U8IN>
-__device__ inline void conv_bn_relu_mfma(const void *in_lds, const float *lut, int cin, const float *wt,
-                                         const float *bias, const float *gamma, const float *beta, float *out,
-                                         float *red, int w, int l)
+template <int KS, int STRIDE, int HIN, int HOUT, int COUT, bool U8IN, int IN_PITCH, int OUT_PITCH>
+__device__ __forceinline__ void conv16_mfma(const void *in_lds, const float *lut, int cin, int taps, const float *wt,
+                                            const float *bias, float *out, int w, int l)
 {
-    constexpr int NPOS = HOUT * HOUT, NBLK = (NPOS + 63) / 64, NT = COUT / 32, NUNIT = NBLK * NT;
-    const int lc = l & 31, lh = l >> 5;
-    const int taps = cin * KS * KS;
-    f32x16 acc[UNITS][2];
-    int base[UNITS][2];
-    bool live[UNITS];
+    static_assert(KS != 3 || (IN_PITCH == 81 && HIN == 9 && !U8IN), "g_tap3 is conv3's table");
+    constexpr int NPOS = HOUT * HOUT, NM = (NPOS + 15) / 16, NP = COUT / 32, NUNITS = NM * NP, MAXU = (NUNITS + 7) / 8;
+    static_assert(8 % NP == 0, "all units of a wave share their channel pair");
+    const int c = l & 15, kk = l >> 4, np = w % NP;
+    f32x4_acc acc[MAXU][2];
+    int base[MAXU];
+    bool live[MAXU];
 #pragma unroll
-    for (int u = 0; u < UNITS; ++u) {
-        const int unit = w + 4 * u;
-        live[u] = unit < NUNIT;
-        const int blk = unit / NT, nt = unit % NT;
-        const float bb = live[u] ? bias[32 * nt + lc] : 0.0f;
+    for (int i = 0; i < MAXU; ++i) {
+        const int u = w + 8 * i;
+        live[i] = u < NUNITS;
+        int p = 16 * (u / NP) + c;
+        if (!live[i] || p >= NPOS) p = 0;   // padded rows read position 0; their results are never stored
+        const int oy = p / HOUT, ox = p % HOUT;
+        base[i] = U8IN ? ((oy * STRIDE) * HIN + ox * STRIDE) * cin : (oy * STRIDE) * HIN + ox * STRIDE;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            int p = 64 * blk + 32 * mt + lc;
-            if (!live[u] || p >= NPOS) p = 0;  // padded rows read position 0 and are masked out of every result
-            const int oy = p / HOUT, ox = p % HOUT;
-            base[u][mt] = U8IN ? ((oy * STRIDE) * HIN + ox * STRIDE) * cin : (oy * STRIDE) * HIN + ox * STRIDE;
+        for (int h = 0; h < 2; ++h) {
+            const float bb = bias[32 * np + 16 * h + c];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[u][mt][r] = bb;
+            for (int r = 0; r < 4; ++r) acc[i][h][r] = bb;
         }
     }
-    // all units of one wave share the column tile when NT == 1 (conv1); otherwise a wave has a single unit
-    const int nt0 = (w % NT);
-    // taps in chunks of 8 k-pairs (all tap counts are multiples of 16): the chunk's 8 weight operands are requested
-    // first (8 independent L2 loads in flight), then 8 x (im2col gather out of LDS, MFMAs)
-    for (int t0 = 0; t0 < taps; t0 += 16) {
-        float bv[8];
+    const float *wcol = wt + 32 * np + c;
+    constexpr int QU = 8;   // k-steps per chunk: their weight operands and tap offsets are requested together, one chunk
+                            // AHEAD of the MFMAs that use them (an L2 round trip per chunk would otherwise be exposed:
+                            // conv2 / conv3 have only one or two units per wave to hide it behind)
+    float bvA[QU][2], bvB[QU][2];
+    int toA[QU], toB[QU];
+    auto issue = [&](float (&bv)[QU][2], int (&to)[QU], int q0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bv[j] = wt[(size_t)(t0 + 2 * j + lh) * COUT + 32 * nt0 + lc];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int t = t0 + 2 * j + lh;
-            const int ci = t / (KS * KS), rem = t % (KS * KS), ky = rem / KS, kx = rem % KS;
-            const int toff = U8IN ? (ky * HIN + kx) * cin + ci : (ci * HIN + ky) * HIN + kx;
-#pragma unroll
-            for (int u = 0; u < UNITS; ++u) {
-                if (!live[u]) continue;  // wave-uniform
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    float av;
-                    if constexpr (U8IN) av = lut[static_cast<const unsigned char *>(in_lds)[base[u][mt] + toff]];
-                    else av = static_cast<const float *>(in_lds)[base[u][mt] + toff];
-                    acc[u][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[u][mt], 0, 0, 0);
-                }
-            }
+        for (int j = 0; j < QU; ++j) {
+            const int t = 4 * (q0 + j) + kk;
+            bv[j][0] = wcol[(size_t)t * COUT];
+            bv[j][1] = wcol[(size_t)t * COUT + 16];
+            to[j] = tap_offset<KS, HIN, U8IN, IN_PITCH>(t, cin);
         }
-    }
-    // ---- BatchNorm statistics: canonical block sums -> LDS -> blocks left to right ------------------------------
-    auto masked = [&](int u, int mt, int r) {
-        const int unit = w + 4 * u, blk = unit / NT;
-        const int p = 64 * blk + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        return p < NPOS;
     };
-    for (int pass = 0; pass < 2; ++pass) {
+    auto consume = [&](const float (&bv)[QU][2], const int (&to)[QU]) {
 #pragma unroll
-        for (int u = 0; u < UNITS; ++u) {
-            if (!live[u]) continue;
-            const int unit = w + 4 * u, blk = unit / NT, nt = unit % NT;
-            f32x16 v0, v1;
+        for (int j = 0; j < QU; ++j) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float x0 = acc[u][0][r], x1 = acc[u][1][r];
-                v0[r] = masked(u, 0, r) ? (pass ? x0 * x0 : x0) : 0.0f;
-                v1[r] = masked(u, 1, r) ? (pass ? x1 * x1 : x1) : 0.0f;
-            }
-            const float s = block_tree_from_acc(v0, v1);
-            if (lh == 0) red[(nt * 8 + blk) * 32 + lc] = s;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < UNITS; ++u) {
-            if (!live[u]) continue;
-            const int unit = w + 4 * u, nt = unit % NT;
-            float tot = red[(nt * 8 + 0) * 32 + lc];
-            for (int b = 1; b < NBLK; ++b) tot = tot + red[(nt * 8 + b) * 32 + lc];
-            const float stat = tot / (float)NPOS;
-            if (pass == 0) {
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[u][mt][r] = acc[u][mt][r] - stat;
-            } else {
-                const int blk = unit / NT;
-                const float rstd = 1.0f / __builtin_sqrtf(stat + LN_EPS);
-                const float ga = gamma[32 * nt + lc], be = beta[32 * nt + lc];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int p = 64 * blk + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (p < NPOS) {
-                            const float y = __builtin_fmaf(acc[u][mt][r] * rstd, ga, be);
-                            out[(size_t)(32 * nt + lc) * NPOS + p] = relu_keep_nan(y);
-                        }
-                    }
+            for (int i = 0; i < MAXU; ++i) {
+                if (!live[i]) continue;   // wave-uniform
+                float av;
+                if constexpr (U8IN) av = lut[static_cast<const unsigned char *>(in_lds)[base[i] + to[j]]];
+                else av = static_cast<const float *>(in_lds)[base[i] + to[j]];
+                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j][0], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j][1], acc[i][1], 0, 0, 0);
             }
         }
-        __syncthreads();
+    };
+    const int nq = taps / 4;   // a multiple of 2 * QU for every layer (C * 16, 128, 144)
+    issue(bvA, toA, 0);
+    for (int q0 = 0; q0 < nq; q0 += 2 * QU) {
+        issue(bvB, toB, q0 + QU);
+        consume(bvA, toA);
+        if (q0 + 2 * QU < nq) issue(bvA, toA, q0 + 2 * QU);
+        consume(bvB, toB);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+        if (!live[i]) continue;
+        const int m = (w + 8 * i) / NP;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = 16 * m + 4 * kk + r;
+                if (p < NPOS) out[(32 * np + 16 * h + c) * OUT_PITCH + p] = acc[i][h][r];
+            }
     }
 }
 
+// BatchNorm in training mode at batch 1 (per-sample, per-channel statistics over the NPOS positions) + ReLU, in place on
+// x[channel][position] in LDS.  A channel belongs to one wave: lane l holds positions 64 b + l, the canonical Reduce
+// (64-wide blocks, zero padded, tree inside, blocks left to right) is one packed butterfly (coevo_common.hip.h).
+// mean = S / N, var = S2 / N (biased), rstd = 1 / sqrtf(var + 1e-5f), y = fmaf(d * rstd, gamma, beta).
+template <int NPOS, int PITCH, int COUT>
+__device__ __forceinline__ void bn_relu_rows(float *x, const float *gamma, const float *beta, int w, int l)
+{
+    constexpr int NB = (NPOS + 63) / 64;
+    for (int ch = w; ch < COUT; ch += 8) {
+        float *row = x + ch * PITCH;
+        float v[NB], sq[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) v[b] = (64 * b + l < NPOS) ? row[64 * b + l] : 0.0f;
+        const float mean = row_blocks_total<NB>(v, l) / (float)NPOS;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            v[b] = v[b] - mean;
+            sq[b] = (64 * b + l < NPOS) ? v[b] * v[b] : 0.0f;
+        }
+        const float var = row_blocks_total<NB>(sq, l) / (float)NPOS;
+        const float rstd = 1.0f / __builtin_sqrtf(var + LN_EPS);
+        const float ga = gamma[ch], be = beta[ch];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            if (64 * b + l < NPOS) row[64 * b + l] = relu_keep_nan(__builtin_fmaf(v[b] * rstd, ga, be));
+    }
+}
+
+constexpr int DQ_P1 = 401, DQ_P2 = 81, DQ_P3 = 49;   // channel pitches of the activation images (odd: conflict-free columns)
+
+template <int CMAX>
 struct DqnSmem {
     float lut[256];
-    float a1[32 * 400];
-    float a2[64 * 81];
-    float red[2 * 8 * 32];
-    unsigned char frame[84 * 84 * 6 + 16];
+    float a1[32 * DQ_P1];                          // conv1 activations; later conv3's [64][49]
+    union {
+        unsigned char frame[84 * 84 * CMAX + 16];  // the uint8 HWC frame (dead after conv1)
+        float a2[64 * DQ_P2];                      // conv2 activations
+    };
 };
+static_assert(sizeof(DqnSmem<4>) <= 81920, "84x84x4 frames: two workgroups per CU");
 
-__global__ __launch_bounds__(256) void dqn_conv_kernel(const float *slab, const coevo_dqn_task *tasks, int C,
-                                                        int n_actions, const uint8_t *frames, float *act)
+// CMAX = 4: up to four channels, 80.6 KB of LDS = two workgroups (16 waves) per CU: one frame's barriers, BatchNorm passes
+// and staging hide behind the other's MFMAs; CMAX = 6 (the reference's wrapper stack would yield 6 channels): one per CU
+template <int CMAX>
+__global__ __launch_bounds__(512, 2) void dqn_conv_kernel(const float *slab, const coevo_dqn_task *tasks, int C,
+                                                           int n_actions, const uint8_t *frames, float *act)
 {
-    __shared__ __attribute__((aligned(16))) DqnSmem sm;
+    __shared__ __attribute__((aligned(16))) DqnSmem<CMAX> sm;
     const coevo_dqn_task task = tasks[blockIdx.x];
     if ((int)blockIdx.y >= task.n_rows) return;
     const int row = task.row_begin + blockIdx.y;
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
     const float *net = slab + task.net_off;
     const DqnLayout L = dqn_layout(C, n_actions);
-    // stage the frame (84*84*C bytes, a multiple of 16) and the /255 table
+    // stage the frame (84*84*C bytes, a multiple of 16) and the /255 table (exact fp32 quotients)
     const int nbytes = 84 * 84 * C;
     const uint4 *src = reinterpret_cast<const uint4 *>(frames + (size_t)row * nbytes);
     uint4 *dst = reinterpret_cast<uint4 *>(sm.frame);
-    for (int i = t; i < nbytes / 16; i += 256) dst[i] = src[i];
-    sm.lut[t] = (float)t / 255.0f;
+    for (int i = t; i < nbytes / 16; i += 512) dst[i] = src[i];
+    if (t < 256) sm.lut[t] = (float)t / 255.0f;
     __syncthreads();
-    conv_bn_relu_mfma<384, 8, 4, 84, 20, 32, 2, true>(sm.frame, sm.lut, C, net + L.w1, net + L.b1, net + L.b1 + 32,
-                                                      net + L.b1 + 64, sm.a1, sm.red, w, l);
-    conv_bn_relu_mfma<512, 4, 2, 20, 9, 64, 1, false>(sm.a1, nullptr, 32, net + L.w2, net + L.b2, net + L.b2 + 64,
-                                                      net + L.b2 + 128, sm.a2, sm.red, w, l);
-    conv_bn_relu_mfma<576, 3, 1, 9, 7, 64, 1, false>(sm.a2, nullptr, 64, net + L.w3, net + L.b3, net + L.b3 + 64,
-                                                     net + L.b3 + 128, act + (size_t)row * DQ_FC1_IN, sm.red, w, l);
+    conv16_mfma<8, 4, 84, 20, 32, true, 0, DQ_P1>(sm.frame, sm.lut, C, C * 64, net + L.w1, net + L.b1, sm.a1, w, l);
+    __syncthreads();
+    bn_relu_rows<400, DQ_P1, 32>(sm.a1, net + L.b1 + 32, net + L.b1 + 64, w, l);
+    __syncthreads();
+    conv16_mfma<4, 2, 20, 9, 64, false, DQ_P1, DQ_P2>(sm.a1, nullptr, 32, 512, net + L.w2, net + L.b2, sm.a2, w, l);
+    __syncthreads();
+    bn_relu_rows<81, DQ_P2, 64>(sm.a2, net + L.b2 + 64, net + L.b2 + 128, w, l);
+    __syncthreads();
+    conv16_mfma<3, 1, 9, 7, 64, false, DQ_P2, DQ_P3>(sm.a2, nullptr, 64, 576, net + L.w3, net + L.b3, sm.a1, w, l);
+    __syncthreads();
+    bn_relu_rows<49, DQ_P3, 64>(sm.a1, net + L.b3 + 64, net + L.b3 + 128, w, l);
+    __syncthreads();
+    // flatten in CHW order (Atari/deepqn.py:45): channel pitch 49 = the flat layout itself
+    float *dsta = act + (size_t)row * DQ_FC1_IN;
+    for (int i = t; i < DQ_FC1_IN; i += 512) dsta[i] = sm.a1[i];
 }
 
 // fc1 + ReLU: grid (task, 8), ONE wavefront per workgroup: it owns outputs [64*ob, +64) and streams their 802 KB
@@ -360,8 +378,12 @@ extern "C" int coevo_dqn_forward_argmax_timed(const float *slab, const coevo_dqn
     float *hid = act + (size_t)n_rows_total * DQ_FC1_IN;
     hipStream_t s = (hipStream_t)stream;
     if (timing_ctx && coevo_timing_begin(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
-    hipLaunchKernelGGL(dqn_conv_kernel, dim3(n_tasks, max_rows_per_task), dim3(256), 0, s, slab, tasks, C, n_actions,
-                       frames, act);
+    if (C <= 4)
+        hipLaunchKernelGGL(dqn_conv_kernel<4>, dim3(n_tasks, max_rows_per_task), dim3(512), 0, s, slab, tasks, C,
+                           n_actions, frames, act);
+    else
+        hipLaunchKernelGGL(dqn_conv_kernel<6>, dim3(n_tasks, max_rows_per_task), dim3(512), 0, s, slab, tasks, C,
+                           n_actions, frames, act);
     if (timing_ctx && coevo_timing_end(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     const dim3 g1(n_tasks, 8), b1(64);
     switch ((max_rows_per_task + 3) / 4) {

@@ -476,62 +476,6 @@ struct FcSmemC {
     float logit[R][COEVO_LOGIT_STRIDE];
 };
 
-// true lane-xor exchanges (the packed butterfly needs partners that agree in the lower lane bits)
-__device__ __forceinline__ float lane_xor4(float v)
-{
-    int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xf, 0x5, false);   // row_shl:4 -> lanes 0-3, 8-11
-    x = __builtin_amdgcn_update_dpp(x, __float_as_int(v), 0x114, 0xf, 0xa, false);       // row_shr:4 -> lanes 4-7, 12-15
-    return __int_as_float(x);
-}
-__device__ __forceinline__ float add_xor16(float v)
-{
-    typedef unsigned u32x2_h __attribute__((ext_vector_type(2)));
-    const u32x2_h s = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
-}
-__device__ __forceinline__ float add_xor32(float v)
-{
-    typedef unsigned u32x2_h __attribute__((ext_vector_type(2)));
-    const u32x2_h s = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
-}
-
-// Reduce(NB * 64) of the canonical arithmetic for one row held by one wave: v[b] = the lane's element of block b.
-// Per block the balanced tree lane xor 1, 2, 4, 8, 16, 32; then the block sums left to right.  After level m the 2m lanes
-// of a group hold the same value, so two blocks share a register from there on (lane bit selects the block).
-template <int NB>
-__device__ __forceinline__ float row_blocks_total(const float (&v)[NB], int l)
-{
-    static_assert(NB == 8 || NB == 4, "LayerNorm(512) / LayerNorm(256)");
-    float p[NB / 2];
-#pragma unroll
-    for (int j = 0; j < NB / 2; ++j) {
-        const float a = v[2 * j] + dpp_move<0xB1>(v[2 * j]), b = v[2 * j + 1] + dpp_move<0xB1>(v[2 * j + 1]);   // xor 1
-        p[j] = (l & 1) ? b : a;
-    }
-    float q[NB / 4];
-#pragma unroll
-    for (int j = 0; j < NB / 4; ++j) {
-        const float a = p[2 * j] + dpp_move<0x4E>(p[2 * j]), b = p[2 * j + 1] + dpp_move<0x4E>(p[2 * j + 1]);   // xor 2
-        q[j] = (l & 2) ? b : a;
-    }
-    float s;
-    if constexpr (NB == 8) {
-        const float a = q[0] + lane_xor4(q[0]), b = q[1] + lane_xor4(q[1]);                                      // xor 4
-        s = (l & 4) ? b : a;
-    } else {
-        s = q[0] + lane_xor4(q[0]);
-    }
-    s = s + dpp_move<0x128>(s);   // xor 8: row_ror:8
-    s = add_xor16(s);
-    s = add_xor32(s);
-    // lane j (j < NB) holds the total of block j
-    float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 0));
-#pragma unroll
-    for (int b = 1; b < NB; ++b) tot = tot + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), b));
-    return tot;
-}
-
 template <int R, int MODE>
 __device__ __forceinline__ void fc_policy_body_c(const FcArgs &a, FcSmemC<R> &sm, const coevo_fc_task *tasks, int first,
                                                  int n_tasks)
