@@ -184,14 +184,24 @@ static_assert(sizeof(DqnSmem<4>) <= 81920, "84x84x4 frames: two workgroups per C
 
 // CMAX = 4: up to four channels, 80.6 KB of LDS = two workgroups (16 waves) per CU: one frame's barriers, BatchNorm passes
 // and staging hide behind the other's MFMAs; CMAX = 6 (the reference's wrapper stack would yield 6 channels): one per CU
+// the task that holds row `row`: the tasks partition the rows in ascending row_begin order (include/coevo.h)
+__device__ __forceinline__ int task_of_row(const coevo_dqn_task *tasks, int n_tasks, int row)
+{
+    int lo = 0, hi = n_tasks - 1;
+    while (lo < hi) {   // workgroup-uniform: scalar loads
+        const int mid = (lo + hi + 1) >> 1;
+        if (tasks[mid].row_begin <= row) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
 template <int CMAX>
-__global__ __launch_bounds__(512, 2) void dqn_conv_kernel(const float *slab, const coevo_dqn_task *tasks, int C,
-                                                           int n_actions, const uint8_t *frames, float *act)
+__global__ __launch_bounds__(512, 2) void dqn_conv_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks,
+                                                           int C, int n_actions, const uint8_t *frames, float *act)
 {
     __shared__ __attribute__((aligned(16))) DqnSmem<CMAX> sm;
-    const coevo_dqn_task task = tasks[blockIdx.x];
-    if ((int)blockIdx.y >= task.n_rows) return;
-    const int row = task.row_begin + blockIdx.y;
+    const int row = blockIdx.x;   // one workgroup per frame; its task by binary search (tasks ascend in row_begin)
+    const coevo_dqn_task task = tasks[task_of_row(tasks, n_tasks, row)];
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
     const float *net = slab + task.net_off;
     const DqnLayout L = dqn_layout(C, n_actions);
@@ -224,25 +234,21 @@ __global__ __launch_bounds__(512, 2) void dqn_conv_kernel(const float *slab, con
 // memory-level parallelism has to come from depth).  The activations of a chunk (rows x 28 k-quads) are staged in LDS
 // with coalesced loads and read back as broadcasts (scalar loads of them serialise: 12 500 dependent s_loads per wave).
 constexpr int DQ_RMAX = 16;
-template <int NG>  // row groups of four the launch provides for (max rows per task rounded up)
-__global__ __launch_bounds__(64) void dqn_fc1_kernel(const float *slab, const coevo_dqn_task *tasks, int C,
-                                                      int n_actions, const float *act, float *hid)
+// NG = row groups of four this task needs (ceil(rows / 4)): a one-frame task (Co-ES) issues a quarter of a 16-frame task's
+// MFMAs.  One launch serves tasks of every size: the kernel picks the instantiation by the task's own row count.
+template <int NG>
+__device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &L, const coevo_dqn_task &task,
+                                             const float *act, float *hid, float (*xs)[28 * 4], int ob, int l)
 {
     constexpr int U = 28;  // k-quads per chunk; 784 = 28 * 28
-    __shared__ __attribute__((aligned(16))) float xs[DQ_RMAX][U * 4];
-    const coevo_dqn_task task = tasks[blockIdx.x];
-    const int l = threadIdx.x;
-    const int ob = blockIdx.y;
-    const float *net = slab + task.net_off;
-    const DqnLayout L = dqn_layout(C, n_actions);
     const int nrows = task.n_rows;
     const float bb = net[L.bf + 64 * ob + l];
     // rows in groups of four on v_mfma_f32_4x4x1_16B_f32 (16 blocks x 4 columns = the wave's 64 outputs, one k per
     // instruction; bit-identical to the fmaf chain, tools/mfma4_chain_probe.hip): the lane's streamed 16-byte piece is
     // the B operand as is, the A operand x[4g + l%4][4q..4q+3] is one ds_read_b128 per group.  (As VALU FMAs fed by one
     // LDS broadcast per row this kernel ran at 1.4 TB/s.)
-    typedef float f32x4_acc __attribute__((ext_vector_type(4)));
-    f32x4_acc acc[NG];
+    typedef float f32x4_acc1 __attribute__((ext_vector_type(4)));
+    f32x4_acc1 acc[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -298,15 +304,34 @@ __global__ __launch_bounds__(64) void dqn_fc1_kernel(const float *slab, const co
                 hid[(size_t)(task.row_begin + 4 * g + i) * DQ_FC1_OUT + 64 * ob + l] = relu_keep_nan(acc[g][i]);
 }
 
+// fc1 + ReLU: grid (task, 8), ONE wavefront per workgroup: it owns outputs [64*ob, +64) and streams their 802 KB
+// ([784][64][4] tile) exactly once for the task's <= 16 rows, 28 KiB in flight (only 8 wavefronts exist per net, so the
+// memory-level parallelism has to come from depth).  The activations of a chunk (rows x 28 k-quads) are staged in LDS
+// with coalesced loads and read back as broadcasts (scalar loads of them serialise: 12 500 dependent s_loads per wave).
+__global__ __launch_bounds__(64) void dqn_fc1_kernel(const float *slab, const coevo_dqn_task *tasks, int C,
+                                                      int n_actions, const float *act, float *hid)
+{
+    __shared__ __attribute__((aligned(16))) float xs[DQ_RMAX][28 * 4];
+    const coevo_dqn_task task = tasks[blockIdx.x];
+    const float *net = slab + task.net_off;
+    const DqnLayout L = dqn_layout(C, n_actions);
+    const int ob = blockIdx.y, l = threadIdx.x;
+    switch ((task.n_rows + 3) >> 2) {   // workgroup-uniform
+    case 1: dqn_fc1_body<1>(net, L, task, act, hid, xs, ob, l); break;
+    case 2: dqn_fc1_body<2>(net, L, task, act, hid, xs, ob, l); break;
+    case 3: dqn_fc1_body<3>(net, L, task, act, hid, xs, ob, l); break;
+    default: dqn_fc1_body<4>(net, L, task, act, hid, xs, ob, l); break;
+    }
+}
+
 // output layer + first-max action: one 64-thread workgroup per (task, row)
-__global__ __launch_bounds__(64) void dqn_out_kernel(const float *slab, const coevo_dqn_task *tasks, int C,
+__global__ __launch_bounds__(64) void dqn_out_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int C,
                                                       int n_actions, const float *hid, int32_t *actions,
                                                       float *logits, int32_t *status)
 {
     __shared__ float lg[64];
-    const coevo_dqn_task task = tasks[blockIdx.x];
-    if ((int)blockIdx.y >= task.n_rows) return;
-    const int row = task.row_begin + blockIdx.y, o = threadIdx.x;
+    const int row = blockIdx.x, o = threadIdx.x;
+    const coevo_dqn_task task = tasks[task_of_row(tasks, n_tasks, row)];
     const float *net = slab + task.net_off;
     const DqnLayout L = dqn_layout(C, n_actions);
     if (o < n_actions) {
@@ -379,20 +404,14 @@ extern "C" int coevo_dqn_forward_argmax_timed(const float *slab, const coevo_dqn
     hipStream_t s = (hipStream_t)stream;
     if (timing_ctx && coevo_timing_begin(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     if (C <= 4)
-        hipLaunchKernelGGL(dqn_conv_kernel<4>, dim3(n_tasks, max_rows_per_task), dim3(512), 0, s, slab, tasks, C,
-                           n_actions, frames, act);
+        hipLaunchKernelGGL(dqn_conv_kernel<4>, dim3(n_rows_total), dim3(512), 0, s, slab, tasks, n_tasks, C, n_actions,
+                           frames, act);
     else
-        hipLaunchKernelGGL(dqn_conv_kernel<6>, dim3(n_tasks, max_rows_per_task), dim3(512), 0, s, slab, tasks, C,
-                           n_actions, frames, act);
+        hipLaunchKernelGGL(dqn_conv_kernel<6>, dim3(n_rows_total), dim3(512), 0, s, slab, tasks, n_tasks, C, n_actions,
+                           frames, act);
     if (timing_ctx && coevo_timing_end(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
-    const dim3 g1(n_tasks, 8), b1(64);
-    switch ((max_rows_per_task + 3) / 4) {
-    case 1: hipLaunchKernelGGL(dqn_fc1_kernel<1>, g1, b1, 0, s, slab, tasks, C, n_actions, act, hid); break;
-    case 2: hipLaunchKernelGGL(dqn_fc1_kernel<2>, g1, b1, 0, s, slab, tasks, C, n_actions, act, hid); break;
-    case 3: hipLaunchKernelGGL(dqn_fc1_kernel<3>, g1, b1, 0, s, slab, tasks, C, n_actions, act, hid); break;
-    default: hipLaunchKernelGGL(dqn_fc1_kernel<4>, g1, b1, 0, s, slab, tasks, C, n_actions, act, hid); break;
-    }
-    hipLaunchKernelGGL(dqn_out_kernel, dim3(n_tasks, max_rows_per_task), dim3(64), 0, s, slab, tasks, C, n_actions, hid,
+    hipLaunchKernelGGL(dqn_fc1_kernel, dim3(n_tasks, 8), dim3(64), 0, s, slab, tasks, C, n_actions, act, hid);
+    hipLaunchKernelGGL(dqn_out_kernel, dim3(n_rows_total), dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, hid,
                        actions, logits, status);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;

@@ -365,7 +365,8 @@ typedef struct {
     int32_t n_rows;    /* 1 .. COEVO_DQN_MAX_ROWS frames that share this weight set */
 } coevo_dqn_task;
 /* frames [n_rows_total][84][84][C] uint8; actions [n_rows_total]; logits [n_rows_total][COEVO_DQN_LOGIT_STRIDE] or
- * NULL; workspace of coevo_dqn_workspace_bytes(n_rows_total) bytes.  Three launches on `stream`. */
+ * NULL; workspace of coevo_dqn_workspace_bytes(n_rows_total) bytes.  The tasks must partition the rows 0 ..
+ * n_rows_total-1 in ascending row_begin order (a frame's task is found by binary search).  Three launches on `stream`. */
 int coevo_dqn_forward_argmax(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int max_rows_per_task,
                              int n_rows_total, int C, int n_actions, const uint8_t *frames, int32_t *actions,
                              float *logits, int32_t *status, void *workspace, void *stream);
