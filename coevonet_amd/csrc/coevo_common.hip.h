@@ -120,57 +120,65 @@ __device__ __forceinline__ float add_xor32(float v)
     return __uint_as_float(s[0]) + __uint_as_float(s[1]);
 }
 
-// Reduce(NB * 64) for one row held by one wave: v[b] = the lane's element of block b (lane l = position l of the block).
-// Per block the balanced tree lane xor 1, 2, 4, 8, 16, 32; then the block sums left to right.  After level m the 2m lanes
-// of a group hold the same value, so two blocks share a register from there on (a lane bit selects the block): 30
-// instructions for eight blocks instead of 88.  NB = 1..8.
-template <int NB>
-__device__ __forceinline__ float row_blocks_total(const float (&v)[NB], int l)
+// N independent 64-lane tree sums (lane xor 1, 2, 4, 8, 16, 32 - the canonical in-block tree) in one packed butterfly:
+// after level m the 2m lanes of a group hold the same value, so two values share a register from there on (a lane bit
+// selects which).  Returns a register whose lane j (j < N) holds the total of v[j].  N <= 16.  ~4 instructions per value
+// instead of 11.
+template <int N>
+__device__ __forceinline__ float packed_totals(const float (&v)[N], int l)
 {
-    static_assert(NB >= 1 && NB <= 8, "up to eight 64-wide blocks");
-    constexpr int PB = NB <= 1 ? 1 : NB <= 2 ? 2 : NB <= 4 ? 4 : 8;   // blocks padded to a power of two (zeros)
-    float x[PB];
+    static_assert(N >= 1 && N <= 16, "four packing levels");
+    constexpr int N1 = (N + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2;
+    float p[N1];
 #pragma unroll
-    for (int b = 0; b < PB; ++b) x[b] = (b < NB) ? v[b] : 0.0f;
-    // level 1 (xor 1), then pack pairs by lane bit 0
-    float p[(PB + 1) / 2];
-#pragma unroll
-    for (int j = 0; j < (PB + 1) / 2; ++j) {
-        const float a = x[2 * j] + dpp_move<0xB1>(x[2 * j]);
-        if constexpr (PB >= 2) {
-            const float b = x[2 * j + 1] + dpp_move<0xB1>(x[2 * j + 1]);
+    for (int j = 0; j < N1; ++j) {
+        const float a = v[2 * j] + dpp_move<0xB1>(v[2 * j]);                       // xor 1
+        if (2 * j + 1 < N) {
+            const float b = v[2 * j + 1] + dpp_move<0xB1>(v[2 * j + 1]);
             p[j] = (l & 1) ? b : a;
         } else {
             p[j] = a;
         }
     }
-    // level 2 (xor 2), pack by lane bit 1
-    float q[(PB + 3) / 4];
+    float q[N2];
 #pragma unroll
-    for (int j = 0; j < (PB + 3) / 4; ++j) {
-        const float a = p[2 * j < (PB + 1) / 2 ? 2 * j : 0] + dpp_move<0x4E>(p[2 * j < (PB + 1) / 2 ? 2 * j : 0]);
-        if constexpr (PB >= 4) {
+    for (int j = 0; j < N2; ++j) {
+        const float a = p[2 * j] + dpp_move<0x4E>(p[2 * j]);                       // xor 2
+        if (2 * j + 1 < N1) {
             const float b = p[2 * j + 1] + dpp_move<0x4E>(p[2 * j + 1]);
             q[j] = (l & 2) ? b : a;
         } else {
             q[j] = a;
         }
     }
-    // level 3 (xor 4), pack by lane bit 2
-    float s;
-    {
-        const float a = q[0] + lane_xor4(q[0]);
-        if constexpr (PB >= 8) {
-            const float b = q[1] + lane_xor4(q[1]);
-            s = (l & 4) ? b : a;
+    float s3[N3];
+#pragma unroll
+    for (int j = 0; j < N3; ++j) {
+        const float a = q[2 * j] + lane_xor4(q[2 * j]);                            // xor 4
+        if (2 * j + 1 < N2) {
+            const float b = q[2 * j + 1] + lane_xor4(q[2 * j + 1]);
+            s3[j] = (l & 4) ? b : a;
         } else {
-            s = a;
+            s3[j] = a;
         }
     }
-    s = s + dpp_move<0x128>(s);   // xor 8: row_ror:8
+    float s = s3[0] + dpp_move<0x128>(s3[0]);                                      // xor 8: row_ror:8
+    if constexpr (N3 > 1) {
+        const float b = s3[1] + dpp_move<0x128>(s3[1]);
+        s = (l & 8) ? b : s;
+    }
     s = add_xor16(s);
     s = add_xor32(s);
-    // lane j (j < NB) holds the total of block j
+    return s;
+}
+
+// Reduce(NB * 64) for one row held by one wave: v[b] = the lane's element of block b (lane l = position l of the block):
+// the block trees by one packed butterfly, then the block sums left to right.  NB = 1..8.
+template <int NB>
+__device__ __forceinline__ float row_blocks_total(const float (&v)[NB], int l)
+{
+    static_assert(NB >= 1 && NB <= 8, "up to eight 64-wide blocks");
+    const float s = packed_totals<NB>(v, l);
     float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 0));
 #pragma unroll
     for (int b = 1; b < NB; ++b) tot = tot + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), b));

@@ -454,15 +454,19 @@ __device__ __forceinline__ void fc_policy_body(const FcArgs &a, FcSmem<R, P> &sm
 
 // =====================================================================================================
 // The per-individual body of the lean merged cycle kernel (COEVO_COMPACT, default), written for FEW ISSUED INSTRUCTIONS.
-// In a cycle launch all sixteen waves of a CU run the same phase at the same time, so everything outside the weight
-// stream is bound by the SIMDs' issue slots, not by latency: with fc1 / LayerNorm computed per thread for every row
-// (fc_policy_body: thread = feature, 6-level butterfly per value) a workgroup spends ~30 of its 67 us there
-// (tools/merged_wg_times.py).  Here a ROW belongs to ONE WAVE (rows w, w + 4): its fc1, both LayerNorm passes and the
-// normalisation need no barrier, and the eight 64-feature block sums of a row are reduced by ONE packed butterfly
-// (after each level the duplicate lanes are re-used for the next block: 30 instead of 88 instructions) - a third of the
-// issued instructions and four barriers less.  fc1's weights and the LayerNorm parameters are staged by LDS-DMA (no
-// registers held across the env step).  The arithmetic - every fmaf chain, every reduction tree, the left-to-right block
-// sums - is the canonical one, so the bits are those of fc_policy_body and of the oracle.
+// In a cycle launch all sixteen waves of a CU run the same phase at the same time and the chip clocks at ~1.5 GHz under
+// the weight stream, so everything outside the stream is bound by the SIMDs' issue slots, not by latency or instruction
+// fetch (tools/merged_wg_times.py: per-wave stamps + shader-clock stamps): with fc1 as 100 VALU FMAs fed by LDS
+// broadcasts and one 6-level butterfly per (row, block) value (fc_policy_body) a workgroup spends ~26 of its 67 us between
+// the entry barrier and the stream.  Here
+//   * fc1 runs on the matrix pipe like fc2 (v_mfma_f32_4x4x1, rows in groups of four: 40 MFMAs instead of 100 FMAs + 70
+//     LDS reads), its weights and the LayerNorm parameters staged by LDS-DMA (no registers held across the env step);
+//   * the 2 R block sums a wave owes per LayerNorm pass come from ONE packed butterfly (coevo_common.hip.h:
+//     packed_totals, ~4 instructions per value instead of 11);
+//   * mean / variance / rstd of a row are computed by one lane per row and broadcast with v_readlane, not by every thread;
+//   * the stream loop carries its own tail (no peeled copy of the last iteration), the last barrier is a wave fence.
+// The arithmetic - every fmaf chain, every reduction tree, the left-to-right block sums - is the canonical one, so the
+// bits are those of fc_policy_body and of the oracle.
 template <int R>
 struct FcSmemC {
     static constexpr int NG = (R + 3) / 4;   // row groups of four = v_mfma_f32_4x4x1 issues per k
@@ -470,9 +474,10 @@ struct FcSmemC {
     union {
         float par[13 * H1];                  // W1t [D][512], fc1.bias, ln1.weight, ln1.bias: contiguous in the slab
         float h1q[128][RP][4];               // A operands of fc2 (written once every wave is done with `par`)
-        struct { float h2[R][260]; float w3s[NACT][260]; float raw2[R][H2]; } tail;   // after the stream
+        struct { float h2[R][260]; float w3s[NACT][260]; } tail;   // after the stream
     };
-    float xs0[R][COEVO_OBS_STRIDE];
+    float xs0[4 * NG][COEVO_OBS_STRIDE];     // observations, rows padded to whole groups (zeros)
+    float red[4][16], red2[4][16];           // per wave: its block sums of every row (sums, squared deviations)
     float logit[R][COEVO_LOGIT_STRIDE];
 };
 
@@ -480,7 +485,9 @@ template <int R, int MODE>
 __device__ __forceinline__ void fc_policy_body_c(const FcArgs &a, FcSmemC<R> &sm, const coevo_fc_task *tasks, int first,
                                                  int n_tasks)
 {
-    static_assert(MODE == MODE_FUSED && R * NACT <= 64 && R <= 8, "the lean merged cycle kernel; rows w and w + 4 per wave");
+    static_assert(MODE == MODE_FUSED && R * NACT <= 64 && R <= 8, "the lean merged cycle kernel");
+    typedef float f32x4_acc __attribute__((ext_vector_type(4)));
+    constexpr int NG = FcSmemC<R>::NG;
     COEVO_STAMP(0);
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
     const bool active = first < n_tasks;
@@ -505,14 +512,11 @@ __device__ __forceinline__ void fc_policy_body_c(const FcArgs &a, FcSmemC<R> &sm
 #pragma unroll
         for (int j = 0; j < 5; ++j) w3r[j] = W3[t + 256 * j];
     }
-    const float p_b2 = b2p[t];
-    float p_g2[4], p_be2[4];   // LayerNorm(256) affine of features 64 b + l (the row-owning wave's layout)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) { p_g2[b] = b2p[H2 + 64 * b + l]; p_be2[b] = b2p[2 * H2 + 64 * b + l]; }
+    const float p_b2 = b2p[t], p_g2 = b2p[H2 + t], p_be2 = b2p[2 * H2 + t];
     const float p_b3 = (w == 0 && l < R * NACT) ? net[fc_off_b3(D) + l % NACT] : 0.0f;
 
     // ---- env step + observation: one lane per row (wave 0) ----------------------------------------------------
-    if (w == 0 && l < R) {
+    if (w == 0 && l < 4 * NG) {
         float o[COEVO_OBS_STRIDE];
 #pragma unroll
         for (int k = 0; k < COEVO_OBS_STRIDE; ++k) o[k] = 0.0f;
@@ -525,7 +529,7 @@ __device__ __forceinline__ void fc_policy_body_c(const FcArgs &a, FcSmemC<R> &sm
                 if (!__builtin_isfinite(o[k])) st |= COEVO_ST_BAD_INPUT;
         }
 #pragma unroll
-        for (int k = 0; k < COEVO_OBS_STRIDE; ++k) sm.xs0[l][k] = o[k];
+        for (int k = 0; k < COEVO_OBS_STRIDE; ++k) sm.xs0[l][k] = o[k];   // rows R .. 4 NG - 1: zeros (tile padding)
     }
     COEVO_WSTAMP(0);
     __syncthreads();   // (waits for the LDS-DMA too: the fence counts it on vmcnt)
@@ -533,67 +537,99 @@ __device__ __forceinline__ void fc_policy_body_c(const FcArgs &a, FcSmemC<R> &sm
     COEVO_CSTAMP(10);
     COEVO_STAMP(1);
 
-    // ---- fc1 + LayerNorm(512) + ReLU of rows w and w + 4, all inside this wave: lane l holds features 64 b + l --------
-    constexpr int NOWN = (R + 3) / 4;   // rows a wave may own
-    // which wave gets the extra row rotates with the workgroup: the waves w of the workgroups that share a CU sit on the
-    // same SIMD, and these phases are bound by the SIMDs' issue slots
-#ifndef COEVO_ROT_SHIFT
-#define COEVO_ROT_SHIFT 8
-#endif
-    const int wo = (w - (int)(blockIdx.x >> COEVO_ROT_SHIFT)) & 3;   // wave-uniform: this wave owns rows wo, wo + 4
-    float y1[NOWN][8];
-    const float *b1s = sm.par + D * H1, *g1s = b1s + H1, *be1s = g1s + H1;
+    // ---- fc1 on the matrix cores, like fc2: wave w owns features 64 w + l (block w) and 256 + 64 w + l (block 4 + w);
+    //      sequential-k chains from the bias, one k per v_mfma_f32_4x4x1 (rows in groups of four) ---------------------
+    const float *b1s = sm.par + D * H1;
+    f32x4_acc c0[NG], c1[NG];
+    {
+        const float bia = b1s[t], bib = b1s[t + 256];
 #pragma unroll
-    for (int i = 0; i < NOWN; ++i) {
-        const int r = wo + 4 * i;
-        if (r < R) {   // wave-uniform
-            float v[8];
+        for (int g = 0; g < NG; ++g)
 #pragma unroll
-            for (int b = 0; b < 8; ++b) v[b] = b1s[64 * b + l];
-#pragma nounroll
-            for (int k = 0; k < D; ++k) {   // sequential-k chains from the bias
-                const float x = sm.xs0[r][k];
-                const float *wk = sm.par + k * H1 + l;
+            for (int i = 0; i < 4; ++i) { c0[g][i] = bia; c1[g][i] = bib; }
+        float4 xk[NG][3];   // observations of row 4 g + l % 4: 12 floats (10 used)
 #pragma unroll
-                for (int b = 0; b < 8; ++b) v[b] = __builtin_fmaf(wk[64 * b], x, v[b]);
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) xk[g][j] = *reinterpret_cast<const float4 *>(&sm.xs0[4 * g + (l & 3)][4 * j]);
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            if (k < D) {   // wave-uniform
+                const float wa = sm.par[k * H1 + t], wb = sm.par[k * H1 + 256 + t];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const float4 xv = xk[g][k >> 2];
+                    const float x = (k & 3) == 0 ? xv.x : (k & 3) == 1 ? xv.y : (k & 3) == 2 ? xv.z : xv.w;
+                    c0[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x, wa, c0[g], 0, 0, 0);
+                    c1[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x, wb, c1[g], 0, 0, 0);
+                }
             }
-            const float mean = row_blocks_total<8>(v, l) * (1.0f / H1);
-            float sq[8];
-#pragma unroll
-            for (int b = 0; b < 8; ++b) { v[b] = v[b] - mean; sq[b] = v[b] * v[b]; }
-            const float var = row_blocks_total<8>(sq, l) * (1.0f / H1);
-            const float rstd = 1.0f / __builtin_sqrtf(var + LN_EPS);
-            bool bad = false;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const float y = __builtin_fmaf(v[b] * rstd, g1s[64 * b + l], be1s[64 * b + l]);
-                bad = bad || bad_post_relu(y);
-                y1[i][b] = relu_keep_nan(y);
-            }
-            if (r < nrows && bad) st |= COEVO_ST_BAD_FC1;
         }
     }
+    // LayerNorm parameters of this thread's two features: read before `par` may be overwritten
+    const float p_g1a = b1s[H1 + t], p_g1b = b1s[H1 + t + 256], p_be1a = b1s[2 * H1 + t], p_be1b = b1s[2 * H1 + t + 256];
     COEVO_STAMP(8);
-    COEVO_CSTAMP(11);
+    // ---- LayerNorm(512) + ReLU.  Per wave 2 R block sums (rows x its two blocks): one packed butterfly; the eight
+    //      partials of a row are combined and turned into mean / rstd by ONE lane per row, then broadcast ---------------
+    float v[2 * R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { v[2 * r] = c0[r >> 2][r & 3]; v[2 * r + 1] = c1[r >> 2][r & 3]; }
+    {
+        const float s = packed_totals<2 * R>(v, l);
+        if (l < 2 * R) sm.red[w][l] = s;          // red[wave][2 r + half]: block (4 half + wave) of row r
+    }
+    COEVO_STAMP(9);
     COEVO_WSTAMP(2);
-    __syncthreads();   // every wave is done with `par`: the k-quad image may overwrite it
+    __syncthreads();
     COEVO_WSTAMP(3);
+    COEVO_STAMP(10);
+    const int lr = l < R ? l : R - 1;             // lane r < R works on row r (the other lanes repeat the last row)
+    {
+        float tot = sm.red[0][2 * lr];            // blocks left to right: 0..3 = first halves, 4..7 = second halves
 #pragma unroll
-    for (int i = 0; i < NOWN; ++i) {
-        const int r = wo + 4 * i;
-        if (r < R) {
+        for (int b = 1; b < 8; ++b) tot = tot + sm.red[b & 3][2 * lr + (b >> 2)];
+        const float meanv = tot * (1.0f / H1);
 #pragma unroll
-            for (int b = 0; b < 8; ++b) sm.h1q[(64 * b + l) >> 2][r][l & 3] = y1[i][b];
+        for (int r = 0; r < R; ++r) {
+            const float m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(meanv), r));
+            v[2 * r] = v[2 * r] - m;
+            v[2 * r + 1] = v[2 * r + 1] - m;
         }
+    }
+    {
+        float sq[2 * R];
+#pragma unroll
+        for (int j = 0; j < 2 * R; ++j) sq[j] = v[j] * v[j];
+        const float s = packed_totals<2 * R>(sq, l);
+        if (l < 2 * R) sm.red2[w][l] = s;
+    }
+    COEVO_WSTAMP(4);
+    __syncthreads();   // every wave is also done with `par` (its fc1 weights and LayerNorm parameters are in registers)
+    COEVO_WSTAMP(5);
+    {
+        float tot = sm.red2[0][2 * lr];
+#pragma unroll
+        for (int b = 1; b < 8; ++b) tot = tot + sm.red2[b & 3][2 * lr + (b >> 2)];
+        const float rstdv = 1.0f / __builtin_sqrtf(tot * (1.0f / H1) + LN_EPS);
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float rstd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rstdv), r));
+            const float y0 = __builtin_fmaf(v[2 * r] * rstd, p_g1a, p_be1a);
+            const float y1 = __builtin_fmaf(v[2 * r + 1] * rstd, p_g1b, p_be1b);
+            if (r < nrows) bad = bad || bad_post_relu(y0) || bad_post_relu(y1);
+            sm.h1q[t >> 2][r][t & 3] = relu_keep_nan(y0);
+            sm.h1q[(t + 256) >> 2][r][t & 3] = relu_keep_nan(y1);
+        }
+        if (bad) st |= COEVO_ST_BAD_FC1;
     }
     COEVO_WSTAMP(6);
     __syncthreads();
     COEVO_WSTAMP(7);
+    COEVO_CSTAMP(11);
     COEVO_STAMP(2);
 
     // ---- fc2 on the matrix cores, as in fc_policy_body; the ping-pong loop carries its own tail ------------------
-    typedef float f32x4_acc __attribute__((ext_vector_type(4)));
-    constexpr int NG = FcSmemC<R>::NG;
     f32x4_acc acc[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
@@ -638,34 +674,41 @@ __device__ __forceinline__ void fc_policy_body_c(const FcArgs &a, FcSmemC<R> &sm
     COEVO_STAMP(3);
     COEVO_WSTAMP(8);
     COEVO_CSTAMP(12);
-    __syncthreads();   // every wave is done reading h1q: the tail image may overwrite it
-    // ---- fc2 results (thread = column) -> rows by wave through LDS; the output layer's weights ride along ----------
+    // ---- LayerNorm(256) + ReLU: canonical block b = wave b; R block sums per wave by one packed butterfly ---------------
+    float u[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) sm.tail.raw2[r][t] = acc[r >> 2][r & 3];
+    for (int r = 0; r < R; ++r) u[r] = acc[r >> 2][r & 3];
+    {
+        const float s = packed_totals<R>(u, l);
+        if (l < R) sm.red[w][l] = s;   // (red / red2 live outside the union: no wave still needs the old contents)
+    }
+    __syncthreads();  // also: every wave is done reading h1q, the tail image may overwrite it below
+    {
+        const float tot = ((sm.red[0][lr] + sm.red[1][lr]) + sm.red[2][lr]) + sm.red[3][lr];
+        const float meanv = tot * (1.0f / H2);
+#pragma unroll
+        for (int r = 0; r < R; ++r) u[r] = u[r] - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(meanv), r));
+        float sq[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) sq[r] = u[r] * u[r];
+        const float s = packed_totals<R>(sq, l);
+        if (l < R) sm.red2[w][l] = s;
+    }
 #pragma unroll
     for (int j = 0; j < 5; ++j) sm.tail.w3s[(t + 256 * j) >> 8][(t + 256 * j) & 255] = w3r[j];
     __syncthreads();
-    // ---- LayerNorm(256) + ReLU of rows w and w + 4: lane l holds features 64 b + l, b < 4 --------------------------
+    {
+        const float tot = ((sm.red2[0][lr] + sm.red2[1][lr]) + sm.red2[2][lr]) + sm.red2[3][lr];
+        const float rstdv = 1.0f / __builtin_sqrtf(tot * (1.0f / H2) + LN_EPS);
+        bool bad = false;
 #pragma unroll
-    for (int i = 0; i < NOWN; ++i) {
-        const int r = wo + 4 * i;
-        if (r < R) {
-            float v[4], sq[4];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) v[b] = sm.tail.raw2[r][64 * b + l];
-            const float mean = row_blocks_total<4>(v, l) * (1.0f / H2);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) { v[b] = v[b] - mean; sq[b] = v[b] * v[b]; }
-            const float rstd = 1.0f / __builtin_sqrtf(row_blocks_total<4>(sq, l) * (1.0f / H2) + LN_EPS);
-            bool bad = false;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const float y = __builtin_fmaf(v[b] * rstd, p_g2[b], p_be2[b]);
-                bad = bad || bad_post_relu(y);
-                sm.tail.h2[r][64 * b + l] = relu_keep_nan(y);
-            }
-            if (r < nrows && bad) st |= COEVO_ST_BAD_FC2;
+        for (int r = 0; r < R; ++r) {
+            const float rstd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rstdv), r));
+            const float y = __builtin_fmaf(u[r] * rstd, p_g2, p_be2);
+            if (r < nrows) bad = bad || bad_post_relu(y);
+            sm.tail.h2[r][t] = relu_keep_nan(y);
         }
+        if (bad) st |= COEVO_ST_BAD_FC2;
     }
     __syncthreads();
     COEVO_STAMP(4);
@@ -697,9 +740,9 @@ __device__ __forceinline__ void fc_policy_body_c(const FcArgs &a, FcSmemC<R> &sm
             float cur = -__builtin_inff();
 #pragma unroll
             for (int o = 0; o < NACT; ++o) {
-                const float v = sm.logit[l][o];
-                if (!__builtin_isfinite(v)) st |= COEVO_ST_BAD_OUT;
-                if (v > cur) { cur = v; best = o; }
+                const float vv = sm.logit[l][o];
+                if (!__builtin_isfinite(vv)) st |= COEVO_ST_BAD_OUT;
+                if (vv > cur) { cur = vv; best = o; }
             }
             if (best < 0) { st |= COEVO_ST_NO_ACTION; best = 0; }
             const int row = row0 + l;
