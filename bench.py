@@ -252,14 +252,13 @@ def run_dqn(a, ctx, dev, algo, pop_per_gpu=None, T=None):
     tr = (DQNGATrainer if ga else DQNESTrainer)(env, args, collect=False, dist_ctx=ctx)
     eng = tr.eng
     eng.ro.start_timing(pairs=2048, every=7)
-    dt = _timed_steps(tr.step, a, ctx, dev,
-                      before_timed=lambda: (torch.cuda.synchronize(),
-                                            L_load().coevo_rollout_ctx_reset_timing(eng.ro.timing_ctx)))
-    conv_ms = eng.ro.conv_times_ms()
+    dt = _timed_steps(tr.step, a, ctx, dev, before_timed=lambda: (torch.cuda.synchronize(), eng.ro.reset_timing()))
+    conv_ms, fc1_ms = eng.ro.times_ms(0), eng.ro.times_ms(1)
     if ga:
         tr.finish()
     gens = a.steps / dt
-    n_frames = eng.ro.n_games
+    lane0 = eng.ro.lanes[0]
+    n_frames = lane0["n"]                       # frames per sampled launch (the first cohort's)
     mac = DQN_CONV_MAC + (a.channels - 4) * 64 * 32 * 400
     out = {"metric": f"env-steps/sec (agent-steps of the whole job), Co-{'GA' if ga else 'ES'} over DeepQN on "
                      f"{args.game}-shaped SYNTHETIC frames",
@@ -270,24 +269,35 @@ def run_dqn(a, ctx, dev, algo, pop_per_gpu=None, T=None):
                                   f" T={T} frames 84x84x{a.channels} actions={eng.n_actions}, synthetic env (no ALE in "
                                   "the image; frames keyed by game, step and the previous action), build-defined 2-role loop",
                       "population": pop, "agent_steps_per_generation": eng.steps_per_generation,
-                      "games_per_launch": n_frames, "offspring": "device_philox",
+                      "games_per_launch": n_frames, "cohorts": len(eng.ro.lanes), "offspring": "device_philox",
                       "parallelism": f"population shard x{ctx.world}" if ctx.world > 1 else "single GPU"}}
-    if conv_ms:
-        avg = float(np.mean(conv_ms))
-        tf = n_frames * 2 * mac / (avg * 1e-3) / 1e12
+    if conv_ms and fc1_ms:
+        c_avg, f_avg = float(np.mean(conv_ms)), float(np.mean(fc1_ms))
+        tf = n_frames * 2 * mac / (c_avg * 1e-3) / 1e12
+        # fc1: every distinct acting net's 512 x 3136 fp32 matrix once + the activations in / out (mean over both parities)
+        nets = np.mean([eng.ro.distinct_nets_per_step(p) for p in (0, 1)])
+        fc1_bytes = nets * 512 * 3136 * 4 + n_frames * (3136 + 512) * 4
+        fc1_gbs = fc1_bytes / (f_avg * 1e-3) / 1e9
         rounds = (T + 1) // 2
         gen_bytes = eng.ro.weight_bytes_per_round() * rounds
-        out["roofline"] = {"bound": "mfma", "kernel": "dqn_conv_kernel (conv stack + per-sample BatchNorm of every frame "
-                           "of one agent-step on v_mfma_f32_32x32x2_f32; exact f32 = the reference's arithmetic)",
-                           "timing": "HIP events around sampled launches on their stream (eager enqueue)",
-                           "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "flops_per_launch": n_frames * 2 * mac,
-                           "avg_launch_ms": avg, "launches_timed": len(conv_ms),
-                           "generation": {"bound": "hbm", "algorithmic_bytes": gen_bytes,
-                                          "achieved": gen_bytes * gens / 1e9, "unit": "GB/s",
-                                          "frac": gen_bytes * gens / 1e9 / HBM_PEAK_GBS,
-                                          "note": "SURVEY 8d cfg 4/5 byte model: every distinct acting weight set once "
-                                                  "per agent-step + frames"}}
+        conv_rl = {"bound": "mfma", "kernel": "dqn_conv_kernel (conv stack + per-sample BatchNorm of every frame of one "
+                   "agent-step of one cohort on v_mfma_f32_16x16x4_f32; exact f32 = the reference's arithmetic)",
+                   "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
+                   "traffic": None, "flops_per_launch": n_frames * 2 * mac, "avg_launch_ms": c_avg,
+                   "launches_timed": len(conv_ms)}
+        fc1_rl = {"bound": "hbm", "kernel": "dqn_fc1_kernel (every acting net's 6.4 MB fc1 matrix streamed once for its "
+                  "<= 16 frames, v_mfma_f32_4x4x1)", "achieved": fc1_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": fc1_gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": fc1_bytes,
+                  "avg_launch_ms": f_avg, "launches_timed": len(fc1_ms)}
+        dom, other = (conv_rl, fc1_rl) if c_avg >= f_avg else (fc1_rl, conv_rl)
+        out["roofline"] = dict(dom)
+        out["roofline"]["timing"] = "HIP events around sampled launches of the first cohort on its stream (eager enqueue)"
+        out["roofline"]["second_kernel"] = other
+        out["roofline"]["generation"] = {"bound": "hbm", "algorithmic_bytes": gen_bytes,
+                                         "achieved": gen_bytes * gens / 1e9, "unit": "GB/s",
+                                         "frac": gen_bytes * gens / 1e9 / HBM_PEAK_GBS,
+                                         "note": "SURVEY 8d cfg 4/5 byte model: every distinct acting weight set once "
+                                                 "per agent-step + frames"}
     return out
 
 

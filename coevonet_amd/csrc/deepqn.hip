@@ -388,13 +388,13 @@ extern "C" int coevo_dqn_forward_argmax(const float *slab, const coevo_dqn_task 
                                         void *workspace, void *stream)
 {
     return coevo_dqn_forward_argmax_timed(slab, tasks, n_tasks, max_rows_per_task, n_rows_total, C, n_actions, frames,
-                                          actions, logits, status, workspace, nullptr, stream);
+                                          actions, logits, status, workspace, nullptr, 0, stream);
 }
 
 extern "C" int coevo_dqn_forward_argmax_timed(const float *slab, const coevo_dqn_task *tasks, int n_tasks,
                                               int max_rows_per_task, int n_rows_total, int C, int n_actions,
                                               const uint8_t *frames, int32_t *actions, float *logits, int32_t *status,
-                                              void *workspace, void *timing_ctx, void *stream)
+                                              void *workspace, void *timing_ctx, int timed_kernel, void *stream)
 {
     if (!slab || !tasks || !frames || !actions || !status || !workspace) return COEVO_ERR_ARG;
     if (n_tasks <= 0 || n_rows_total <= 0 || !dqn_shape_ok(C, n_actions)) return COEVO_ERR_ARG;
@@ -402,15 +402,18 @@ extern "C" int coevo_dqn_forward_argmax_timed(const float *slab, const coevo_dqn
     float *act = static_cast<float *>(workspace);
     float *hid = act + (size_t)n_rows_total * DQ_FC1_IN;
     hipStream_t s = (hipStream_t)stream;
-    if (timing_ctx && coevo_timing_begin(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
+    if (timing_ctx && (timed_kernel < 0 || timed_kernel > 1)) return COEVO_ERR_ARG;
+    if (timing_ctx && timed_kernel == 0 && coevo_timing_begin(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     if (C <= 4)
         hipLaunchKernelGGL(dqn_conv_kernel<4>, dim3(n_rows_total), dim3(512), 0, s, slab, tasks, n_tasks, C, n_actions,
                            frames, act);
     else
         hipLaunchKernelGGL(dqn_conv_kernel<6>, dim3(n_rows_total), dim3(512), 0, s, slab, tasks, n_tasks, C, n_actions,
                            frames, act);
-    if (timing_ctx && coevo_timing_end(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
+    if (timing_ctx && timed_kernel == 0 && coevo_timing_end(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
+    if (timing_ctx && timed_kernel == 1 && coevo_timing_begin(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     hipLaunchKernelGGL(dqn_fc1_kernel, dim3(n_tasks, 8), dim3(64), 0, s, slab, tasks, C, n_actions, act, hid);
+    if (timing_ctx && timed_kernel == 1 && coevo_timing_end(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     hipLaunchKernelGGL(dqn_out_kernel, dim3(n_rows_total), dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, hid,
                        actions, logits, status);
     COEVO_HIP_CHECK(hipGetLastError());

@@ -19,6 +19,7 @@ distance) per individual (Co-GA: elites rebuilt from noise, no weight crosses xG
 """
 from __future__ import annotations
 
+import os
 import time
 
 import numpy as np
@@ -37,73 +38,123 @@ FRAME = 84 * 84
 
 class SynthRollout:
     """A batch of synthetic-env games: game g seats net ``game_nets[g][0]`` as first_0 and ``[g][1]`` as second_0.
-    Per parity (who acts) the rows are grouped by acting net into tasks of <= 16 frames."""
+    Per parity (who acts) the rows are grouped by acting net into tasks of <= 16 frames.
 
-    def __init__(self, game_nets, net_off, ordinal0, C, n_actions, slab, env_seed, ordinals_per_gen, device="cuda"):
+    ``bounds`` cuts the games into contiguous cohorts (default: one).  Games are independent, so each cohort runs its own
+    chain of per-step launches on its own stream: one cohort's conv stack (matrix cores) overlaps the other's fc1 weight
+    stream (HBM) instead of the whole chip alternating between the two.  Eager enqueue only (no graph capture)."""
+
+    def __init__(self, game_nets, net_off, ordinal0, C, n_actions, slab, env_seed, ordinals_per_gen, device="cuda",
+                 bounds=None):
         self.n_games = n = int(len(game_nets))
         self.C, self.n_actions, self.slab, self.env_seed = C, n_actions, slab, int(env_seed)
         self.ordinals_per_gen = int(ordinals_per_gen)
+        self.device = device
         game_nets = np.asarray(game_nets, dtype=np.int64).reshape(n, 2)
-        self.tasks, self.rows, self.n_tasks, self.max_rows = [], [], [], []
-        self.tasks_np = []
-        for parity in range(2):
-            by_net = {}
-            for g in range(n):
-                by_net.setdefault(int(game_nets[g, parity]), []).append(g)
-            tasks, row_of_game = [], np.zeros(n, dtype=np.int32)
-            row = 0
-            for net, games in by_net.items():
-                for i in range(0, len(games), TASK_ROWS):
-                    chunk = games[i:i + TASK_ROWS]
-                    tasks.append((int(net_off[net]), row, len(chunk)))
-                    for g in chunk:
-                        row_of_game[g] = row
-                        row += 1
-            t_np = np.array(tasks, dtype=L.DQN_TASK_DTYPE)
-            self.tasks_np.append(t_np)
-            self.tasks.append(L.tasks_to_device(t_np, device))
-            self.rows.append(torch.from_numpy(row_of_game).to(device))
-            self.n_tasks.append(len(tasks))
-            self.max_rows.append(int(max(t[2] for t in tasks)))
+        bounds = [0, n] if bounds is None else [int(x) for x in bounds]
+        assert bounds[0] == 0 and bounds[-1] == n and all(b1 > b0 for b0, b1 in zip(bounds, bounds[1:]))
         self.ordinal0 = torch.from_numpy(np.asarray(ordinal0, dtype=np.int64)).to(device)
-        self.frames = torch.zeros(n * FRAME * C, dtype=torch.uint8, device=device)
-        self.actions = torch.zeros(2, n, dtype=torch.int32, device=device)
         self.gstate = torch.zeros(n, 4, dtype=torch.int32, device=device)
         self.acc = torch.zeros(n, 3, dtype=torch.float64, device=device)   # play_game returns (first_0, second_0), 0
         self.limit = torch.zeros(n, dtype=torch.int32, device=device)
         self.status = torch.zeros(1, dtype=torch.int32, device=device)
-        self.ws = torch.zeros(int(L.load().coevo_dqn_workspace_bytes(n)) // 4, dtype=torch.float32, device=device)
-        self.timing_ctx = None      # set by start_timing(): HIP events around sampled conv-stack launches (eager only)
+        self.lanes = []
+        for g0, g1 in zip(bounds, bounds[1:]):
+            m = g1 - g0
+            lane = {"g0": g0, "n": m, "tasks": [], "tasks_np": [], "rows": [], "n_tasks": [], "max_rows": []}
+            for parity in range(2):
+                by_net = {}
+                for g in range(g0, g1):
+                    by_net.setdefault(int(game_nets[g, parity]), []).append(g - g0)
+                tasks, row_of_game = [], np.zeros(m, dtype=np.int32)
+                row = 0
+                for net, games in by_net.items():
+                    for i in range(0, len(games), TASK_ROWS):
+                        chunk = games[i:i + TASK_ROWS]
+                        tasks.append((int(net_off[net]), row, len(chunk)))
+                        for g in chunk:
+                            row_of_game[g] = row
+                            row += 1
+                t_np = np.array(tasks, dtype=L.DQN_TASK_DTYPE)
+                lane["tasks_np"].append(t_np)
+                lane["tasks"].append(L.tasks_to_device(t_np, device))
+                lane["rows"].append(torch.from_numpy(row_of_game).to(device))
+                lane["n_tasks"].append(len(tasks))
+                lane["max_rows"].append(int(max(t[2] for t in tasks)))
+            lane["frames"] = torch.zeros(m * FRAME * C, dtype=torch.uint8, device=device)
+            lane["actions"] = torch.zeros(2, m, dtype=torch.int32, device=device)
+            lane["ws"] = torch.zeros(int(L.load().coevo_dqn_workspace_bytes(m)) // 4, dtype=torch.float32, device=device)
+            lane["stream"] = None if not self.lanes else torch.cuda.Stream(device=device)
+            lane["done"] = torch.cuda.Event() if self.lanes else None
+            self.lanes.append(lane)
+        self.tasks_np = [np.concatenate([ln["tasks_np"][p] for ln in self.lanes]) for p in range(2)]
+        self._fork = torch.cuda.Event() if len(self.lanes) > 1 else None
+        self.timing_ctx = None      # set by start_timing(): HIP events around sampled launches (eager only)
         self.timing_every = 1
 
     def start_timing(self, pairs=512, every=7):
-        self.timing_ctx = L.load().coevo_rollout_ctx_create(int(pairs))
+        """sample the conv-stack launch (and, on other steps, the fc1 launch) of the first cohort with HIP events"""
+        self.timing_ctx = [L.load().coevo_rollout_ctx_create(int(pairs)) for _ in range(2)]
         self.timing_every = int(every)
 
-    def conv_times_ms(self, max_out=100000):
+    def reset_timing(self):
+        for c in self.timing_ctx or []:
+            L.load().coevo_rollout_ctx_reset_timing(c)
+
+    def times_ms(self, which, max_out=100000):
+        """durations of the sampled launches: which = 0 conv stack, 1 fc1"""
         if not self.timing_ctx:
             return []
         buf = (L.C.c_float * max_out)()
-        n = L.load().coevo_rollout_ctx_light_times(self.timing_ctx, buf, max_out)
+        n = L.load().coevo_rollout_ctx_light_times(self.timing_ctx[which], buf, max_out)
         return [buf[i] for i in range(max(n, 0))]
+
+    def conv_times_ms(self):
+        return self.times_ms(0)
 
     def set_limits(self, limits):
         self.limit.copy_(torch.from_numpy(np.asarray(limits, dtype=np.int32)))
 
-    def enqueue(self, T, gen_dev):
-        """T agent-steps of every game + the closing bookkeeping call, on the current stream"""
-        g = L._p(gen_dev) if gen_dev is not None else None
+    def _enqueue_lane(self, ln, T, g, stream, timed):
+        g0, m = ln["g0"], ln["n"]
+        gs, ac = self.gstate.data_ptr() + 16 * g0, self.acc.data_ptr() + 24 * g0
+        o0, lim = self.ordinal0.data_ptr() + 8 * g0, self.limit.data_ptr() + 4 * g0
+        lib = L.load()
         for t in range(T + 1):
             p, q = t & 1, (t - 1) & 1
-            L.call("coevo_synth_step", L._p(self.gstate), L._p(self.acc), self.n_games, L._p(self.ordinal0), g,
-                   self.ordinals_per_gen, t, L._p(self.limit), L._p(self.rows[q]) if t else None,
-                   self.actions[q].data_ptr() if t else None, L._p(self.rows[p]) if t < T else None,
-                   L._p(self.frames) if t < T else None, self.C, self.n_actions, self.env_seed)
+            L._check(lib.coevo_synth_step(gs, ac, m, o0, g, self.ordinals_per_gen, t, lim,
+                                          L._p(ln["rows"][q]) if t else None,
+                                          ln["actions"][q].data_ptr() if t else None,
+                                          L._p(ln["rows"][p]) if t < T else None,
+                                          L._p(ln["frames"]) if t < T else None, self.C, self.n_actions, self.env_seed,
+                                          stream), "coevo_synth_step")
             if t < T:
-                timed = self.timing_ctx if (self.timing_ctx and t % self.timing_every == 0) else None
-                L.call("coevo_dqn_forward_argmax_timed", L._p(self.slab), L._p(self.tasks[p]), self.n_tasks[p],
-                       self.max_rows[p], self.n_games, self.C, self.n_actions, L._p(self.frames),
-                       self.actions[p].data_ptr(), None, L._p(self.status), L._p(self.ws), timed)
+                tc, which = None, 0
+                if timed and self.timing_ctx and t % self.timing_every == 0:
+                    which = (t // self.timing_every) & 1
+                    tc = self.timing_ctx[which]
+                L._check(lib.coevo_dqn_forward_argmax_timed(L._p(self.slab), L._p(ln["tasks"][p]), ln["n_tasks"][p],
+                                                            ln["max_rows"][p], m, self.C, self.n_actions,
+                                                            L._p(ln["frames"]), ln["actions"][p].data_ptr(), None,
+                                                            L._p(self.status), L._p(ln["ws"]), tc, which, stream),
+                         "coevo_dqn_forward_argmax_timed")
+
+    def enqueue(self, T, gen_dev):
+        """T agent-steps of every game + the closing bookkeeping call; cohort 0 on the current stream, the others on
+        their own streams (forked from / joined to the current one)"""
+        g = L._p(gen_dev) if gen_dev is not None else None
+        main = torch.cuda.current_stream()
+        if len(self.lanes) > 1:
+            self._fork.record(main)
+        for k, ln in reversed(list(enumerate(self.lanes))):   # the caller's stream last
+            if k:
+                ln["stream"].wait_event(self._fork)
+                self._enqueue_lane(ln, T, g, ln["stream"].cuda_stream, False)
+                ln["done"].record(ln["stream"])
+            else:
+                self._enqueue_lane(ln, T, g, main.cuda_stream, True)
+        for ln in self.lanes[1:]:
+            main.wait_event(ln["done"])
 
     def weight_bytes_per_round(self):
         """algorithmic bytes of one round (two agent-steps): every distinct acting weight set once per agent-step +
@@ -111,6 +162,9 @@ class SynthRollout:
         P4 = int(L.load().coevo_dqn_param_count(self.C, self.n_actions)) * 4
         nets = sum(len({int(t["net_off"]) for t in tn}) for tn in self.tasks_np)
         return nets * P4 + 2 * self.n_games * FRAME * self.C
+
+    def distinct_nets_per_step(self, parity, lane=0):
+        return len({int(t["net_off"]) for t in self.lanes[lane]["tasks_np"][parity]})
 
 
 def dqn_init_flat(C, n_actions):
@@ -182,7 +236,14 @@ class DQNGAEngine(_SlabMixin):
         for j in range(N_EVAL):  # the best pair = the newest HoF members; generation g-1's games ride in g's launch
             games.append((net("hof", "first_0", h - 1), net("hof", "second_0", h - 1)))
             ordinal0.append(first_ordinal - self.per_gen + M + j)
-        self.ro = SynthRollout(games, net_off, ordinal0, C, n_actions, self.slab, env_seed, self.per_gen, device)
+        # optional (COEVO_DQN_COHORTS=2): two cohorts = the two role phases (contiguous game ranges; the evaluation games
+        # go with the second) on two streams.  Measured on the cfg 4 shard: 12.2 vs 12.6 generations/s for one chain - conv
+        # stack and fc1 both live on the matrix pipe at these row counts, there is nothing complementary to overlap
+        K = int(os.environ.get("COEVO_DQN_COHORTS", "1"))
+        bounds = [0, self.n_main // 2, len(games)] if (K > 1 and self.n_main >= 2) else None
+        self.ro = SynthRollout(games, net_off, ordinal0, C, n_actions, self.slab, env_seed, self.per_gen, device,
+                               bounds=bounds)
+        self.cohorts = len(self.ro.lanes)
         # ---- device-resident loop state ------------------------------------------------------------------------
         f32 = dict(dtype=torch.float32, device=device)
         i32 = dict(dtype=torch.int32, device=device)
@@ -282,7 +343,7 @@ class DQNGAEngine(_SlabMixin):
             limits = np.full(self.ro.n_games, self.T_train, dtype=np.int32)
             limits[self.n_main:] = self.T_eval if gen == 1 else 0
             self.ro.set_limits(limits)
-        if self.world == 1 and use_graph:
+        if self.world == 1 and use_graph and self.cohorts == 1:   # (cohort chains are enqueued eagerly on their streams)
             if self._graph is None:
                 torch.cuda.synchronize()
                 gr = torch.cuda.CUDAGraph()
@@ -452,7 +513,11 @@ class DQNESEngine(_SlabMixin):
                 games.append((me, 1) if ri == 0 else (0, me))
                 ordinal0.append(first_ordinal + 2 * (self.lo + j) + ri)
         self.n_main = len(games)
-        self.ro = SynthRollout(games, net_off, ordinal0, C, n_actions, self.slab, env_seed, self.per_gen, device)
+        K = int(os.environ.get("COEVO_DQN_COHORTS", "1"))   # (cfg 5 shard: 8.7 vs 8.4 generations/s with two cohorts)
+        half = 2 * (self.n_local // 2)   # games are individual-major: the first half of the individuals / the rest
+        bounds = [0, half, self.n_main] if (K > 1 and 0 < half < self.n_main) else None
+        self.ro = SynthRollout(games, net_off, ordinal0, C, n_actions, self.slab, env_seed, self.per_gen, device,
+                               bounds=bounds)
         self.ro.set_limits(np.full(self.n_main, self.T_train, dtype=np.int32))
         self.eval_ro = SynthRollout([(0, 1)] * N_EVAL, net_off[:2], [first_ordinal + 2 * pop + j for j in range(N_EVAL)],
                                     C, n_actions, self.slab, env_seed, self.per_gen, device)

@@ -107,7 +107,7 @@ _SIGS = {
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "coevo_dqn_forward_argmax_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                                 C.c_void_p]),
+                                                 C.c_int, C.c_void_p]),
     "coevo_timing_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "coevo_timing_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "coevo_dqn_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

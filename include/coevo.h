@@ -371,11 +371,13 @@ int coevo_dqn_forward_argmax(const float *slab, const coevo_dqn_task *tasks, int
                              int n_rows_total, int C, int n_actions, const uint8_t *frames, int32_t *actions,
                              float *logits, int32_t *status, void *workspace, void *stream);
 
-/* the same with the conv-stack launch (the dominant kernel) bracketed by the next timing event pair of a rollout context
- * (coevo_rollout_ctx_create / coevo_rollout_ctx_light_times); eager enqueue only; timing_ctx == NULL = untimed */
+/* the same with one of its launches (timed_kernel: 0 = conv stack, 1 = fc1) bracketed by the next timing event pair of a
+ * rollout context (coevo_rollout_ctx_create / coevo_rollout_ctx_light_times); eager enqueue only; timing_ctx == NULL =
+ * untimed */
 int coevo_dqn_forward_argmax_timed(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int max_rows_per_task,
                                    int n_rows_total, int C, int n_actions, const uint8_t *frames, int32_t *actions,
-                                   float *logits, int32_t *status, void *workspace, void *timing_ctx, void *stream);
+                                   float *logits, int32_t *status, void *workspace, void *timing_ctx, int timed_kernel,
+                                   void *stream);
 /* bracket whatever is enqueued on `stream` between the two calls with the context's next timing event pair */
 int coevo_timing_begin(void *ctx, void *stream);
 int coevo_timing_end(void *ctx, void *stream);
