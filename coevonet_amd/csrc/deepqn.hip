@@ -229,18 +229,14 @@ __global__ __launch_bounds__(512, 2) void dqn_conv_kernel(const float *slab, con
     for (int i = t; i < DQ_FC1_IN; i += 512) dsta[i] = sm.a1[i];
 }
 
-// fc1 + ReLU: grid (task, 8), ONE wavefront per workgroup: it owns outputs [64*ob, +64) and streams their 802 KB
-// ([784][64][4] tile) exactly once for the task's <= 16 rows, 28 KiB in flight (only 8 wavefronts exist per net, so the
-// memory-level parallelism has to come from depth).  The activations of a chunk (rows x 28 k-quads) are staged in LDS
-// with coalesced loads and read back as broadcasts (scalar loads of them serialise: 12 500 dependent s_loads per wave).
 constexpr int DQ_RMAX = 16;
 // NG = row groups of four this task needs (ceil(rows / 4)): a one-frame task (Co-ES) issues a quarter of a 16-frame task's
 // MFMAs.  One launch serves tasks of every size: the kernel picks the instantiation by the task's own row count.
 template <int NG>
 __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &L, const coevo_dqn_task &task,
-                                             const float *act, float *hid, float (*xs)[28 * 4], int ob, int l)
+                                             const float *act, float *hid, float (*xs)[DQ_RMAX][14 * 4], int ob, int l)
 {
-    constexpr int U = 28;  // k-quads per chunk; 784 = 28 * 28
+    constexpr int U = 14;  // k-quads per chunk; 784 = 56 * 14; two chunks in flight (ping-pong)
     const int nrows = task.n_rows;
     const float bb = net[L.bf + 64 * ob + l];
     // rows in groups of four on v_mfma_f32_4x4x1_16B_f32 (16 blocks x 4 columns = the wave's 64 outputs, one k per
@@ -248,6 +244,7 @@ __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &
     // the B operand as is, the A operand x[4g + l%4][4q..4q+3] is one ds_read_b128 per group.  (As VALU FMAs fed by one
     // LDS broadcast per row this kernel ran at 1.4 TB/s.)
     typedef float f32x4_acc1 __attribute__((ext_vector_type(4)));
+    typedef float f32x4_nt __attribute__((ext_vector_type(4)));
     f32x4_acc1 acc[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
@@ -255,18 +252,16 @@ __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &
         for (int i = 0; i < 4; ++i) acc[g][i] = bb;
     const float4 *wp = reinterpret_cast<const float4 *>(net + L.wf) + (size_t)ob * 784 * 64 + l;
     const float *arow = act + (size_t)task.row_begin * DQ_FC1_IN;
-    for (int kq = 0; kq < 784; kq += U) {
-        float4 wv[U];
+    constexpr int XI = (4 * NG * U + 63) / 64;
+    float4 wA[U], wB[U], xA[XI], xB[XI];
+    // a chunk's weight pieces (read once per launch: non-temporal, keeps the conv weights / activations in L2) and its
+    // activations (rows x 14 float4 pieces, coalesced per row; pad rows: zeros), all requested together
+    auto issue = [&](float4 (&wv)[U], float4 (&xr)[XI], int kq) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {  // read once per launch: non-temporal, keeps the conv weights / activations in L2
-            typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+        for (int u = 0; u < U; ++u) {
             const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt *>(wp + (size_t)(kq + u) * 64));
             wv[u] = make_float4(v[0], v[1], v[2], v[3]);
         }
-        // the chunk's activations (rows x 28 float4 pieces, coalesced per row; pad rows: zeros): all requested at once,
-        // next to the weight loads (one iteration at a time they cost six serial memory latencies per chunk)
-        constexpr int XI = (4 * NG * U + 63) / 64;
-        float4 xr[XI];
 #pragma unroll
         for (int j = 0; j < XI; ++j) {
             const int i = l + 64 * j, r = i / U, q = i % U;
@@ -274,18 +269,19 @@ __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &
                         ? *reinterpret_cast<const float4 *>(arow + (size_t)r * DQ_FC1_IN + 4 * (kq + q))
                         : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        __syncthreads();  // the previous chunk's activations have been consumed
+    };
+    auto consume = [&](const float4 (&wv)[U], const float4 (&xr)[XI], float (*x_lds)[14 * 4]) {
 #pragma unroll
         for (int j = 0; j < XI; ++j) {
             const int i = l + 64 * j;
-            if (i < 4 * NG * U) *reinterpret_cast<float4 *>(&xs[i / U][4 * (i % U)]) = xr[j];
+            if (i < 4 * NG * U) *reinterpret_cast<float4 *>(&x_lds[i / U][4 * (i % U)]) = xr[j];
         }
-        __syncthreads();
+        __syncthreads();   // one wave per workgroup: orders the LDS round trip
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float4 x[NG];
 #pragma unroll
-            for (int g = 0; g < NG; ++g) x[g] = *reinterpret_cast<const float4 *>(&xs[4 * g + (l & 3)][4 * u]);
+            for (int g = 0; g < NG; ++g) x[g] = *reinterpret_cast<const float4 *>(&x_lds[4 * g + (l & 3)][4 * u]);
 #pragma unroll
             for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].x, wv[u].x, acc[g], 0, 0, 0);
 #pragma unroll
@@ -295,6 +291,18 @@ __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &
 #pragma unroll
             for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].w, wv[u].w, acc[g], 0, 0, 0);
         }
+    };
+    // ping-pong: while one chunk feeds the matrix pipe the next chunk's 14 KiB are in flight (the order pinned with
+    // sched_barrier; serially - load, wait, compute - the 56 memory latencies of a wave added up to half the kernel)
+    issue(wA, xA, 0);
+#pragma nounroll
+    for (int kq = 0; kq < 784; kq += 2 * U) {
+        issue(wB, xB, kq + U);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(wA, xA, xs[0]);
+        if (kq + 2 * U < 784) issue(wA, xA, kq + 2 * U);   // wave-uniform
+        __builtin_amdgcn_sched_barrier(0);
+        consume(wB, xB, xs[1]);
     }
 #pragma unroll
     for (int g = 0; g < NG; ++g)
@@ -306,12 +314,12 @@ __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &
 
 // fc1 + ReLU: grid (task, 8), ONE wavefront per workgroup: it owns outputs [64*ob, +64) and streams their 802 KB
 // ([784][64][4] tile) exactly once for the task's <= 16 rows, 28 KiB in flight (only 8 wavefronts exist per net, so the
-// memory-level parallelism has to come from depth).  The activations of a chunk (rows x 28 k-quads) are staged in LDS
+// memory-level parallelism has to come from depth).  The activations of a chunk (rows x 14 k-quads) are staged in LDS
 // with coalesced loads and read back as broadcasts (scalar loads of them serialise: 12 500 dependent s_loads per wave).
 __global__ __launch_bounds__(64) void dqn_fc1_kernel(const float *slab, const coevo_dqn_task *tasks, int C,
                                                       int n_actions, const float *act, float *hid)
 {
-    __shared__ __attribute__((aligned(16))) float xs[DQ_RMAX][28 * 4];
+    __shared__ __attribute__((aligned(16))) float xs[2][DQ_RMAX][14 * 4];
     const coevo_dqn_task task = tasks[blockIdx.x];
     const float *net = slab + task.net_off;
     const DqnLayout L = dqn_layout(C, n_actions);
