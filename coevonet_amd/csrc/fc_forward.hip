@@ -757,12 +757,20 @@ __device__ __forceinline__ void fc_policy_body_c(const FcArgs &a, FcSmemC<R> &sm
     COEVO_STAMP(6);
 }
 
+#ifndef COEVO_COMPACT
+#define COEVO_COMPACT 1   // 0: the unrolled per-individual body everywhere (A/B runs)
+#endif
 template <int R, int MODE>
 __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
 {
-    __shared__ FcSmem<R, 1> sm;
     stamp_begin(a.stamps);
-    fc_policy_body<R, MODE, 1>(a, sm, a.tasks, blockIdx.x, gridDim.x);
+    if constexpr (COEVO_COMPACT && MODE == MODE_FUSED && R <= 8) {   // fused env step: the body built for few instructions
+        __shared__ FcSmemC<R> smc;
+        fc_policy_body_c<R, MODE>(a, smc, a.tasks, blockIdx.x, gridDim.x);
+    } else {
+        __shared__ FcSmem<R, 1> sm;
+        fc_policy_body<R, MODE, 1>(a, sm, a.tasks, blockIdx.x, gridDim.x);
+    }
     stamp_end(a.stamps);
 }
 
@@ -1368,9 +1376,6 @@ __device__ __forceinline__ void fc_policy_mfma16_body(const FcArgs &a, FcMfma16S
 
 // The lean merged cycle launch: shared-opponent tasks of <= 16 rows (fc_policy_mfma16_body) + one per-individual net per
 // streaming workgroup, four workgroups per CU.
-#ifndef COEVO_COMPACT
-#define COEVO_COMPACT 1   // 0: the unrolled per-individual body (A/B runs)
-#endif
 template <int R>
 __global__ __launch_bounds__(256, 4) void fc_cycle16_kernel(FcArgs a)
 {
