@@ -44,31 +44,36 @@ __global__ __launch_bounds__(256) void dqn_pack_kernel(const float *flat, float 
 // The raw sums go to LDS as out[channel][position] (odd pitch); BatchNorm + ReLU then runs over them channel by channel.
 typedef float f32x4_acc __attribute__((ext_vector_type(4)));
 
-// tap t = (ci, ky, kx) in the canonical order -> offset of that input element relative to the window's corner.  conv1 and
-// conv2 have power-of-two windows (shifts); conv3's 3 x 3 comes from a compile-time table in global memory (L1-resident,
-// requested a chunk ahead like the weights) - an LDS table would cost the 2.3 KB that keep two workgroups on a CU.
-struct Tap3Table { int v[576]; };
-constexpr Tap3Table make_tap3()
-{
-    Tap3Table t{};
-    for (int i = 0; i < 576; ++i) t.v[i] = (i / 9) * 81 + ((i % 9) / 3) * 9 + (i % 3);   // ci * DQ_P2 + ky * 9 + kx
-    return t;
-}
-__device__ const Tap3Table g_tap3 = make_tap3();
+// Addressing is organised per chunk of QU = 8 k-steps (32 taps) so that the MFMA loop issues almost no address arithmetic
+// (SQ counters of the first 16x16x4 version: 4 VALU instructions per MFMA - 64-bit weight addresses, tap decoding - kept
+// the matrix pipe at 46 %): within a chunk the tap of k-step j, lane group kk is
+//   conv1 (8 x 8 window, t = 4 q + kk):  ci = q0 / 16, ky = (q0 / 2) % 8 + j / 2, kx = kk + 4 (j % 2)
+//   conv2 (4 x 4):                        ci = q0 / 4 + j / 4, ky = j % 4, kx = kk
+// i.e. one per-lane chunk base + a compile-time offset per j (an instruction immediate); conv3's 3 x 3 window does not
+// decompose that way: its offsets come from a 16-bit table in LDS (1.1 KB: still two workgroups per CU).
+template <int KS, int HIN, bool U8IN, int IN_PITCH, int CT>
+struct TapAddr {
+    // offset of tap (chunk q0, step j, lane group kk) = chunk_base(q0, kk) + rel(j)
+    __device__ static __forceinline__ int chunk_base(int q0, int kk, int cin)
+    {
+        if constexpr (KS == 8) {
+            const int ci = q0 >> 4, ky0 = (q0 >> 1) & 7;
+            return U8IN ? (ky0 * HIN + kk) * (CT ? CT : cin) + ci : ci * IN_PITCH + ky0 * HIN + kk;
+        } else {
+            return (q0 >> 2) * IN_PITCH + kk;
+        }
+    }
+    __device__ static __forceinline__ int rel(int j, int cin)
+    {
+        if constexpr (KS == 8) return U8IN ? ((j >> 1) * HIN + 4 * (j & 1)) * (CT ? CT : cin) : (j >> 1) * HIN + 4 * (j & 1);
+        else return (j >> 2) * IN_PITCH + (j & 3) * HIN;
+    }
+};
 
-template <int KS, int HIN, bool U8IN, int IN_PITCH>
-__device__ __forceinline__ int tap_offset(int t, int cin)
-{
-    if constexpr (KS == 8) return U8IN ? (((t >> 3) & 7) * HIN + (t & 7)) * cin + (t >> 6) : (t >> 6) * IN_PITCH + ((t >> 3) & 7) * HIN + (t & 7);
-    else if constexpr (KS == 4) return (t >> 4) * IN_PITCH + ((t >> 2) & 3) * HIN + (t & 3);
-    else return g_tap3.v[t];
-}
-
-template <int KS, int STRIDE, int HIN, int HOUT, int COUT, bool U8IN, int IN_PITCH, int OUT_PITCH>
+template <int KS, int STRIDE, int HIN, int HOUT, int COUT, bool U8IN, int IN_PITCH, int OUT_PITCH, int CT>
 __device__ __forceinline__ void conv16_mfma(const void *in_lds, const float *lut, int cin, int taps, const float *wt,
-                                            const float *bias, float *out, int w, int l)
+                                            const float *bias, float *out, const unsigned short *tap3, int w, int l)
 {
-    static_assert(KS != 3 || (IN_PITCH == 81 && HIN == 9 && !U8IN), "g_tap3 is conv3's table");
     constexpr int NPOS = HOUT * HOUT, NM = (NPOS + 15) / 16, NP = COUT / 32, NUNITS = NM * NP, MAXU = (NUNITS + 7) / 8;
     static_assert(8 % NP == 0, "all units of a wave share their channel pair");
     const int c = l & 15, kk = l >> 4, np = w % NP;
@@ -82,7 +87,7 @@ __device__ __forceinline__ void conv16_mfma(const void *in_lds, const float *lut
         int p = 16 * (u / NP) + c;
         if (!live[i] || p >= NPOS) p = 0;   // padded rows read position 0; their results are never stored
         const int oy = p / HOUT, ox = p % HOUT;
-        base[i] = U8IN ? ((oy * STRIDE) * HIN + ox * STRIDE) * cin : (oy * STRIDE) * HIN + ox * STRIDE;
+        base[i] = U8IN ? ((oy * STRIDE) * HIN + ox * STRIDE) * (CT ? CT : cin) : (oy * STRIDE) * HIN + ox * STRIDE;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const float bb = bias[32 * np + 16 * h + c];
@@ -90,42 +95,51 @@ __device__ __forceinline__ void conv16_mfma(const void *in_lds, const float *lut
             for (int r = 0; r < 4; ++r) acc[i][h][r] = bb;
         }
     }
-    const float *wcol = wt + 32 * np + c;
-    constexpr int QU = 8;   // k-steps per chunk: their weight operands and tap offsets are requested together, one chunk
-                            // AHEAD of the MFMAs that use them (an L2 round trip per chunk would otherwise be exposed:
-                            // conv2 / conv3 have only one or two units per wave to hide it behind)
+    constexpr int QU = 8;   // k-steps per chunk: their weight operands are requested together, one chunk AHEAD of the
+                            // MFMAs that use them (an L2 round trip per chunk would otherwise be exposed: conv2 / conv3
+                            // have only one or two units per wave to hide it behind)
+    const float *wlane = wt + (size_t)kk * COUT + 32 * np + c;   // this lane's column of B, rows kk, kk + 4, ...
     float bvA[QU][2], bvB[QU][2];
-    int toA[QU], toB[QU];
-    auto issue = [&](float (&bv)[QU][2], int (&to)[QU], int q0) {
+    int cbA, cbB;            // chunk bases (conv1 / conv2) ...
+    int toA[QU], toB[QU];    // ... or the table offsets (conv3)
+    auto issue = [&](float (&bv)[QU][2], int &cb, int (&to)[QU], int q0) {
+        const float *wq = wlane + (size_t)q0 * 4 * COUT;
 #pragma unroll
         for (int j = 0; j < QU; ++j) {
-            const int t = 4 * (q0 + j) + kk;
-            bv[j][0] = wcol[(size_t)t * COUT];
-            bv[j][1] = wcol[(size_t)t * COUT + 16];
-            to[j] = tap_offset<KS, HIN, U8IN, IN_PITCH>(t, cin);
+            bv[j][0] = wq[j * 4 * COUT];
+            bv[j][1] = wq[j * 4 * COUT + 16];
+        }
+        if constexpr (KS == 3) {
+#pragma unroll
+            for (int j = 0; j < QU; ++j) to[j] = tap3[4 * (q0 + j) + kk];
+        } else {
+            cb = TapAddr<KS, HIN, U8IN, IN_PITCH, CT>::chunk_base(q0, kk, cin);
         }
     };
-    auto consume = [&](const float (&bv)[QU][2], const int (&to)[QU]) {
+    auto consume = [&](const float (&bv)[QU][2], int cb, const int (&to)[QU]) {
 #pragma unroll
         for (int j = 0; j < QU; ++j) {
 #pragma unroll
             for (int i = 0; i < MAXU; ++i) {
                 if (!live[i]) continue;   // wave-uniform
+                int off;
+                if constexpr (KS == 3) off = base[i] + to[j];
+                else off = base[i] + cb + TapAddr<KS, HIN, U8IN, IN_PITCH, CT>::rel(j, cin);
                 float av;
-                if constexpr (U8IN) av = lut[static_cast<const unsigned char *>(in_lds)[base[i] + to[j]]];
-                else av = static_cast<const float *>(in_lds)[base[i] + to[j]];
+                if constexpr (U8IN) av = lut[static_cast<const unsigned char *>(in_lds)[off]];
+                else av = static_cast<const float *>(in_lds)[off];
                 acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j][0], acc[i][0], 0, 0, 0);
                 acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j][1], acc[i][1], 0, 0, 0);
             }
         }
     };
     const int nq = taps / 4;   // a multiple of 2 * QU for every layer (C * 16, 128, 144)
-    issue(bvA, toA, 0);
+    issue(bvA, cbA, toA, 0);
     for (int q0 = 0; q0 < nq; q0 += 2 * QU) {
-        issue(bvB, toB, q0 + QU);
-        consume(bvA, toA);
-        if (q0 + 2 * QU < nq) issue(bvA, toA, q0 + 2 * QU);
-        consume(bvB, toB);
+        issue(bvB, cbB, toB, q0 + QU);
+        consume(bvA, cbA, toA);
+        if (q0 + 2 * QU < nq) issue(bvA, cbA, toA, q0 + 2 * QU);
+        consume(bvB, cbB, toB);
     }
 #pragma unroll
     for (int i = 0; i < MAXU; ++i) {
@@ -174,6 +188,7 @@ constexpr int DQ_P1 = 401, DQ_P2 = 81, DQ_P3 = 49;   // channel pitches of the a
 template <int CMAX>
 struct DqnSmem {
     float lut[256];
+    unsigned short tap3[576];                      // conv3's tap offsets ci * 81 + ky * 9 + kx
     float a1[32 * DQ_P1];                          // conv1 activations; later conv3's [64][49]
     union {
         unsigned char frame[84 * 84 * CMAX + 16];  // the uint8 HWC frame (dead after conv1)
@@ -195,8 +210,9 @@ __device__ __forceinline__ int task_of_row(const coevo_dqn_task *tasks, int n_ta
     return lo;
 }
 
-template <int CMAX>
-__global__ __launch_bounds__(512, 2) void dqn_conv_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks,
+// CT: the channel count as a compile-time constant (4 or 6: the gather offsets become instruction immediates), 0 = run time
+template <int CMAX, int CT>
+__global__ __launch_bounds__(512, CMAX <= 4 ? 4 : 2) void dqn_conv_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks,
                                                            int C, int n_actions, const uint8_t *frames, float *act)
 {
     __shared__ __attribute__((aligned(16))) DqnSmem<CMAX> sm;
@@ -211,16 +227,17 @@ __global__ __launch_bounds__(512, 2) void dqn_conv_kernel(const float *slab, con
     uint4 *dst = reinterpret_cast<uint4 *>(sm.frame);
     for (int i = t; i < nbytes / 16; i += 512) dst[i] = src[i];
     if (t < 256) sm.lut[t] = (float)t / 255.0f;
+    for (int i = t; i < 576; i += 512) sm.tap3[i] = (unsigned short)((i / 9) * DQ_P2 + ((i % 9) / 3) * 9 + (i % 3));
     __syncthreads();
-    conv16_mfma<8, 4, 84, 20, 32, true, 0, DQ_P1>(sm.frame, sm.lut, C, C * 64, net + L.w1, net + L.b1, sm.a1, w, l);
+    conv16_mfma<8, 4, 84, 20, 32, true, 0, DQ_P1, CT>(sm.frame, sm.lut, C, C * 64, net + L.w1, net + L.b1, sm.a1, nullptr, w, l);
     __syncthreads();
     bn_relu_rows<400, DQ_P1, 32>(sm.a1, net + L.b1 + 32, net + L.b1 + 64, w, l);
     __syncthreads();
-    conv16_mfma<4, 2, 20, 9, 64, false, DQ_P1, DQ_P2>(sm.a1, nullptr, 32, 512, net + L.w2, net + L.b2, sm.a2, w, l);
+    conv16_mfma<4, 2, 20, 9, 64, false, DQ_P1, DQ_P2, 0>(sm.a1, nullptr, 32, 512, net + L.w2, net + L.b2, sm.a2, nullptr, w, l);
     __syncthreads();
     bn_relu_rows<81, DQ_P2, 64>(sm.a2, net + L.b2 + 64, net + L.b2 + 128, w, l);
     __syncthreads();
-    conv16_mfma<3, 1, 9, 7, 64, false, DQ_P2, DQ_P3>(sm.a2, nullptr, 64, 576, net + L.w3, net + L.b3, sm.a1, w, l);
+    conv16_mfma<3, 1, 9, 7, 64, false, DQ_P2, DQ_P3, 0>(sm.a2, nullptr, 64, 576, net + L.w3, net + L.b3, sm.a1, sm.tap3, w, l);
     __syncthreads();
     bn_relu_rows<49, DQ_P3, 64>(sm.a1, net + L.b3 + 64, net + L.b3 + 128, w, l);
     __syncthreads();
@@ -412,12 +429,11 @@ extern "C" int coevo_dqn_forward_argmax_timed(const float *slab, const coevo_dqn
     hipStream_t s = (hipStream_t)stream;
     if (timing_ctx && (timed_kernel < 0 || timed_kernel > 1)) return COEVO_ERR_ARG;
     if (timing_ctx && timed_kernel == 0 && coevo_timing_begin(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
-    if (C <= 4)
-        hipLaunchKernelGGL(dqn_conv_kernel<4>, dim3(n_rows_total), dim3(512), 0, s, slab, tasks, n_tasks, C, n_actions,
-                           frames, act);
-    else
-        hipLaunchKernelGGL(dqn_conv_kernel<6>, dim3(n_rows_total), dim3(512), 0, s, slab, tasks, n_tasks, C, n_actions,
-                           frames, act);
+    const dim3 cg(n_rows_total), cb(512);
+    if (C == 4) hipLaunchKernelGGL((dqn_conv_kernel<4, 4>), cg, cb, 0, s, slab, tasks, n_tasks, C, n_actions, frames, act);
+    else if (C < 4) hipLaunchKernelGGL((dqn_conv_kernel<4, 0>), cg, cb, 0, s, slab, tasks, n_tasks, C, n_actions, frames, act);
+    else if (C == 6) hipLaunchKernelGGL((dqn_conv_kernel<6, 6>), cg, cb, 0, s, slab, tasks, n_tasks, C, n_actions, frames, act);
+    else hipLaunchKernelGGL((dqn_conv_kernel<6, 0>), cg, cb, 0, s, slab, tasks, n_tasks, C, n_actions, frames, act);
     if (timing_ctx && timed_kernel == 0 && coevo_timing_end(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     if (timing_ctx && timed_kernel == 1 && coevo_timing_begin(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     hipLaunchKernelGGL(dqn_fc1_kernel, dim3(n_tasks, 8), dim3(64), 0, s, slab, tasks, C, n_actions, act, hid);
