@@ -70,7 +70,7 @@ struct TapAddr {
     }
 };
 
-template <int KS, int STRIDE, int HIN, int HOUT, int COUT, bool U8IN, int IN_PITCH, int OUT_PITCH, int CT>
+template <int KS, int STRIDE, int HIN, int HOUT, int COUT, bool U8IN, int IN_PITCH, int OUT_PITCH, int CT, int QU>
 __device__ __forceinline__ void conv16_mfma(const void *in_lds, const float *lut, int cin, int taps, const float *wt,
                                             const float *bias, float *out, const unsigned short *tap3, int w, int l)
 {
@@ -95,19 +95,26 @@ __device__ __forceinline__ void conv16_mfma(const void *in_lds, const float *lut
             for (int r = 0; r < 4; ++r) acc[i][h][r] = bb;
         }
     }
-    constexpr int QU = 8;   // k-steps per chunk: their weight operands are requested together, one chunk AHEAD of the
-                            // MFMAs that use them (an L2 round trip per chunk would otherwise be exposed: conv2 / conv3
-                            // have only one or two units per wave to hide it behind)
-    const float *wlane = wt + (size_t)kk * COUT + 32 * np + c;   // this lane's column of B, rows kk, kk + 4, ...
+    // QU = k-steps per chunk: their weight operands are requested together, one chunk AHEAD of the MFMAs that use them (an
+    // L2 round trip per chunk would otherwise be exposed: conv2 / conv3 have only one or two units per wave to hide it behind)
+    // this lane's B operands: one float4 per k-step pair (layout: dqn_common.hip.h dqn_conv_slab_to_flat)
+    const float4 *wlane = reinterpret_cast<const float4 *>(wt) + np * 64 + l;
     float bvA[QU][2], bvB[QU][2];
     int cbA, cbB;            // chunk bases (conv1 / conv2) ...
     int toA[QU], toB[QU];    // ... or the table offsets (conv3)
     auto issue = [&](float (&bv)[QU][2], int &cb, int (&to)[QU], int q0) {
-        const float *wq = wlane + (size_t)q0 * 4 * COUT;
+        const float4 *wq = wlane + (size_t)(q0 >> 1) * (NP * 64);
 #pragma unroll
-        for (int j = 0; j < QU; ++j) {
-            bv[j][0] = wq[j * 4 * COUT];
-            bv[j][1] = wq[j * 4 * COUT + 16];
+        for (int jp = 0; jp < QU / 2; ++jp) {
+#if defined(DQ_EXP) && (DQ_EXP & 2)
+            const float4 v = make_float4(__int_as_float(q0 + jp + l), __int_as_float(q0 + jp + l + 16), 0.f, 1.f);
+#else
+            const float4 v = wq[jp * NP * 64];
+#endif
+            bv[2 * jp][0] = v.x;
+            bv[2 * jp][1] = v.y;
+            bv[2 * jp + 1][0] = v.z;
+            bv[2 * jp + 1][1] = v.w;
         }
         if constexpr (KS == 3) {
 #pragma unroll
@@ -126,18 +133,23 @@ __device__ __forceinline__ void conv16_mfma(const void *in_lds, const float *lut
                 if constexpr (KS == 3) off = base[i] + to[j];
                 else off = base[i] + cb + TapAddr<KS, HIN, U8IN, IN_PITCH, CT>::rel(j, cin);
                 float av;
+#if defined(DQ_EXP) && (DQ_EXP & 1)
+                av = __int_as_float(off);
+#else
                 if constexpr (U8IN) av = lut[static_cast<const unsigned char *>(in_lds)[off]];
                 else av = static_cast<const float *>(in_lds)[off];
+#endif
                 acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j][0], acc[i][0], 0, 0, 0);
                 acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j][1], acc[i][1], 0, 0, 0);
             }
         }
     };
-    const int nq = taps / 4;   // a multiple of 2 * QU for every layer (C * 16, 128, 144)
+    const int nq = taps / 4;   // a multiple of QU for every layer (C * 16, 128, 144)
     issue(bvA, cbA, toA, 0);
     for (int q0 = 0; q0 < nq; q0 += 2 * QU) {
-        issue(bvB, cbB, toB, q0 + QU);
+        if (q0 + QU < nq) issue(bvB, cbB, toB, q0 + QU);
         consume(bvA, cbA, toA);
+        if (q0 + QU >= nq) break;
         if (q0 + 2 * QU < nq) issue(bvA, cbA, toA, q0 + 2 * QU);
         consume(bvB, cbB, toB);
     }
@@ -163,6 +175,9 @@ template <int NPOS, int PITCH, int COUT>
 __device__ __forceinline__ void bn_relu_rows(float *x, const float *gamma, const float *beta, int w, int l)
 {
     constexpr int NB = (NPOS + 63) / 64;
+#if defined(DQ_EXP) && (DQ_EXP & 4)
+    return;
+#endif
     for (int ch = w; ch < COUT; ch += 8) {
         float *row = x + ch * PITCH;
         float v[NB], sq[NB];
@@ -183,6 +198,15 @@ __device__ __forceinline__ void bn_relu_rows(float *x, const float *gamma, const
     }
 }
 
+#ifndef DQ_QU1
+#define DQ_QU1 8
+#endif
+#ifndef DQ_QU2
+#define DQ_QU2 8
+#endif
+#ifndef DQ_QU3
+#define DQ_QU3 8
+#endif
 constexpr int DQ_P1 = 401, DQ_P2 = 81, DQ_P3 = 49;   // channel pitches of the activation images (odd: conflict-free columns)
 
 template <int CMAX>
@@ -210,18 +234,39 @@ __device__ __forceinline__ int task_of_row(const coevo_dqn_task *tasks, int n_ta
     return lo;
 }
 
+#ifdef COEVO_PHASE_STAMPS
+// diagnostic build only (tools/dqn_conv_phases.py): wave 0's arrival at each phase boundary, 100 MHz constant clock
+__device__ unsigned long long g_dqn_stamps[2048 * 16];
+#define DQ_STAMP(i)                                                                                   \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x < 2048) g_dqn_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define DQ_STAMP(i) do { } while (0)
+#endif
+
 // CT: the channel count as a compile-time constant (4 or 6: the gather offsets become instruction immediates), 0 = run time
 template <int CMAX, int CT>
 __global__ __launch_bounds__(512, CMAX <= 4 ? 4 : 2) void dqn_conv_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks,
-                                                           int C, int n_actions, const uint8_t *frames, float *act)
+                                                           int n_rows, int C, int n_actions, const uint8_t *frames, float *act)
 {
     __shared__ __attribute__((aligned(16))) DqnSmem<CMAX> sm;
-    const int row = blockIdx.x;   // one workgroup per frame; its task by binary search (tasks ascend in row_begin)
+    // one workgroup per frame; its task by binary search (tasks ascend in row_begin).  Workgroups are dealt to the 8 XCDs
+    // round robin: XCD x takes the contiguous rows [x * per, (x + 1) * per), so the frames of one net meet in ONE L2 (and,
+    // dispatched back to back, on one CU's L1) instead of pulling every net's conv weights into all eight.
+#ifdef DQ_NO_XCD_MAP
+    const int row = blockIdx.x;
+#else
+    const int per = gridDim.x >> 3;
+    const int row = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (row >= n_rows) return;   // workgroup-uniform
+#endif
     const coevo_dqn_task task = tasks[task_of_row(tasks, n_tasks, row)];
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
     const float *net = slab + task.net_off;
     const DqnLayout L = dqn_layout(C, n_actions);
     // stage the frame (84*84*C bytes, a multiple of 16) and the /255 table (exact fp32 quotients)
+    DQ_STAMP(0);
     const int nbytes = 84 * 84 * C;
     const uint4 *src = reinterpret_cast<const uint4 *>(frames + (size_t)row * nbytes);
     uint4 *dst = reinterpret_cast<uint4 *>(sm.frame);
@@ -229,21 +274,29 @@ __global__ __launch_bounds__(512, CMAX <= 4 ? 4 : 2) void dqn_conv_kernel(const 
     if (t < 256) sm.lut[t] = (float)t / 255.0f;
     for (int i = t; i < 576; i += 512) sm.tap3[i] = (unsigned short)((i / 9) * DQ_P2 + ((i % 9) / 3) * 9 + (i % 3));
     __syncthreads();
-    conv16_mfma<8, 4, 84, 20, 32, true, 0, DQ_P1, CT>(sm.frame, sm.lut, C, C * 64, net + L.w1, net + L.b1, sm.a1, nullptr, w, l);
+    DQ_STAMP(1);
+    conv16_mfma<8, 4, 84, 20, 32, true, 0, DQ_P1, CT, DQ_QU1>(sm.frame, sm.lut, C, C * 64, net + L.w1, net + L.b1, sm.a1, nullptr, w, l);
     __syncthreads();
+    DQ_STAMP(2);
     bn_relu_rows<400, DQ_P1, 32>(sm.a1, net + L.b1 + 32, net + L.b1 + 64, w, l);
     __syncthreads();
-    conv16_mfma<4, 2, 20, 9, 64, false, DQ_P1, DQ_P2, 0>(sm.a1, nullptr, 32, 512, net + L.w2, net + L.b2, sm.a2, nullptr, w, l);
+    DQ_STAMP(3);
+    conv16_mfma<4, 2, 20, 9, 64, false, DQ_P1, DQ_P2, 0, DQ_QU2>(sm.a1, nullptr, 32, 512, net + L.w2, net + L.b2, sm.a2, nullptr, w, l);
     __syncthreads();
+    DQ_STAMP(4);
     bn_relu_rows<81, DQ_P2, 64>(sm.a2, net + L.b2 + 64, net + L.b2 + 128, w, l);
     __syncthreads();
-    conv16_mfma<3, 1, 9, 7, 64, false, DQ_P2, DQ_P3, 0>(sm.a2, nullptr, 64, 576, net + L.w3, net + L.b3, sm.a1, sm.tap3, w, l);
+    DQ_STAMP(5);
+    conv16_mfma<3, 1, 9, 7, 64, false, DQ_P2, DQ_P3, 0, DQ_QU3>(sm.a2, nullptr, 64, 576, net + L.w3, net + L.b3, sm.a1, sm.tap3, w, l);
     __syncthreads();
+    DQ_STAMP(6);
     bn_relu_rows<49, DQ_P3, 64>(sm.a1, net + L.b3 + 64, net + L.b3 + 128, w, l);
     __syncthreads();
+    DQ_STAMP(7);
     // flatten in CHW order (Atari/deepqn.py:45): channel pitch 49 = the flat layout itself
     float *dsta = act + (size_t)row * DQ_FC1_IN;
     for (int i = t; i < DQ_FC1_IN; i += 512) dsta[i] = sm.a1[i];
+    DQ_STAMP(8);
 }
 
 constexpr int DQ_RMAX = 16;
@@ -429,11 +482,11 @@ extern "C" int coevo_dqn_forward_argmax_timed(const float *slab, const coevo_dqn
     hipStream_t s = (hipStream_t)stream;
     if (timing_ctx && (timed_kernel < 0 || timed_kernel > 1)) return COEVO_ERR_ARG;
     if (timing_ctx && timed_kernel == 0 && coevo_timing_begin(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
-    const dim3 cg(n_rows_total), cb(512);
-    if (C == 4) hipLaunchKernelGGL((dqn_conv_kernel<4, 4>), cg, cb, 0, s, slab, tasks, n_tasks, C, n_actions, frames, act);
-    else if (C < 4) hipLaunchKernelGGL((dqn_conv_kernel<4, 0>), cg, cb, 0, s, slab, tasks, n_tasks, C, n_actions, frames, act);
-    else if (C == 6) hipLaunchKernelGGL((dqn_conv_kernel<6, 6>), cg, cb, 0, s, slab, tasks, n_tasks, C, n_actions, frames, act);
-    else hipLaunchKernelGGL((dqn_conv_kernel<6, 0>), cg, cb, 0, s, slab, tasks, n_tasks, C, n_actions, frames, act);
+    const dim3 cg(8 * ((n_rows_total + 7) / 8)), cb(512);   // a multiple of 8: the kernel's XCD-aware row mapping
+    if (C == 4) hipLaunchKernelGGL((dqn_conv_kernel<4, 4>), cg, cb, 0, s, slab, tasks, n_tasks, n_rows_total, C, n_actions, frames, act);
+    else if (C < 4) hipLaunchKernelGGL((dqn_conv_kernel<4, 0>), cg, cb, 0, s, slab, tasks, n_tasks, n_rows_total, C, n_actions, frames, act);
+    else if (C == 6) hipLaunchKernelGGL((dqn_conv_kernel<6, 6>), cg, cb, 0, s, slab, tasks, n_tasks, n_rows_total, C, n_actions, frames, act);
+    else hipLaunchKernelGGL((dqn_conv_kernel<6, 0>), cg, cb, 0, s, slab, tasks, n_tasks, n_rows_total, C, n_actions, frames, act);
     if (timing_ctx && timed_kernel == 0 && coevo_timing_end(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     if (timing_ctx && timed_kernel == 1 && coevo_timing_begin(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     hipLaunchKernelGGL(dqn_fc1_kernel, dim3(n_tasks, 8), dim3(64), 0, s, slab, tasks, C, n_actions, act, hid);
@@ -443,3 +496,11 @@ extern "C" int coevo_dqn_forward_argmax_timed(const float *slab, const coevo_dqn
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }
+
+#ifdef COEVO_PHASE_STAMPS
+extern "C" int coevo_debug_read_dqn_stamps(unsigned long long *host_out, int n_words)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(coevo::g_dqn_stamps), sizeof(unsigned long long) * n_words) ==
+                   hipSuccess ? 0 : -2;
+}
+#endif

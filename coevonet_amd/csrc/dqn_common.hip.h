@@ -33,6 +33,20 @@ __host__ __device__ inline int64_t dqn_param_count(int C, int n)
     return 32LL * C * 64 + 32 + 64LL * 512 + 64 + 64LL * 576 + 64 + 512LL * DQ_FC1_IN + 512 + 512LL * n + n + 320;
 }
 
+// Conv weights are stored in the order the implicit-GEMM kernel's lanes consume them (deepqn.hip conv16_mfma): position
+// i = ((qp * NP + np) * 64 + lane) * 4 + e holds W[co = 32 np + 16 (e & 1) + lane % 16][tap = 4 (2 qp + e / 2) + lane / 16]
+// (NP = COUT / 32, taps in the canonical (ci, ky, kx) order), so one 16-byte load per lane brings the B operands of two
+// k-steps x two channel tiles and a wave reads 1 KB contiguously.  (As [tap][cout] every operand was its own dword
+// load: the texture addresser spends 16 cycles on a wave's load whatever its width, and conv3 - two loads per two
+// MFMAs - ran at its pace, not the matrix pipe's.)  Returns co * taps + tap.
+__host__ __device__ inline int64_t dqn_conv_slab_to_flat(int64_t i, int cout, int64_t taps)
+{
+    const int64_t np_count = cout / 32;
+    const int64_t e = i & 3, lane = (i >> 2) & 63, blk = i >> 8, np = blk % np_count, qp = blk / np_count;
+    const int64_t co = 32 * np + 16 * (e & 1) + (lane & 15), tap = 4 * (2 * qp + (e >> 1)) + (lane >> 4);
+    return co * taps + tap;
+}
+
 // slab position -> canonical flat index (parameters() order: conv1.w conv1.b conv2.w conv2.b conv3.w conv3.b fc1.w
 // fc1.b output.w output.b vbn1.w vbn1.b vbn2.w vbn2.b vbn3.w vbn3.b); -1 for padding
 __host__ __device__ inline int64_t dqn_slab_to_flat(int64_t s, int C, int n)
@@ -44,11 +58,11 @@ __host__ __device__ inline int64_t dqn_slab_to_flat(int64_t s, int C, int n)
                   F_bo = F_wo + 512LL * n, F_g1 = F_bo + n, F_be1 = F_g1 + 32, F_g2 = F_be1 + 32, F_be2 = F_g2 + 64,
                   F_g3 = F_be2 + 64, F_be3 = F_g3 + 64;
     if (s >= L.total) return -1;
-    if (s < L.b1) { const int64_t t = s / 32, co = s % 32; return F_w1 + co * T1 + t; }
+    if (s < L.b1) return F_w1 + dqn_conv_slab_to_flat(s, 32, T1);
     if (s < L.w2) { const int64_t i = s - L.b1; return i < 32 ? F_b1 + i : (i < 64 ? F_g1 + i - 32 : F_be1 + i - 64); }
-    if (s < L.b2) { const int64_t i = s - L.w2, t = i / 64, co = i % 64; return F_w2 + co * 512 + t; }
+    if (s < L.b2) return F_w2 + dqn_conv_slab_to_flat(s - L.w2, 64, 512);
     if (s < L.w3) { const int64_t i = s - L.b2; return i < 64 ? F_b2 + i : (i < 128 ? F_g2 + i - 64 : F_be2 + i - 128); }
-    if (s < L.b3) { const int64_t i = s - L.w3, t = i / 64, co = i % 64; return F_w3 + co * 576 + t; }
+    if (s < L.b3) return F_w3 + dqn_conv_slab_to_flat(s - L.w3, 64, 576);
     if (s < L.wf) { const int64_t i = s - L.b3; return i < 64 ? F_b3 + i : (i < 128 ? F_g3 + i - 64 : F_be3 + i - 128); }
     if (s < L.bf) {  // wfq[ob][kq][l][c] = fc1.w[64 ob + l][4 kq + c]
         const int64_t i = s - L.wf, c = i & 3, l = (i >> 2) & 63, kq = (i >> 8) % 784, ob = (i >> 8) / 784;

@@ -39,3 +39,20 @@ alg = a.nets * P * 4 + rows * 84 * 84 * a.C
 flops = rows * 2 * (a.C * 64 * 32 * 400 + 512 * 64 * 81 + 576 * 64 * 49 + 3136 * 512 + 512 * a.actions)
 print(f"DeepQN step: {a.nets} nets x {a.rows} frames: {ms:.3f} ms  -> {rows / ms * 1e3:.0f} frames/s, "
       f"{alg / ms / 1e6:.0f} GB/s algorithmic ({alg / 1e6:.0f} MB), {flops / ms / 1e9:.1f} TFLOP/s fp32")
+
+# diagnostic build (COEVO_EXTRA_FLAGS=-DCOEVO_PHASE_STAMPS): where a frame's workgroup spends its time
+import ctypes as C
+dll = L.load()
+if hasattr(dll, "coevo_debug_read_dqn_stamps"):
+    n = min(rows, 2048)
+    buf = (C.c_ulonglong * (n * 16))()
+    dll.coevo_debug_read_dqn_stamps.argtypes = [C.c_void_p, C.c_int]
+    assert dll.coevo_debug_read_dqn_stamps(buf, n * 16) == 0
+    st = np.frombuffer(buf, dtype=np.uint64).reshape(n, 16).astype(np.int64)
+    names = ["stage frame", "conv1", "bn1", "conv2", "bn2", "conv3", "bn3", "store act"]
+    d = (st[:, 1:9] - st[:, 0:8]) / 100.0
+    for i, nm in enumerate(names):
+        print(f"  {nm:12s} mean {d[:, i].mean():7.2f} us  min {d[:, i].min():7.2f}  max {d[:, i].max():7.2f}")
+    tot = (st[:, 8] - st[:, 0]) / 100.0
+    print(f"  workgroup total mean {tot.mean():.2f} us; launch span {(st[:, 8].max() - st[:, 0].min()) / 100.0:.1f} us; "
+          f"starts spread {(st[:, 0].max() - st[:, 0].min()) / 100.0:.1f} us")
