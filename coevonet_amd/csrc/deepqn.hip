@@ -5,7 +5,7 @@
 //
 // Three launches per env step:
 //   dqn_conv_kernel   one workgroup (8 waves) per frame: the uint8 HWC frame is staged in LDS once (coalesced 16-byte
-//                     loads), /255 through a 256-entry LDS table (exact fp32 quotients), the three convolutions run as
+//                     loads), /255 as an exact two-term product (u8_over_255), the three convolutions run as
 //                     implicit GEMMs on v_mfma_f32_16x16x4_f32 (A = im2col gather out of LDS, B = weights [tap][cout]
 //                     from L2), BatchNorm statistics are reduced channel by channel in the canonical tree order by packed
 //                     butterflies, activations stay in LDS between layers; conv3's output goes to HBM as act[row][3136].
@@ -44,6 +44,19 @@ __global__ __launch_bounds__(256) void dqn_pack_kernel(const float *flat, float 
 // The raw sums go to LDS as out[channel][position] (odd pitch); BatchNorm + ReLU then runs over them channel by channel.
 typedef float f32x4_acc __attribute__((ext_vector_type(4)));
 
+// x / 255.0f for x = 0 .. 255, correctly rounded, without the divide: 1/255 split into a float head and tail,
+// fma(x, head, x * tail) equals the IEEE quotient for all 256 inputs (tests/test_host_logic_cpu.py checks the identity
+// in numpy; an LDS table of the quotients cost a dependent, bank-conflicted read per gathered tap)
+__device__ __forceinline__ float u8_over_255(unsigned b)
+{
+    constexpr float HEAD = (float)(1.0 / 255.0), TAIL = (float)(1.0 / 255.0 - (double)HEAD);
+    const float x = (float)b;
+#ifdef DQ_DIV255
+    return x / 255.0f;
+#endif
+    return __builtin_fmaf(x, HEAD, x * TAIL);
+}
+
 // Addressing is organised per chunk of QU = 8 k-steps (32 taps) so that the MFMA loop issues almost no address arithmetic
 // (SQ counters of the first 16x16x4 version: 4 VALU instructions per MFMA - 64-bit weight addresses, tap decoding - kept
 // the matrix pipe at 46 %): within a chunk the tap of k-step j, lane group kk is
@@ -71,99 +84,154 @@ struct TapAddr {
 };
 
 template <int KS, int STRIDE, int HIN, int HOUT, int COUT, bool U8IN, int IN_PITCH, int OUT_PITCH, int CT, int QU>
-__device__ __forceinline__ void conv16_mfma(const void *in_lds, const float *lut, int cin, int taps, const float *wt,
-                                            const float *bias, float *out, const unsigned short *tap3, int w, int l)
-{
-    constexpr int NPOS = HOUT * HOUT, NM = (NPOS + 15) / 16, NP = COUT / 32, NUNITS = NM * NP, MAXU = (NUNITS + 7) / 8;
+struct Conv16 {
+    static constexpr int NPOS = HOUT * HOUT, NM = (NPOS + 15) / 16, NP = COUT / 32, NUNITS = NM * NP;
+    // SPLIT (conv1: 25 units on 8 waves): every wave takes three whole units and the 25th is halved between waves 0 and 1
+    // (they sit on different SIMDs), one channel tile each: 7 MFMAs per k-step on the critical waves instead of 8
+#ifdef DQ_NO_SPLIT
+    static constexpr bool SPLIT = false;
+#else
+    static constexpr bool SPLIT = (NP == 1) && (NUNITS % 8 == 1);
+#endif
+    static constexpr int NFULL = NUNITS / 8, REM = SPLIT ? 0 : NUNITS % 8;   // waves w < REM carry NFULL + 1 units
     static_assert(8 % NP == 0, "all units of a wave share their channel pair");
-    const int c = l & 15, kk = l >> 4, np = w % NP;
-    f32x4_acc acc[MAXU][2];
-    int base[MAXU];
-    bool live[MAXU];
+    using Tap = TapAddr<KS, HIN, U8IN, IN_PITCH, CT>;
+
+    // NU whole units (+ the half unit when XL) of wave w, as straight-line code: the unit count is a template argument so
+    // that the k-loop has no branches and the scheduler can move a k-step's gathers above the previous step's MFMAs
+    template <int NU, bool XL>
+    static __device__ __forceinline__ void run(const void *in_lds, int cin, int taps, const float *wt, const float *bias,
+                                               float *out, const unsigned short *tap3, int w, int l)
+    {
+        const int c = l & 15, kk = l >> 4, np = w % NP;
+        constexpr int NA = NU > 0 ? NU : 1;
+        f32x4_acc acc[NA][2], accx;
+        int base[NA], xbase = 0;
+        auto tile_base = [&](int m) {
+            int p = 16 * m + c;
+            if (p >= NPOS) p = 0;   // padded rows read position 0; their results are never stored
+            const int oy = p / HOUT, ox = p % HOUT;
+            return U8IN ? ((oy * STRIDE) * HIN + ox * STRIDE) * (CT ? CT : cin) : (oy * STRIDE) * HIN + ox * STRIDE;
+        };
 #pragma unroll
-    for (int i = 0; i < MAXU; ++i) {
-        const int u = w + 8 * i;
-        live[i] = u < NUNITS;
-        int p = 16 * (u / NP) + c;
-        if (!live[i] || p >= NPOS) p = 0;   // padded rows read position 0; their results are never stored
-        const int oy = p / HOUT, ox = p % HOUT;
-        base[i] = U8IN ? ((oy * STRIDE) * HIN + ox * STRIDE) * (CT ? CT : cin) : (oy * STRIDE) * HIN + ox * STRIDE;
+        for (int i = 0; i < NU; ++i) {
+            base[i] = tile_base((w + 8 * i) / NP);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float bb = bias[32 * np + 16 * h + c];
+            for (int h = 0; h < 2; ++h) {
+                const float bb = bias[32 * np + 16 * h + c];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][h][r] = bb;
-        }
-    }
-    // QU = k-steps per chunk: their weight operands are requested together, one chunk AHEAD of the MFMAs that use them (an
-    // L2 round trip per chunk would otherwise be exposed: conv2 / conv3 have only one or two units per wave to hide it behind)
-    // this lane's B operands: one float4 per k-step pair (layout: dqn_common.hip.h dqn_conv_slab_to_flat)
-    const float4 *wlane = reinterpret_cast<const float4 *>(wt) + np * 64 + l;
-    float bvA[QU][2], bvB[QU][2];
-    int cbA, cbB;            // chunk bases (conv1 / conv2) ...
-    int toA[QU], toB[QU];    // ... or the table offsets (conv3)
-    auto issue = [&](float (&bv)[QU][2], int &cb, int (&to)[QU], int q0) {
-        const float4 *wq = wlane + (size_t)(q0 >> 1) * (NP * 64);
-#pragma unroll
-        for (int jp = 0; jp < QU / 2; ++jp) {
-#if defined(DQ_EXP) && (DQ_EXP & 2)
-            const float4 v = make_float4(__int_as_float(q0 + jp + l), __int_as_float(q0 + jp + l + 16), 0.f, 1.f);
-#else
-            const float4 v = wq[jp * NP * 64];
-#endif
-            bv[2 * jp][0] = v.x;
-            bv[2 * jp][1] = v.y;
-            bv[2 * jp + 1][0] = v.z;
-            bv[2 * jp + 1][1] = v.w;
-        }
-        if constexpr (KS == 3) {
-#pragma unroll
-            for (int j = 0; j < QU; ++j) to[j] = tap3[4 * (q0 + j) + kk];
-        } else {
-            cb = TapAddr<KS, HIN, U8IN, IN_PITCH, CT>::chunk_base(q0, kk, cin);
-        }
-    };
-    auto consume = [&](const float (&bv)[QU][2], int cb, const int (&to)[QU]) {
-#pragma unroll
-        for (int j = 0; j < QU; ++j) {
-#pragma unroll
-            for (int i = 0; i < MAXU; ++i) {
-                if (!live[i]) continue;   // wave-uniform
-                int off;
-                if constexpr (KS == 3) off = base[i] + to[j];
-                else off = base[i] + cb + TapAddr<KS, HIN, U8IN, IN_PITCH, CT>::rel(j, cin);
-                float av;
-#if defined(DQ_EXP) && (DQ_EXP & 1)
-                av = __int_as_float(off);
-#else
-                if constexpr (U8IN) av = lut[static_cast<const unsigned char *>(in_lds)[off]];
-                else av = static_cast<const float *>(in_lds)[off];
-#endif
-                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j][0], acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j][1], acc[i][1], 0, 0, 0);
+                for (int r = 0; r < 4; ++r) acc[i][h][r] = bb;
+                // pin the splat in a real register tuple: hipcc 7.2 otherwise kept only element 0 of some accumulators
+                // live up to the first MFMA and reused elements 1..3 for the loop's address / operand temporaries
+                // (seen in the ISA of the three-unit + half-unit instantiation; tests/test_deepqn_gpu.py caught it)
+                asm volatile("" : "+v"(acc[i][h]));
             }
         }
-    };
-    const int nq = taps / 4;   // a multiple of QU for every layer (C * 16, 128, 144)
-    issue(bvA, cbA, toA, 0);
-    for (int q0 = 0; q0 < nq; q0 += 2 * QU) {
-        if (q0 + QU < nq) issue(bvB, cbB, toB, q0 + QU);
-        consume(bvA, cbA, toA);
-        if (q0 + QU >= nq) break;
-        if (q0 + 2 * QU < nq) issue(bvA, cbA, toA, q0 + 2 * QU);
-        consume(bvB, cbB, toB);
-    }
+        if constexpr (XL) {
+            xbase = tile_base(NM - 1);
+            const float bb = bias[16 * (w & 1) + c];
 #pragma unroll
-    for (int i = 0; i < MAXU; ++i) {
-        if (!live[i]) continue;
-        const int m = (w + 8 * i) / NP;
+            for (int r = 0; r < 4; ++r) accx[r] = bb;
+            asm volatile("" : "+v"(accx));
+        }
+        // QU = k-steps per chunk: their weight operands are requested together, one chunk AHEAD of the MFMAs that use them
+        // (an L2 round trip per chunk would otherwise be exposed: conv2 / conv3 have only one or two units per wave to hide
+        // it behind).  This lane's B operands: one float4 per k-step pair (layout: dqn_common.hip.h dqn_conv_slab_to_flat)
+        const float4 *wlane = reinterpret_cast<const float4 *>(wt) + np * 64 + l;
+        float bvA[QU][2], bvB[QU][2];
+        int cbA, cbB;            // chunk bases (conv1 / conv2) ...
+        int toA[QU], toB[QU];    // ... or the table offsets (conv3)
+        auto issue = [&](float (&bv)[QU][2], int &cb, int (&to)[QU], int q0) {
+            const float4 *wq = wlane + (size_t)(q0 >> 1) * (NP * 64);
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int jp = 0; jp < QU / 2; ++jp) {
+#if defined(DQ_EXP) && (DQ_EXP & 2)
+                const float4 v = make_float4(__int_as_float(q0 + jp + l), __int_as_float(q0 + jp + l + 16), 0.f, 1.f);
+#else
+                const float4 v = wq[jp * NP * 64];
+#endif
+                bv[2 * jp][0] = v.x;
+                bv[2 * jp][1] = v.y;
+                bv[2 * jp + 1][0] = v.z;
+                bv[2 * jp + 1][1] = v.w;
+            }
+            if constexpr (KS == 3) {
+#pragma unroll
+                for (int j = 0; j < QU; ++j) to[j] = tap3[4 * (q0 + j) + kk];
+            } else {
+                cb = Tap::chunk_base(q0, kk, cin);
+            }
+        };
+        auto consume = [&](const float (&bv)[QU][2], int cb, const int (&to)[QU]) {
+#pragma unroll
+            for (int j = 0; j < QU; ++j) {
+                auto gather = [&](int b0) {
+                    int off;
+                    if constexpr (KS == 3) off = b0 + to[j];
+                    else off = b0 + cb + Tap::rel(j, cin);
+#if defined(DQ_EXP) && (DQ_EXP & 1)
+                    return __int_as_float(off);
+#else
+                    if constexpr (U8IN) return u8_over_255(static_cast<const unsigned char *>(in_lds)[off]);
+                    else return static_cast<const float *>(in_lds)[off];
+#endif
+                };
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    const float av = gather(base[i]);
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j][0], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j][1], acc[i][1], 0, 0, 0);
+                }
+                if constexpr (XL) {
+                    const float av = gather(xbase);
+                    accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av, (w & 1) ? bv[j][1] : bv[j][0], accx, 0, 0, 0);
+                }
+            }
+        };
+        const int nq = taps / 4;   // a multiple of QU for every layer (C * 16, 128, 144)
+        issue(bvA, cbA, toA, 0);
+        for (int q0 = 0; q0 < nq; q0 += 2 * QU) {
+            if (q0 + QU < nq) issue(bvB, cbB, toB, q0 + QU);
+            consume(bvA, cbA, toA);
+            if (q0 + QU >= nq) break;
+            if (q0 + 2 * QU < nq) issue(bvA, cbA, toA, q0 + 2 * QU);
+            consume(bvB, cbB, toB);
+        }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int m = (w + 8 * i) / NP;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int p = 16 * m + 4 * kk + r;
+                    if (p < NPOS) out[(32 * np + 16 * h + c) * OUT_PITCH + p] = acc[i][h][r];
+                }
+        }
+        if constexpr (XL) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int p = 16 * m + 4 * kk + r;
-                if (p < NPOS) out[(32 * np + 16 * h + c) * OUT_PITCH + p] = acc[i][h][r];
+                const int p = 16 * (NM - 1) + 4 * kk + r;
+                if (p < NPOS) out[(16 * (w & 1) + c) * OUT_PITCH + p] = accx[r];
             }
+        }
+    }
+};
+
+// w must be wave-uniform in an SGPR (readfirstlane): the dispatch below is a scalar branch
+template <int KS, int STRIDE, int HIN, int HOUT, int COUT, bool U8IN, int IN_PITCH, int OUT_PITCH, int CT, int QU>
+__device__ __forceinline__ void conv16_mfma(const void *in_lds, int cin, int taps, const float *wt, const float *bias,
+                                            float *out, const unsigned short *tap3, int w, int l)
+{
+    using K = Conv16<KS, STRIDE, HIN, HOUT, COUT, U8IN, IN_PITCH, OUT_PITCH, CT, QU>;
+    if constexpr (K::SPLIT) {
+        if (w < 2) K::template run<K::NFULL, true>(in_lds, cin, taps, wt, bias, out, tap3, w, l);
+        else K::template run<K::NFULL, false>(in_lds, cin, taps, wt, bias, out, tap3, w, l);
+    } else if constexpr (K::REM == 0) {
+        K::template run<K::NFULL, false>(in_lds, cin, taps, wt, bias, out, tap3, w, l);
+    } else {
+        if (w < K::REM) K::template run<K::NFULL + 1, false>(in_lds, cin, taps, wt, bias, out, tap3, w, l);
+        else if constexpr (K::NFULL > 0) K::template run<K::NFULL, false>(in_lds, cin, taps, wt, bias, out, tap3, w, l);
     }
 }
 
@@ -211,7 +279,6 @@ constexpr int DQ_P1 = 401, DQ_P2 = 81, DQ_P3 = 49;   // channel pitches of the a
 
 template <int CMAX>
 struct DqnSmem {
-    float lut[256];
     unsigned short tap3[576];                      // conv3's tap offsets ci * 81 + ky * 9 + kx
     float a1[32 * DQ_P1];                          // conv1 activations; later conv3's [64][49]
     union {
@@ -262,32 +329,41 @@ __global__ __launch_bounds__(512, CMAX <= 4 ? 4 : 2) void dqn_conv_kernel(const 
     if (row >= n_rows) return;   // workgroup-uniform
 #endif
     const coevo_dqn_task task = tasks[task_of_row(tasks, n_tasks, row)];
+#ifdef DQ_NO_RFL
     const int t = threadIdx.x, w = t >> 6, l = t & 63;
+#else
+    const int t = threadIdx.x, w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;   // w: scalar (wave-uniform branches)
+#endif
     const float *net = slab + task.net_off;
     const DqnLayout L = dqn_layout(C, n_actions);
-    // stage the frame (84*84*C bytes, a multiple of 16) and the /255 table (exact fp32 quotients)
+    // stage the frame (84*84*C bytes, a multiple of 16)
     DQ_STAMP(0);
     const int nbytes = 84 * 84 * C;
     const uint4 *src = reinterpret_cast<const uint4 *>(frames + (size_t)row * nbytes);
     uint4 *dst = reinterpret_cast<uint4 *>(sm.frame);
     for (int i = t; i < nbytes / 16; i += 512) dst[i] = src[i];
-    if (t < 256) sm.lut[t] = (float)t / 255.0f;
     for (int i = t; i < 576; i += 512) sm.tap3[i] = (unsigned short)((i / 9) * DQ_P2 + ((i % 9) / 3) * 9 + (i % 3));
     __syncthreads();
     DQ_STAMP(1);
-    conv16_mfma<8, 4, 84, 20, 32, true, 0, DQ_P1, CT, DQ_QU1>(sm.frame, sm.lut, C, C * 64, net + L.w1, net + L.b1, sm.a1, nullptr, w, l);
+    conv16_mfma<8, 4, 84, 20, 32, true, 0, DQ_P1, CT, DQ_QU1>(sm.frame, C, C * 64, net + L.w1, net + L.b1, sm.a1, nullptr, w, l);
     __syncthreads();
     DQ_STAMP(2);
+#if defined(DQ_DUMP)
+    if (DQ_DUMP == 2) { if (row == 0) for (int i = t; i < 32 * DQ_P1; i += 512) act[i] = sm.a1[i]; return; }
+#endif
     bn_relu_rows<400, DQ_P1, 32>(sm.a1, net + L.b1 + 32, net + L.b1 + 64, w, l);
     __syncthreads();
     DQ_STAMP(3);
-    conv16_mfma<4, 2, 20, 9, 64, false, DQ_P1, DQ_P2, 0, DQ_QU2>(sm.a1, nullptr, 32, 512, net + L.w2, net + L.b2, sm.a2, nullptr, w, l);
+#if defined(DQ_DUMP)
+    if (DQ_DUMP == 1) { if (row == 0) for (int i = t; i < 32 * DQ_P1; i += 512) act[i] = sm.a1[i]; return; }
+#endif
+    conv16_mfma<4, 2, 20, 9, 64, false, DQ_P1, DQ_P2, 0, DQ_QU2>(sm.a1, 32, 512, net + L.w2, net + L.b2, sm.a2, nullptr, w, l);
     __syncthreads();
     DQ_STAMP(4);
     bn_relu_rows<81, DQ_P2, 64>(sm.a2, net + L.b2 + 64, net + L.b2 + 128, w, l);
     __syncthreads();
     DQ_STAMP(5);
-    conv16_mfma<3, 1, 9, 7, 64, false, DQ_P2, DQ_P3, 0, DQ_QU3>(sm.a2, nullptr, 64, 576, net + L.w3, net + L.b3, sm.a1, sm.tap3, w, l);
+    conv16_mfma<3, 1, 9, 7, 64, false, DQ_P2, DQ_P3, 0, DQ_QU3>(sm.a2, 64, 576, net + L.w3, net + L.b3, sm.a1, sm.tap3, w, l);
     __syncthreads();
     DQ_STAMP(6);
     bn_relu_rows<49, DQ_P3, 64>(sm.a1, net + L.b3 + 64, net + L.b3 + 128, w, l);
