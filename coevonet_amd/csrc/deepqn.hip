@@ -236,33 +236,60 @@ __device__ __forceinline__ void conv16_mfma(const void *in_lds, int cin, int tap
 }
 
 // BatchNorm in training mode at batch 1 (per-sample, per-channel statistics over the NPOS positions) + ReLU, in place on
-// x[channel][position] in LDS.  A channel belongs to one wave: lane l holds positions 64 b + l, the canonical Reduce
-// (64-wide blocks, zero padded, tree inside, blocks left to right) is one packed butterfly (coevo_common.hip.h).
-// mean = S / N, var = S2 / N (biased), rstd = 1 / sqrtf(var + 1e-5f), y = fmaf(d * rstd, gamma, beta).
+// x[channel][position] in LDS.  mean = S / N, var = S2 / N (biased), rstd = 1 / sqrtf(var + 1e-5f),
+// y = fmaf(d * rstd, gamma, beta); S = the canonical Reduce (64-wide blocks, zero padded, tree inside, blocks left to right).
+// A wave owns COUT / 8 channels and reduces G of them (G * NB <= 16 values per lane) in ONE packed butterfly
+// (coevo_common.hip.h): lane j < G * NB then holds the tree sum of block j % NB of channel j / NB, the block sums are
+// chained left to right by row shifts, and the IEEE divides and the square root run once per group, lane-parallel, instead
+// of once per channel; each channel's mean / rstd comes back by v_readlane.  (f32 MFMA and VALU instructions never
+// co-execute here - SQ_VALU_MFMA_COEXEC_CYCLES = 0 - so every vector instruction of this pass is taken from the other
+// workgroup's matrix time: channel by channel it was 2/3 of the kernel's vector instructions.)
+template <int B, int NB>
+__device__ __forceinline__ float chain_blocks(float acc, float s)
+{
+    if constexpr (B < NB) return chain_blocks<B + 1, NB>(acc + dpp_move<0x100 + B>(s), s);   // row_shl:B: lane i <- lane i + B
+    else return acc;
+}
+
 template <int NPOS, int PITCH, int COUT>
 __device__ __forceinline__ void bn_relu_rows(float *x, const float *gamma, const float *beta, int w, int l)
 {
-    constexpr int NB = (NPOS + 63) / 64;
+    constexpr int NB = (NPOS + 63) / 64, CPW = COUT / 8, G = (16 / NB < CPW) ? 16 / NB : CPW, NG = CPW / G;
+    static_assert(CPW % G == 0 && G * NB <= 16, "groups of G channels fill one packed butterfly");
 #if defined(DQ_EXP) && (DQ_EXP & 4)
     return;
 #endif
-    for (int ch = w; ch < COUT; ch += 8) {
-        float *row = x + ch * PITCH;
-        float v[NB], sq[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) v[b] = (64 * b + l < NPOS) ? row[64 * b + l] : 0.0f;
-        const float mean = row_blocks_total<NB>(v, l) / (float)NPOS;
+    for (int g = 0; g < NG; ++g) {
+        float v[G * NB], sq[G * NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            v[b] = v[b] - mean;
-            sq[b] = (64 * b + l < NPOS) ? v[b] * v[b] : 0.0f;
+        for (int k = 0; k < G; ++k)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                v[k * NB + b] = (64 * b + l < NPOS) ? x[(w + 8 * (g * G + k)) * PITCH + 64 * b + l] : 0.0f;
+        const float s1 = packed_totals<G * NB>(v, l);
+        const float meanv = chain_blocks<1, NB>(s1, s1) / (float)NPOS;   // lane k * NB: channel k's mean
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const float mean = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(meanv), k * NB));
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                v[k * NB + b] = v[k * NB + b] - mean;
+                sq[k * NB + b] = (64 * b + l < NPOS) ? v[k * NB + b] * v[k * NB + b] : 0.0f;
+            }
         }
-        const float var = row_blocks_total<NB>(sq, l) / (float)NPOS;
-        const float rstd = 1.0f / __builtin_sqrtf(var + LN_EPS);
-        const float ga = gamma[ch], be = beta[ch];
+        const float s2 = packed_totals<G * NB>(sq, l);
+        const float varv = chain_blocks<1, NB>(s2, s2) / (float)NPOS;
+        const float rstdv = 1.0f / __builtin_sqrtf(varv + LN_EPS);
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
-            if (64 * b + l < NPOS) row[64 * b + l] = relu_keep_nan(__builtin_fmaf(v[b] * rstd, ga, be));
+        for (int k = 0; k < G; ++k) {
+            const int ch = w + 8 * (g * G + k);
+            const float rstd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rstdv), k * NB));
+            const float ga = gamma[ch], be = beta[ch];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                if (64 * b + l < NPOS) x[ch * PITCH + 64 * b + l] = relu_keep_nan(__builtin_fmaf(v[k * NB + b] * rstd, ga, be));
+        }
     }
 }
 
