@@ -19,6 +19,23 @@
 
 namespace coevo {
 
+// build-time tuning switches (defaults = the shipped configuration; tools/build_variant.sh for A/B runs)
+#ifndef DQ_LUT
+#define DQ_LUT 0   // 1: /255 through a 256-entry LDS table instead of u8_over_255 (measured equal at 3 workgroups per CU)
+#endif
+#ifndef DQ_WPE
+#define DQ_WPE 6   // waves per SIMD the register budget is set for: 3 workgroups x 8 waves / 4 SIMDs
+#endif
+#ifndef DQ_QU1
+#define DQ_QU1 4
+#endif
+#ifndef DQ_QU2
+#define DQ_QU2 4
+#endif
+#ifndef DQ_QU3
+#define DQ_QU3 4
+#endif
+
 
 __global__ __launch_bounds__(256) void dqn_pack_kernel(const float *flat, float *slab, int C, int n)
 {
@@ -83,7 +100,7 @@ struct TapAddr {
     }
 };
 
-template <int KS, int STRIDE, int HIN, int HOUT, int COUT, bool U8IN, int IN_PITCH, int OUT_PITCH, int CT, int QU>
+template <int KS, int STRIDE, int HIN, int HOUT, int COUT, bool U8IN, int IN_PITCH, int OUT_PITCH, int CT, int QU, bool OVER>
 struct Conv16 {
     static constexpr int NPOS = HOUT * HOUT, NM = (NPOS + 15) / 16, NP = COUT / 32, NUNITS = NM * NP;
     // SPLIT (conv1: 25 units on 8 waves): every wave takes three whole units and the 25th is halved between waves 0 and 1
@@ -100,8 +117,8 @@ struct Conv16 {
     // NU whole units (+ the half unit when XL) of wave w, as straight-line code: the unit count is a template argument so
     // that the k-loop has no branches and the scheduler can move a k-step's gathers above the previous step's MFMAs
     template <int NU, bool XL>
-    static __device__ __forceinline__ void run(const void *in_lds, int cin, int taps, const float *wt, const float *bias,
-                                               float *out, const unsigned short *tap3, int w, int l)
+    static __device__ __forceinline__ void run(const void *in_lds, const float *lut, int cin, int taps, const float *wt,
+                                               const float *bias, float *out, const unsigned short *tap3, int w, int l)
     {
         const int c = l & 15, kk = l >> 4, np = w % NP;
         constexpr int NA = NU > 0 ? NU : 1;
@@ -172,7 +189,8 @@ struct Conv16 {
 #if defined(DQ_EXP) && (DQ_EXP & 1)
                     return __int_as_float(off);
 #else
-                    if constexpr (U8IN) return u8_over_255(static_cast<const unsigned char *>(in_lds)[off]);
+                    if constexpr (U8IN) return DQ_LUT ? lut[static_cast<const unsigned char *>(in_lds)[off]]
+                                              : u8_over_255(static_cast<const unsigned char *>(in_lds)[off]);
                     else return static_cast<const float *>(in_lds)[off];
 #endif
                 };
@@ -197,6 +215,7 @@ struct Conv16 {
             if (q0 + 2 * QU < nq) issue(bvA, cbA, toA, q0 + 2 * QU);
             consume(bvB, cbB, toB);
         }
+        if constexpr (OVER) __syncthreads();   // the output overwrites the input: every wave has gathered its last tap
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
             const int m = (w + 8 * i) / NP;
@@ -218,20 +237,21 @@ struct Conv16 {
     }
 };
 
-// w must be wave-uniform in an SGPR (readfirstlane): the dispatch below is a scalar branch
-template <int KS, int STRIDE, int HIN, int HOUT, int COUT, bool U8IN, int IN_PITCH, int OUT_PITCH, int CT, int QU>
-__device__ __forceinline__ void conv16_mfma(const void *in_lds, int cin, int taps, const float *wt, const float *bias,
-                                            float *out, const unsigned short *tap3, int w, int l)
+// w must be wave-uniform in an SGPR (readfirstlane): the dispatch below is a scalar branch (every wave runs exactly one
+// instantiation, so the barrier inside is reached once by all of them)
+template <int KS, int STRIDE, int HIN, int HOUT, int COUT, bool U8IN, int IN_PITCH, int OUT_PITCH, int CT, int QU, bool OVER>
+__device__ __forceinline__ void conv16_mfma(const void *in_lds, const float *lut, int cin, int taps, const float *wt,
+                                            const float *bias, float *out, const unsigned short *tap3, int w, int l)
 {
-    using K = Conv16<KS, STRIDE, HIN, HOUT, COUT, U8IN, IN_PITCH, OUT_PITCH, CT, QU>;
+    using K = Conv16<KS, STRIDE, HIN, HOUT, COUT, U8IN, IN_PITCH, OUT_PITCH, CT, QU, OVER>;
     if constexpr (K::SPLIT) {
-        if (w < 2) K::template run<K::NFULL, true>(in_lds, cin, taps, wt, bias, out, tap3, w, l);
-        else K::template run<K::NFULL, false>(in_lds, cin, taps, wt, bias, out, tap3, w, l);
+        if (w < 2) K::template run<K::NFULL, true>(in_lds, lut, cin, taps, wt, bias, out, tap3, w, l);
+        else K::template run<K::NFULL, false>(in_lds, lut, cin, taps, wt, bias, out, tap3, w, l);
     } else if constexpr (K::REM == 0) {
-        K::template run<K::NFULL, false>(in_lds, cin, taps, wt, bias, out, tap3, w, l);
+        K::template run<K::NFULL, false>(in_lds, lut, cin, taps, wt, bias, out, tap3, w, l);
     } else {
-        if (w < K::REM) K::template run<K::NFULL + 1, false>(in_lds, cin, taps, wt, bias, out, tap3, w, l);
-        else if constexpr (K::NFULL > 0) K::template run<K::NFULL, false>(in_lds, cin, taps, wt, bias, out, tap3, w, l);
+        if (w < K::REM) K::template run<K::NFULL + 1, false>(in_lds, lut, cin, taps, wt, bias, out, tap3, w, l);
+        else if constexpr (K::NFULL > 0) K::template run<K::NFULL, false>(in_lds, lut, cin, taps, wt, bias, out, tap3, w, l);
     }
 }
 
@@ -293,30 +313,27 @@ __device__ __forceinline__ void bn_relu_rows(float *x, const float *gamma, const
     }
 }
 
-#ifndef DQ_QU1
-#define DQ_QU1 8
-#endif
-#ifndef DQ_QU2
-#define DQ_QU2 8
-#endif
-#ifndef DQ_QU3
-#define DQ_QU3 8
-#endif
 constexpr int DQ_P1 = 401, DQ_P2 = 81, DQ_P3 = 49;   // channel pitches of the activation images (odd: conflict-free columns)
 
+// One region serves every layer: the frame, then conv1's output written OVER it (conv1 keeps its sums in registers until
+// every wave has read its last tap: one extra barrier), conv2's output over that the same way, conv3's next to conv2's.
+// 52.5 KB instead of 80.6 KB: three workgroups (24 waves) per CU - while one frame is in a barrier, a BatchNorm pass or its
+// staging, two others feed the matrix pipe - and six-channel frames fit the same footprint.
 template <int CMAX>
 struct DqnSmem {
     unsigned short tap3[576];                      // conv3's tap offsets ci * 81 + ky * 9 + kx
-    float a1[32 * DQ_P1];                          // conv1 activations; later conv3's [64][49]
+    float lut[DQ_LUT ? 256 : 1];                   // x / 255.0f for x = 0 .. 255
     union {
-        unsigned char frame[84 * 84 * CMAX + 16];  // the uint8 HWC frame (dead after conv1)
-        float a2[64 * DQ_P2];                      // conv2 activations
+        unsigned char frame[84 * 84 * CMAX + 16];  // the uint8 HWC frame (dead after conv1's last gather)
+        float a1[32 * DQ_P1];                      // conv1 activations (dead after conv2's last gather)
+        struct {
+            float a2[64 * DQ_P2];                  // conv2 activations
+            float a3[64 * DQ_P3];                  // conv3 activations = the flattened CHW row
+        };
     };
 };
-static_assert(sizeof(DqnSmem<4>) <= 81920, "84x84x4 frames: two workgroups per CU");
+static_assert(sizeof(DqnSmem<6>) * 3 <= 160 * 1024, "three workgroups per CU");
 
-// CMAX = 4: up to four channels, 80.6 KB of LDS = two workgroups (16 waves) per CU: one frame's barriers, BatchNorm passes
-// and staging hide behind the other's MFMAs; CMAX = 6 (the reference's wrapper stack would yield 6 channels): one per CU
 // the task that holds row `row`: the tasks partition the rows in ascending row_begin order (include/coevo.h)
 __device__ __forceinline__ int task_of_row(const coevo_dqn_task *tasks, int n_tasks, int row)
 {
@@ -341,7 +358,7 @@ __device__ unsigned long long g_dqn_stamps[2048 * 16];
 
 // CT: the channel count as a compile-time constant (4 or 6: the gather offsets become instruction immediates), 0 = run time
 template <int CMAX, int CT>
-__global__ __launch_bounds__(512, CMAX <= 4 ? 4 : 2) void dqn_conv_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks,
+__global__ __launch_bounds__(512, DQ_WPE) void dqn_conv_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks,
                                                            int n_rows, int C, int n_actions, const uint8_t *frames, float *act)
 {
     __shared__ __attribute__((aligned(16))) DqnSmem<CMAX> sm;
@@ -369,10 +386,11 @@ __global__ __launch_bounds__(512, CMAX <= 4 ? 4 : 2) void dqn_conv_kernel(const 
     const uint4 *src = reinterpret_cast<const uint4 *>(frames + (size_t)row * nbytes);
     uint4 *dst = reinterpret_cast<uint4 *>(sm.frame);
     for (int i = t; i < nbytes / 16; i += 512) dst[i] = src[i];
+    if (DQ_LUT && t < 256) sm.lut[t] = (float)t / 255.0f;
     for (int i = t; i < 576; i += 512) sm.tap3[i] = (unsigned short)((i / 9) * DQ_P2 + ((i % 9) / 3) * 9 + (i % 3));
     __syncthreads();
     DQ_STAMP(1);
-    conv16_mfma<8, 4, 84, 20, 32, true, 0, DQ_P1, CT, DQ_QU1>(sm.frame, C, C * 64, net + L.w1, net + L.b1, sm.a1, nullptr, w, l);
+    conv16_mfma<8, 4, 84, 20, 32, true, 0, DQ_P1, CT, DQ_QU1, true>(sm.frame, sm.lut, C, C * 64, net + L.w1, net + L.b1, sm.a1, nullptr, w, l);
     __syncthreads();
     DQ_STAMP(2);
 #if defined(DQ_DUMP)
@@ -384,21 +402,21 @@ __global__ __launch_bounds__(512, CMAX <= 4 ? 4 : 2) void dqn_conv_kernel(const 
 #if defined(DQ_DUMP)
     if (DQ_DUMP == 1) { if (row == 0) for (int i = t; i < 32 * DQ_P1; i += 512) act[i] = sm.a1[i]; return; }
 #endif
-    conv16_mfma<4, 2, 20, 9, 64, false, DQ_P1, DQ_P2, 0, DQ_QU2>(sm.a1, 32, 512, net + L.w2, net + L.b2, sm.a2, nullptr, w, l);
+    conv16_mfma<4, 2, 20, 9, 64, false, DQ_P1, DQ_P2, 0, DQ_QU2, true>(sm.a1, nullptr, 32, 512, net + L.w2, net + L.b2, sm.a2, nullptr, w, l);
     __syncthreads();
     DQ_STAMP(4);
     bn_relu_rows<81, DQ_P2, 64>(sm.a2, net + L.b2 + 64, net + L.b2 + 128, w, l);
     __syncthreads();
     DQ_STAMP(5);
-    conv16_mfma<3, 1, 9, 7, 64, false, DQ_P2, DQ_P3, 0, DQ_QU3>(sm.a2, 64, 576, net + L.w3, net + L.b3, sm.a1, sm.tap3, w, l);
+    conv16_mfma<3, 1, 9, 7, 64, false, DQ_P2, DQ_P3, 0, DQ_QU3, false>(sm.a2, nullptr, 64, 576, net + L.w3, net + L.b3, sm.a3, sm.tap3, w, l);
     __syncthreads();
     DQ_STAMP(6);
-    bn_relu_rows<49, DQ_P3, 64>(sm.a1, net + L.b3 + 64, net + L.b3 + 128, w, l);
+    bn_relu_rows<49, DQ_P3, 64>(sm.a3, net + L.b3 + 64, net + L.b3 + 128, w, l);
     __syncthreads();
     DQ_STAMP(7);
     // flatten in CHW order (Atari/deepqn.py:45): channel pitch 49 = the flat layout itself
     float *dsta = act + (size_t)row * DQ_FC1_IN;
-    for (int i = t; i < DQ_FC1_IN; i += 512) dsta[i] = sm.a1[i];
+    for (int i = t; i < DQ_FC1_IN; i += 512) dsta[i] = sm.a3[i];
     DQ_STAMP(8);
 }
 
