@@ -513,7 +513,10 @@ class DQNESEngine(_SlabMixin):
                 games.append((me, 1) if ri == 0 else (0, me))
                 ordinal0.append(first_ordinal + 2 * (self.lo + j) + ri)
         self.n_main = len(games)
-        K = int(os.environ.get("COEVO_DQN_COHORTS", "1"))   # (cfg 5 shard: 8.7 vs 8.4 generations/s with two cohorts)
+        # two cohorts by default: one-frame tasks make this rollout fc1-bound (6.4 MB of weights per frame), and one
+        # cohort's conv launch (matrix pipe) then runs under the other's fc1 stream (HBM): cfg 5 shard 9.5 vs 9.1
+        # generations/s.  (Co-GA's 10-frame tasks are conv-bound: one cohort is faster there, 16.4 vs 15.6.)
+        K = int(os.environ.get("COEVO_DQN_COHORTS", "2"))
         half = 2 * (self.n_local // 2)   # games are individual-major: the first half of the individuals / the rest
         bounds = [0, half, self.n_main] if (K > 1 and 0 < half < self.n_main) else None
         self.ro = SynthRollout(games, net_off, ordinal0, C, n_actions, self.slab, env_seed, self.per_gen, device,

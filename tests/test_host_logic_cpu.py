@@ -205,3 +205,31 @@ def test_weights_only_safe_checkpoint_roundtrip(tmp_path):
     one = agents_from_state_dicts(env, args, "adversary_0",
                                   save_state_dicts(agents[1], os.path.join(tmp_path, "adversary.pth"), role="adversary_0"))
     assert sha(one.model.flat()) == sha(agents[1].model.flat())
+
+
+def test_u8_over_255_two_term_product_is_the_ieee_quotient():
+    """csrc/deepqn.hip u8_over_255: fma(x, head, x * tail) with 1/255 = head + tail equals x / 255.0f (the oracle's
+    preprocess_observation divide) for every byte value; the fma is emulated exactly in float64 (24 x 24-bit product +
+    a float32 addend fit its 53 bits before the single rounding to float32)"""
+    x = np.arange(256, dtype=np.float32)
+    head = np.float32(1.0 / 255.0)
+    tail = np.float32(1.0 / 255.0 - float(head))
+    low = (x * tail).astype(np.float32)
+    got = (x.astype(np.float64) * np.float64(head) + low.astype(np.float64)).astype(np.float32)
+    want = x / np.float32(255.0)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_dqn_conv_slab_layout_is_a_permutation():
+    """csrc/dqn_common.hip.h dqn_conv_slab_to_flat (restated): the lane-ordered conv weight layout visits every
+    (cout, tap) of a layer exactly once"""
+    for cout, taps in ((32, 256), (32, 384), (64, 512), (64, 576)):
+        i = np.arange(cout * taps, dtype=np.int64)
+        np_count = cout // 32
+        e, lane, blk = i & 3, (i >> 2) & 63, i >> 8
+        npi, qp = blk % np_count, blk // np_count
+        co = 32 * npi + 16 * (e & 1) + (lane & 15)
+        tap = 4 * (2 * qp + (e >> 1)) + (lane >> 4)
+        flat = co * taps + tap
+        assert co.max() == cout - 1 and tap.max() == taps - 1
+        assert np.array_equal(np.sort(flat), i)
