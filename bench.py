@@ -293,6 +293,11 @@ def run_dqn(a, ctx, dev, algo, pop_per_gpu=None, T=None):
         out["roofline"] = dict(dom)
         out["roofline"]["timing"] = "HIP events around sampled launches of the first cohort on its stream (eager enqueue)"
         out["roofline"]["second_kernel"] = other
+        out["roofline"]["concurrent_cohorts"] = len(eng.ro.lanes)
+        if len(eng.ro.lanes) > 1:
+            out["roofline"]["note"] = ("the sampled launches run beside the other cohort's conv / fc1 launches (separate "
+                                       "streams), so a launch's own duration includes the HBM and CU time it shares; "
+                                       "`generation` is the whole-rollout rate")
         out["roofline"]["generation"] = {"bound": "hbm", "algorithmic_bytes": gen_bytes,
                                          "achieved": gen_bytes * gens / 1e9, "unit": "GB/s",
                                          "frac": gen_bytes * gens / 1e9 / HBM_PEAK_GBS,

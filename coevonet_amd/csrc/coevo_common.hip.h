@@ -387,7 +387,8 @@ __device__ inline double block_sum_f64(double v, double *scratch)
 }
 
 __device__ inline bool bad_post_relu(float y) { return __builtin_isnan(y) || (__builtin_isinf(y) && y > 0.0f); }
-__device__ inline float relu_keep_nan(float y) { return (y > 0.0f) ? y : (__builtin_isnan(y) ? y : 0.0f); }
+// one compare: !(y <= 0) is true for y > 0 AND for NaN (unordered), so NaN passes through and -0 / negatives give +0
+__device__ inline float relu_keep_nan(float y) { return !(y <= 0.0f) ? y : 0.0f; }
 
 }  // namespace coevo
 
