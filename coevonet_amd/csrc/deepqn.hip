@@ -523,20 +523,41 @@ __global__ __launch_bounds__(64) void dqn_fc1_kernel(const float *slab, const co
     }
 }
 
-// output layer + first-max action: one 64-thread workgroup per (task, row)
+// output layer + first-max action: one 64-thread workgroup per (task, row).  Lane o < n_actions runs the canonical
+// sequential-k chain of its logit; the hidden row is staged in LDS once (every lane reads the same element: a broadcast)
+// and the lane's weight row comes in 16-byte pieces, 16 of them in flight (as a dword-at-a-time loop this kernel took as
+// long as a tenth of the conv stack).
 __global__ __launch_bounds__(64) void dqn_out_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int C,
                                                       int n_actions, const float *hid, int32_t *actions,
                                                       float *logits, int32_t *status)
 {
+    __shared__ __attribute__((aligned(16))) float xs[DQ_FC1_OUT];
     __shared__ float lg[64];
     const int row = blockIdx.x, o = threadIdx.x;
     const coevo_dqn_task task = tasks[task_of_row(tasks, n_tasks, row)];
     const float *net = slab + task.net_off;
     const DqnLayout L = dqn_layout(C, n_actions);
+    const float4 *x4 = reinterpret_cast<const float4 *>(hid + (size_t)row * DQ_FC1_OUT);
+    reinterpret_cast<float4 *>(xs)[o] = x4[o];
+    reinterpret_cast<float4 *>(xs)[o + 64] = x4[o + 64];
+    __syncthreads();
     if (o < n_actions) {
         float y = net[L.bo + o];
-        const float *wr = net + L.wo + (size_t)o * DQ_FC1_OUT, *x = hid + (size_t)row * DQ_FC1_OUT;
-        for (int k = 0; k < DQ_FC1_OUT; ++k) y = __builtin_fmaf(wr[k], x[k], y);
+        const float4 *w4 = reinterpret_cast<const float4 *>(net + L.wo + (size_t)o * DQ_FC1_OUT);
+        constexpr int B = 16;
+        for (int k0 = 0; k0 < DQ_FC1_OUT / 4; k0 += B) {
+            float4 wv[B];
+#pragma unroll
+            for (int i = 0; i < B; ++i) wv[i] = w4[k0 + i];
+#pragma unroll
+            for (int i = 0; i < B; ++i) {
+                const float4 xv = reinterpret_cast<const float4 *>(xs)[k0 + i];
+                y = __builtin_fmaf(wv[i].x, xv.x, y);
+                y = __builtin_fmaf(wv[i].y, xv.y, y);
+                y = __builtin_fmaf(wv[i].z, xv.z, y);
+                y = __builtin_fmaf(wv[i].w, xv.w, y);
+            }
+        }
         lg[o] = y;
         if (logits) logits[(size_t)row * COEVO_DQN_LOGIT_STRIDE + o] = y;
     }
