@@ -416,20 +416,18 @@ def run_ga(a, ctx, dev):
                     nets[int(t["net_off"])] = L.fc_param_count(int(t["D"])) * 4
                     rows += int(t["n_rows"])
             cycle_bytes = sum(nets.values()) + rows * (4 * 10 + 4)   # all cohorts, one env-cycle
-            persistent = bool(getattr(eng.ro, "_persistent_cycles", 0))
-            # a launch = one cohort's env-cycle, or (persistent rollout kernel) the whole rollout of all cohorts
-            alg_bytes = cycle_bytes * eng.n_cycles if persistent else cycle_bytes / max(eng.ro.n_cohorts, 1)
+            alg_bytes = cycle_bytes / max(eng.ro.n_cohorts, 1)    # a launch = one cohort's env-cycle
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-            K = 1 if persistent else max(eng.ro.n_cohorts, 1)
+            K = max(eng.ro.n_cohorts, 1)
             aggregate = None
             if getattr(eng.ro, "_span_ms", None):
                 # all policy launches of a rollout together: bytes of every launch / (first start .. last end); with one
                 # cohort this is the per-launch figure minus the inter-launch gaps, with K cohorts it accounts for the
                 # launches that run side by side
                 span_ms = float(np.mean(eng.ro._span_ms))
-                tot = alg_bytes if persistent else alg_bytes * K * eng.ro._span_cycles
+                tot = alg_bytes * K * eng.ro._span_cycles
                 aggregate = {"achieved": tot / (span_ms * 1e-3) / 1e9, "frac": tot / (span_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "rollout_span_ms": span_ms, "launches": 1 if persistent else K * eng.ro._span_cycles,
+                             "rollout_span_ms": span_ms, "launches": K * eng.ro._span_cycles,
                              "note": "algorithmic bytes of every policy launch of one rollout / (first workgroup start "
                                      ".. last workgroup end of the rollout)"}
             # which instantiation the C side picks (coevo_mpe_policy_cycle_merged): row-count template, lean 16-row
@@ -440,16 +438,14 @@ def run_ga(a, ctx, dev):
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
             per_launch = (len(eng.plan.heavy_np) + len(eng.plan.light_np)) / Kc
             lean = merged and eng.plan.heavy_max <= 16 and per_launch * Kc <= 4 * cus
-            if persistent:
-                kernel_id = f"fc_rollout16_kernel<{R}>"
-            elif lean:
+            if lean:
                 kernel_id = f"fc_cycle16_kernel<{R}>"
             elif merged:
                 kernel_id = f"fc_cycle_kernel<{R}, {2 if per_launch * Kc > 2 * cus else 1}>"
             else:
                 kernel_id = f"fc_policy_kernel<{R}, 2>"
             traffic, traffic_note = None, None
-            pmc = os.path.join(REPO, "profiles", "r01_pmc_hbm_traffic.json")
+            pmc = os.path.join(REPO, "profiles", "r02_pmc_hbm_traffic.json")
             if a.pop_per_gpu == 200 and a.hof == 5 and os.path.exists(pmc):
                 # HBM bytes per launch of this kernel from the PMC counters (FETCH_SIZE/WRITE_SIZE, separate rocprofv3
                 # passes of this same command, gfx950 correction applied) - collected offline, see the file
@@ -458,12 +454,10 @@ def run_ga(a, ctx, dev):
                 want = kernel_id
                 if want in j.get("dominant_kernel", ""):
                     traffic = j["dominant_kernel_hbm_bytes_per_launch"]
-                    traffic_note = "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc passes of this command)"
+                    traffic_note = "profiles/r02_pmc_hbm_traffic.json (rocprofv3 --pmc passes of this command)"
             kname = (kernel_id +
-                     (" (the whole rollout in one persistent launch: per env-cycle every per-individual weight set "
-                      "streamed once + shared-opponent tasks on the matrix cores, fused env step)" if persistent else
-                      " (one env-cycle of one cohort: per-individual weight sets streamed once + shared-opponent tasks "
-                      "on the matrix cores, fused env step)") if merged else
+                     " (one env-cycle of one cohort: per-individual weight sets streamed once + shared-opponent tasks "
+                     "on the matrix cores, fused env step)" if merged else
                      kernel_id + " (per-individual weight sets, fused env step)")
             out["roofline"] = {"bound": "hbm", "kernel": kname,
                                "timing": ("HIP events around each launch on its stream" if a.no_graph else

@@ -212,59 +212,32 @@ struct MpeGame {
     double gx, gy;                        // goal landmark
 };
 
-// Accesses to the small mutable rollout data (game state, actions).  COH = true: agent-scope relaxed atomics, i.e.
-// loads and stores that are coherent across the XCDs' L2s without cache-wide invalidates - what the persistent rollout
-// kernel needs, where one workgroup reads what another wrote earlier in the SAME launch.  COH = false: plain accesses
-// (the producer ran in an earlier launch).
-template <bool COH> __device__ __forceinline__ double ld_f64(const double *p)
-{
-    if constexpr (COH) return __hip_atomic_load(const_cast<double *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else return *p;
-}
-template <bool COH> __device__ __forceinline__ void st_f64(double *p, double v)
-{
-    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-template <bool COH> __device__ __forceinline__ int32_t ld_i32(const int32_t *p)
-{
-    if constexpr (COH) return __hip_atomic_load(const_cast<int32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else return *p;
-}
-template <bool COH> __device__ __forceinline__ void st_i32(int32_t *p, int32_t v)
-{
-    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-
-template <bool COH = false>
 __device__ __forceinline__ void mpe_load_game(const double *st, int n, int g, MpeGame &s)
 {
     const size_t N = (size_t)n;
-    s.ax = ld_f64<COH>(st + 0 * N + g); s.ay = ld_f64<COH>(st + 1 * N + g);
-    s.bx = ld_f64<COH>(st + 2 * N + g); s.by = ld_f64<COH>(st + 3 * N + g);
-    s.cx = ld_f64<COH>(st + 4 * N + g); s.cy = ld_f64<COH>(st + 5 * N + g);
-    s.avx = ld_f64<COH>(st + 6 * N + g); s.avy = ld_f64<COH>(st + 7 * N + g);
-    s.bvx = ld_f64<COH>(st + 8 * N + g); s.bvy = ld_f64<COH>(st + 9 * N + g);
-    s.cvx = ld_f64<COH>(st + 10 * N + g); s.cvy = ld_f64<COH>(st + 11 * N + g);
-    s.l0x = ld_f64<COH>(st + 12 * N + g); s.l0y = ld_f64<COH>(st + 13 * N + g);
-    s.l1x = ld_f64<COH>(st + 14 * N + g); s.l1y = ld_f64<COH>(st + 15 * N + g);
-    s.gx = ld_f64<COH>(st + 16 * N + g); s.gy = ld_f64<COH>(st + 17 * N + g);
+    s.ax = st[0 * N + g]; s.ay = st[1 * N + g];
+    s.bx = st[2 * N + g]; s.by = st[3 * N + g];
+    s.cx = st[4 * N + g]; s.cy = st[5 * N + g];
+    s.avx = st[6 * N + g]; s.avy = st[7 * N + g];
+    s.bvx = st[8 * N + g]; s.bvy = st[9 * N + g];
+    s.cvx = st[10 * N + g]; s.cvy = st[11 * N + g];
+    s.l0x = st[12 * N + g]; s.l0y = st[13 * N + g];
+    s.l1x = st[14 * N + g]; s.l1y = st[15 * N + g];
+    s.gx = st[16 * N + g]; s.gy = st[17 * N + g];
 }
 
-template <bool COH = false>
 __device__ __forceinline__ void mpe_store_game(double *st, int n, int g, const MpeGame &s)
 {
     const size_t N = (size_t)n;
-    st_f64<COH>(st + 0 * N + g, s.ax); st_f64<COH>(st + 1 * N + g, s.ay);
-    st_f64<COH>(st + 2 * N + g, s.bx); st_f64<COH>(st + 3 * N + g, s.by);
-    st_f64<COH>(st + 4 * N + g, s.cx); st_f64<COH>(st + 5 * N + g, s.cy);
-    st_f64<COH>(st + 6 * N + g, s.avx); st_f64<COH>(st + 7 * N + g, s.avy);
-    st_f64<COH>(st + 8 * N + g, s.bvx); st_f64<COH>(st + 9 * N + g, s.bvy);
-    st_f64<COH>(st + 10 * N + g, s.cvx); st_f64<COH>(st + 11 * N + g, s.cvy);
-    st_f64<COH>(st + 12 * N + g, s.l0x); st_f64<COH>(st + 13 * N + g, s.l0y);
-    st_f64<COH>(st + 14 * N + g, s.l1x); st_f64<COH>(st + 15 * N + g, s.l1y);
-    st_f64<COH>(st + 16 * N + g, s.gx); st_f64<COH>(st + 17 * N + g, s.gy);
+    st[0 * N + g] = s.ax; st[1 * N + g] = s.ay;
+    st[2 * N + g] = s.bx; st[3 * N + g] = s.by;
+    st[4 * N + g] = s.cx; st[5 * N + g] = s.cy;
+    st[6 * N + g] = s.avx; st[7 * N + g] = s.avy;
+    st[8 * N + g] = s.bvx; st[9 * N + g] = s.bvy;
+    st[10 * N + g] = s.cvx; st[11 * N + g] = s.cvy;
+    st[12 * N + g] = s.l0x; st[13 * N + g] = s.l0y;
+    st[14 * N + g] = s.l1x; st[15 * N + g] = s.l1y;
+    st[16 * N + g] = s.gx; st[17 * N + g] = s.gy;
 }
 
 // one agent's integration step for one coordinate (discrete action -> force 5*u, dt 0.1, damping 0.25)
@@ -338,36 +311,34 @@ __device__ __forceinline__ void mpe_obs_from_game(const MpeGame &s, int slot, fl
 // Fused env step (coevo_mpe_rollout): the state a policy launch of cycle `cycle` observes is derived in registers
 // from the previous cycle's state buffer and the previous cycle's actions; only the row in the adversary's seat (one
 // per game) writes the new state and credits the rewards (quirk Q1), into the OTHER buffer.  obs_out[0..D) filled.
-template <bool COH = false>
 __device__ __forceinline__ void mpe_fused_observe(const double *st_prev, double *st_next, const int32_t *act_prev,
                                          const int32_t *game_limit, int n, int g, int slot, int cycle, int pos_first,
                                          float *obs_out)
 {
     const size_t N = (size_t)n;
     MpeGame s;
-    mpe_load_game<COH>(st_prev, n, g, s);
+    mpe_load_game(st_prev, n, g, s);
     if (cycle > 0) {
         const int limit = game_limit ? game_limit[g] : 0x7fffffff;
         const int t0 = 3 * (cycle - 1);
         const bool stepped = t0 + 2 < limit;  // agent_1 acted in the previous cycle: the world moved
         double r_good = 0.0, r_adv = 0.0;
         if (stepped) {
-            const int a0 = ld_i32<COH>(act_prev + 3 * g), a1 = ld_i32<COH>(act_prev + 3 * g + 1),
-                      a2 = ld_i32<COH>(act_prev + 3 * g + 2);
+            const int a0 = act_prev[3 * g], a1 = act_prev[3 * g + 1], a2 = act_prev[3 * g + 2];
             if (slot == COEVO_SLOT_ADVERSARY) mpe_world_step(s, a0, a1, a2, pos_first, r_good, r_adv);
             else mpe_world_move(s, a0, a1, a2, pos_first);  // only the owner row credits rewards
         }
         if (slot == COEVO_SLOT_ADVERSARY) {  // the game's owner row: carry the bookkeeping into the new buffer
-            double rg_prev = ld_f64<COH>(st_prev + 18 * N + g), a_adv = ld_f64<COH>(st_prev + 19 * N + g),
-                   a_a0 = ld_f64<COH>(st_prev + 20 * N + g), a_a1 = ld_f64<COH>(st_prev + 21 * N + g);
+            double rg_prev = st_prev[18 * N + g], a_adv = st_prev[19 * N + g], a_a0 = st_prev[20 * N + g],
+                   a_a1 = st_prev[21 * N + g];
             if (t0 < limit) a_adv = a_adv + rg_prev;
             if (t0 + 1 < limit) a_a0 = a_a0 + rg_prev;
             if (stepped) { a_a1 = a_a1 + r_adv; rg_prev = r_good; }
-            mpe_store_game<COH>(st_next, n, g, s);
-            st_f64<COH>(st_next + 18 * N + g, rg_prev);
-            st_f64<COH>(st_next + 19 * N + g, a_adv);
-            st_f64<COH>(st_next + 20 * N + g, a_a0);
-            st_f64<COH>(st_next + 21 * N + g, a_a1);
+            mpe_store_game(st_next, n, g, s);
+            st_next[18 * N + g] = rg_prev;
+            st_next[19 * N + g] = a_adv;
+            st_next[20 * N + g] = a_a0;
+            st_next[21 * N + g] = a_a1;
         }
     }
     mpe_obs_from_game(s, slot, obs_out);

@@ -85,9 +85,6 @@ struct FcArgs {
     int n_heavy, n_light;
 };
 constexpr int MODE_OBS = 0, MODE_STATE = 1, MODE_FUSED = 2;
-// MODE_PERSIST = the fused env step inside the persistent rollout kernel: state and actions were written by other
-// workgroups of the SAME launch, so they are accessed coherently (ld_/st_ helpers in coevo_common.hip.h)
-constexpr int MODE_PERSIST = 3;
 
 // 100 MHz wall clock; the first/last workgroup of a launch bracket its duration (used where HIP events cannot be:
 // inside hipGraph replays)
@@ -194,7 +191,7 @@ __device__ __forceinline__ void fc_policy_body(const FcArgs &a, FcSmem<R, P> &sm
             for (int k = 0; k < COEVO_OBS_STRIDE; ++k) o[k] = 0.0f;
             if (l < nrows[pw]) {
                 const int row = row0[pw] + l;
-                mpe_fused_observe<MODE == MODE_PERSIST>(a.state, a.state_next, a.act_prev, a.game_limit, a.n_games, a.row_game[row],
+                mpe_fused_observe(a.state, a.state_next, a.act_prev, a.game_limit, a.n_games, a.row_game[row],
                                   a.row_slot[row], a.cycle, a.pos_first, o);
 #pragma unroll
                 for (int k = 0; k < 10; ++k)
@@ -439,7 +436,7 @@ __device__ __forceinline__ void fc_policy_body(const FcArgs &a, FcSmem<R, P> &sm
         if (best < 0) { st |= COEVO_ST_NO_ACTION; best = 0; }
         const int row = row0[pw] + l;
         if constexpr (MODE >= MODE_FUSED) {
-            st_i32<MODE == MODE_PERSIST>(&a.act_cur[3 * a.row_game[row] + a.row_slot[row]], best);  // by (game, slot)
+            a.act_cur[3 * a.row_game[row] + a.row_slot[row]] = best;  // by (game, slot)
         } else {
             a.actions[row] = best;
         }
@@ -522,7 +519,7 @@ __device__ __forceinline__ void fc_policy_body_c(const FcArgs &a, FcSmemC<R> &sm
         for (int k = 0; k < COEVO_OBS_STRIDE; ++k) o[k] = 0.0f;
         if (l < nrows) {
             const int row = row0 + l;
-            mpe_fused_observe<false>(a.state, a.state_next, a.act_prev, a.game_limit, a.n_games, a.row_game[row],
+            mpe_fused_observe(a.state, a.state_next, a.act_prev, a.game_limit, a.n_games, a.row_game[row],
                                      a.row_slot[row], a.cycle, a.pos_first, o);
 #pragma unroll
             for (int k = 0; k < 10; ++k)
@@ -846,7 +843,7 @@ __device__ __forceinline__ void fc_policy_mfma_body(const FcArgs &a, FcMfmaSmem 
             for (int k = 0; k < COEVO_OBS_STRIDE; ++k) o[k] = 0.0f;
             if (t < nrows) {
                 const int row = row0 + t;
-                mpe_fused_observe<MODE == MODE_PERSIST>(a.state, a.state_next, a.act_prev, a.game_limit, a.n_games, a.row_game[row],
+                mpe_fused_observe(a.state, a.state_next, a.act_prev, a.game_limit, a.n_games, a.row_game[row],
                                   a.row_slot[row], a.cycle, a.pos_first, o);
 #pragma unroll
                 for (int k = 0; k < 10; ++k)
@@ -1065,7 +1062,7 @@ __device__ __forceinline__ void fc_policy_mfma_body(const FcArgs &a, FcMfmaSmem 
         if (best < 0) { st |= COEVO_ST_NO_ACTION; best = 0; }
         if constexpr (MODE >= MODE_FUSED) {
             const int row = row0 + t;
-            st_i32<MODE == MODE_PERSIST>(&a.act_cur[3 * a.row_game[row] + a.row_slot[row]], best);  // by (game, slot)
+            a.act_cur[3 * a.row_game[row] + a.row_slot[row]] = best;  // by (game, slot)
         } else {
             a.actions[row0 + t] = best;
         }
@@ -1149,7 +1146,7 @@ __device__ __forceinline__ void fc_policy_mfma16_body(const FcArgs &a, FcMfma16S
             for (int k = 0; k < COEVO_OBS_STRIDE; ++k) o[k] = 0.0f;
             if (t < nrows) {
                 const int row = row0 + t;
-                mpe_fused_observe<MODE == MODE_PERSIST>(a.state, a.state_next, a.act_prev, a.game_limit, a.n_games, a.row_game[row],
+                mpe_fused_observe(a.state, a.state_next, a.act_prev, a.game_limit, a.n_games, a.row_game[row],
                                   a.row_slot[row], a.cycle, a.pos_first, o);
 #pragma unroll
                 for (int k = 0; k < 10; ++k)
@@ -1361,7 +1358,7 @@ __device__ __forceinline__ void fc_policy_mfma16_body(const FcArgs &a, FcMfma16S
         if (best < 0) { st |= COEVO_ST_NO_ACTION; best = 0; }
         if constexpr (MODE >= MODE_FUSED) {
             const int row = row0 + t;
-            st_i32<MODE == MODE_PERSIST>(&a.act_cur[3 * a.row_game[row] + a.row_slot[row]], best);  // by (game, slot)
+            a.act_cur[3 * a.row_game[row] + a.row_slot[row]] = best;  // by (game, slot)
         } else {
             a.actions[row0 + t] = best;
         }
@@ -1398,133 +1395,6 @@ __global__ __launch_bounds__(256, 4) void fc_cycle16_kernel(FcArgs a)
         fc_policy_body<R, MODE_FUSED, 1>(a, sm.light, a.light_tasks, (int)blockIdx.x - a.n_heavy, a.n_light);
 #endif
     stamp_end(a.stamps);
-}
-
-// =====================================================================================================
-// The persistent rollout: ONE launch plays all n_cycles env-cycles of all cohorts.  Why: the execute-once sections of a
-// cycle (env step, LayerNorms, output layer: ~12 KiB of straight-line code per body) run from a cold instruction cache
-// in every per-cycle launch - tools/merged_wg_times.py: 31.6 us for a section that takes 6.7 us when the body is simply
-// run a second time in the same launch.  Here every workgroup keeps its task for the whole rollout and the kernel
-// boundary between cycles becomes an arrival counter per cohort in device memory:
-//   * all workgroups of the launch must be resident (the host checks the occupancy: 4 per CU);
-//   * a workgroup waits until every workgroup of ITS cohort has finished the previous cycle - cohorts share nothing and
-//     drift apart, which staggers their weight streaming;
-//   * state and actions written by other workgroups of the same launch are read with agent-scope coherent accesses
-//     (MODE_PERSIST: write-through stores, cache-bypassing loads); the arrival increment follows a workgroup barrier
-//     that waits for the stores' acknowledgement;
-//   * every spin is bounded: a workgroup that waits longer than ~0.2 s raises COEVO_ST_TIMEOUT in the status word, which
-//     also releases every other spinning workgroup - the launch always terminates.
-#ifndef COEVO_PERSIST_STAGGER_TICKS
-#define COEVO_PERSIST_STAGGER_TICKS 5500   // one cycle period in 100 MHz ticks (~55 us)
-#endif
-#ifndef COEVO_POLL_SLEEP
-#define COEVO_POLL_SLEEP 32   // s_sleep units of 64 clocks between two polls of the go word (~1 us)
-#endif
-struct PersistArgs {
-    double *state_a, *state_b;        // the two state buffers (a holds the reset state)
-    int32_t *act;                     // [2][n_games][3]
-    int32_t *arrive;                  // [32 * (1 + COEVO_MAX_COHORTS)] ints, zero at launch: arrival counters in the
-                                      // first line, then one "go" word per cohort on its own 128-byte line
-    int n_cycles, n_cohorts;
-    int hb[COEVO_MAX_COHORTS + 1];    // cohort boundaries in the shared-opponent / per-individual task lists
-    int lb[COEVO_MAX_COHORTS + 1];
-};
-
-template <int R>
-__global__ __launch_bounds__(256, 4) void fc_rollout16_kernel(FcArgs a, PersistArgs pa)
-{
-    __shared__ union Rollout16Smem {
-        FcMfma16Smem heavy;
-        FcSmem<R, 1> light;
-    } sm;
-    __shared__ int abort_s;
-    stamp_begin(a.stamps);
-    const int b = (int)blockIdx.x;
-    const bool is_heavy = b < a.n_heavy;          // workgroup-uniform
-    const int idx = is_heavy ? b : b - a.n_heavy;
-    int k = 0;
-    for (int j = 1; j < pa.n_cohorts; ++j)
-        if (idx >= (is_heavy ? pa.hb[j] : pa.lb[j])) k = j;
-    const int n_k = (pa.hb[k + 1] - pa.hb[k]) + (pa.lb[k + 1] - pa.lb[k]);  // workgroups of this cohort
-    const size_t act_stride = 3 * (size_t)a.n_games;
-    // wait until the last workgroup of this cohort has published "cycle cyc may start"; false: abandoned
-    auto wait_for_cohort = [&](int cyc) -> bool {
-        COEVO_STAMP(13);
-        if (threadIdx.x == 0) {
-            int32_t *go = pa.arrive + 32 * (1 + k);  // one 128-byte line per cohort, written once per cycle
-            int ok = 0;
-            for (int it = 0; it < (1 << 17); ++it) {  // ~0.3 s: the launch cannot hang
-                if (__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= cyc) { ok = 1; break; }
-                if ((it & 63) == 63 &&
-                    (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & COEVO_ST_TIMEOUT))
-                    break;
-                __builtin_amdgcn_s_sleep(COEVO_POLL_SLEEP);
-            }
-            if (!ok) atomicOr(a.status, COEVO_ST_TIMEOUT);
-            abort_s = !ok;
-        }
-        __syncthreads();
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);  // no access of the cycle may be moved above the wait
-        COEVO_STAMP(14);
-        return !abort_s;  // workgroup-uniform
-    };
-    // Every wave's state / action stores are agent-scope write-through atomics and the barrier waits for their
-    // acknowledgement (vmcnt(0)), so a RELAXED increment publishes them.  (A release here costs a whole-L2 writeback
-    // per workgroup per cycle: measured 176 instead of ~50 us per cycle.)  The last workgroup of the cohort in this
-    // cycle opens the next one.
-    auto arrive = [&](int cyc) {
-        __syncthreads();
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        if (threadIdx.x == 0) {
-            const int arrived = __hip_atomic_fetch_add(&pa.arrive[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (arrived == (cyc + 1) * n_k - 1)
-                __hip_atomic_store(pa.arrive + 32 * (1 + k), cyc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-    // cycle c reads the state of cycle c-1 (buffer (c-1)&1; buffer a holds the reset state), writes buffer c&1
-    auto cycle_args = [&](int cyc) {
-        FcArgs ac = a;
-        ac.stamps = nullptr;
-        ac.cycle = cyc;
-        ac.state = (cyc == 0) ? pa.state_a : (((cyc - 1) & 1) ? pa.state_b : pa.state_a);
-        ac.state_next = (cyc == 0) ? pa.state_b : ((cyc & 1) ? pa.state_b : pa.state_a);
-        ac.act_prev = pa.act + (size_t)((cyc + 1) & 1) * act_stride;
-        ac.act_cur = pa.act + (size_t)(cyc & 1) * act_stride;
-        return ac;
-    };
-    // stagger: cohort k starts k/K of a cycle late, and the cohorts then keep that phase (equal periods), so one
-    // cohort's weight streaming falls into the other's non-streaming phases
-    if (k > 0) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        const unsigned long long delay = (unsigned long long)COEVO_PERSIST_STAGGER_TICKS * k / pa.n_cohorts;
-        while (__builtin_amdgcn_s_memrealtime() - t0 < delay) __builtin_amdgcn_s_sleep(32);
-    }
-    // a workgroup keeps its kind for the whole rollout: two loops, one body each (one loop around both bodies mixes
-    // their live ranges and spills)
-    if (is_heavy) {
-#pragma nounroll
-        for (int cyc = 0; cyc < pa.n_cycles; ++cyc) {
-            if (cyc > 0 && !wait_for_cohort(cyc)) break;
-            const FcArgs ac = cycle_args(cyc);
-            fc_policy_mfma16_body<MODE_PERSIST>(ac, sm.heavy, a.tasks[idx]);
-            arrive(cyc);
-        }
-    } else {
-#pragma nounroll
-        for (int cyc = 0; cyc < pa.n_cycles; ++cyc) {
-            if (cyc > 0 && !wait_for_cohort(cyc)) break;
-            const FcArgs ac = cycle_args(cyc);
-            fc_policy_body<R, MODE_PERSIST, 1>(ac, sm.light, a.light_tasks, idx, a.n_light);
-            arrive(cyc);
-        }
-    }
-    stamp_end(a.stamps);
-}
-
-__global__ void zero_i32_kernel(int32_t *p, int n)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0;
 }
 
 // One launch = one env-cycle of one cohort of games (fused env step): the shared-opponent tasks first (lowest block
@@ -1634,74 +1504,6 @@ extern "C" int coevo_mpe_policy_cycle_fused(const float *slab, const coevo_fc_ta
                     reinterpret_cast<unsigned long long *>(stamps), state_next, act_prev, act_cur, game_limit, cycle,
                     pos_first, nullptr, 0, 0};
     return coevo::launch_fc<coevo::MODE_FUSED>(a, n_tasks, max_rows_per_task, (hipStream_t)stream);
-}
-
-static const void *persistent_kernel(int light_max_rows)
-{
-    return light_max_rows <= 1   ? (const void *)coevo::fc_rollout16_kernel<1>
-           : light_max_rows <= 2 ? (const void *)coevo::fc_rollout16_kernel<2>
-           : light_max_rows <= 5 ? (const void *)coevo::fc_rollout16_kernel<5>
-                                 : (const void *)coevo::fc_rollout16_kernel<8>;
-}
-
-// how many workgroups of the persistent rollout kernel the current device holds at once (occupancy x CUs); cached, so
-// that the launch itself makes no query (call this once outside any graph capture)
-extern "C" int coevo_mpe_rollout_persistent_capacity(int light_max_rows)
-{
-    static int cap[4] = {0, 0, 0, 0};
-    if (light_max_rows < 1 || light_max_rows > 8) return COEVO_ERR_ARG;
-    const int v = light_max_rows <= 1 ? 0 : light_max_rows <= 2 ? 1 : light_max_rows <= 5 ? 2 : 3;
-    if (cap[v] == 0) {
-        int dev = 0, cus = 0, per_cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0 ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, persistent_kernel(light_max_rows), 256, 0) != hipSuccess)
-            return COEVO_ERR_HIP;
-        cap[v] = per_cu * cus;
-    }
-    return cap[v];
-}
-
-extern "C" int coevo_mpe_rollout_persistent(const float *slab, const coevo_fc_task *heavy_tasks, int n_heavy,
-                                            int heavy_max_rows, const coevo_fc_task *light_tasks, int n_light,
-                                            int light_max_rows, int n_cohorts, const int32_t *heavy_begin,
-                                            const int32_t *light_begin, double *state, double *state_alt, int n_games,
-                                            const int32_t *row_game, const int32_t *row_slot,
-                                            int32_t *actions_by_game, const int32_t *game_limit, int n_cycles,
-                                            int pos_first, int32_t *status, int32_t *arrive, uint64_t *stamps,
-                                            void *stream)
-{
-    if (!slab || !heavy_tasks || !light_tasks || !state || !state_alt || !row_game || !row_slot || !actions_by_game ||
-        !status || !arrive)
-        return COEVO_ERR_ARG;
-    if (n_heavy <= 0 || n_light <= 0 || n_games <= 0 || n_cycles < 0 || state == state_alt) return COEVO_ERR_ARG;
-    if (heavy_max_rows < 1 || heavy_max_rows > 16 || light_max_rows < 1 || light_max_rows > 8) return COEVO_ERR_UNSUPPORTED;
-    const int K = n_cohorts > 1 ? n_cohorts : 1;
-    if (K > COEVO_MAX_COHORTS || (K > 1 && (!heavy_begin || !light_begin))) return COEVO_ERR_ARG;
-    if (n_cycles == 0) return COEVO_OK;
-    coevo::FcArgs a{slab, heavy_tasks, nullptr, state, row_game, row_slot, n_games, nullptr, nullptr, status,
-                    reinterpret_cast<unsigned long long *>(stamps), state_alt, nullptr, nullptr, game_limit, 0,
-                    pos_first, light_tasks, n_heavy, n_light};
-    coevo::PersistArgs pa{};
-    pa.state_a = state; pa.state_b = state_alt; pa.act = actions_by_game; pa.arrive = arrive;
-    pa.n_cycles = n_cycles; pa.n_cohorts = K;
-    for (int k = 0; k <= K; ++k) {
-        pa.hb[k] = K > 1 ? heavy_begin[k] : (k ? n_heavy : 0);
-        pa.lb[k] = K > 1 ? light_begin[k] : (k ? n_light : 0);
-    }
-    if (pa.hb[0] != 0 || pa.lb[0] != 0 || pa.hb[K] != n_heavy || pa.lb[K] != n_light) return COEVO_ERR_ARG;
-    const void *fn = persistent_kernel(light_max_rows);
-    // every workgroup must be resident at once: they wait for each other
-    const int capacity = coevo_mpe_rollout_persistent_capacity(light_max_rows);
-    if (capacity < 0) return capacity;
-    if ((long long)n_heavy + n_light > (long long)capacity) return COEVO_ERR_UNSUPPORTED;
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(coevo::zero_i32_kernel, dim3(2), dim3(256), 0, s, arrive, 32 * (1 + COEVO_MAX_COHORTS));
-    const dim3 grid(n_heavy + n_light), block(256);
-    void *params[] = {(void *)&a, (void *)&pa};
-    COEVO_HIP_CHECK(hipLaunchKernel(fn, grid, block, params, 0, s));
-    COEVO_HIP_CHECK(hipGetLastError());
-    return COEVO_OK;
 }
 
 extern "C" int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_task *heavy_tasks, int n_heavy,

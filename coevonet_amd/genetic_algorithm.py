@@ -393,10 +393,7 @@ class GAEngine:
         offspring -> generation counter tick; every launch takes the generation from the device counter, so the
         captured graph is replayed unchanged generation after generation"""
         self._enqueue_resets()
-        if self.ro.persistent_ok():
-            self.ro.enqueue_persistent(self.n_cycles)   # one launch for the whole rollout (+ the closing step)
-        else:
-            self.ro.enqueue(self.n_cycles)
+        self.ro.enqueue(self.n_cycles)
         self._enqueue_selection_and_breeding()
 
     def _enqueue_resets(self):
@@ -652,10 +649,9 @@ class GAEngine:
             if gen == 1:
                 limits[self.n_main:] = self.T_eval
             self.ro.set_limits(limits)
-        persistent = self.ro.use_graph and self.ro.persistent_ok()  # then the generation is one single-stream graph
-        if not persistent and self.ro.use_graph and self.ro.n_cohorts > 1 and self.fused_tail and self.pipelined:
+        if self.ro.use_graph and self.ro.n_cohorts > 1 and self.fused_tail and self.pipelined:
             return self.replay_generation_pipelined(gen)
-        if not persistent and self.ro.use_graph and self.ro.n_cohorts > 1:
+        if self.ro.use_graph and self.ro.n_cohorts > 1:
             # cohort chains only run side by side when their launches are enqueued eagerly on their own streams (inside a
             # captured graph this runtime schedules them no better than one chain): the resets and the selection /
             # breeding tail are two small graphs, the rollout between them is one C call

@@ -21,8 +21,7 @@ MPE_STATE_DOUBLES = 24
 STAMP_SLOTS = 32
 ST_NAMES = {1: "input contains inf or NaN", 2: "output contains inf or NaN after fc1",
             4: "output contains inf or NaN after fc2", 8: "output contains inf or NaN",
-            16: "no action selected (current_best_position = -1)",
-            32: "persistent rollout abandoned: a workgroup timed out waiting for its cohort"}
+            16: "no action selected (current_best_position = -1)"}
 
 DQN_LOGIT_STRIDE = 32
 DQN_MAX_ROWS = 16
@@ -130,11 +129,6 @@ _SIGS = {
                                                 C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                 C.c_int, C.c_int, C.c_void_p]),
-    "coevo_mpe_rollout_persistent_capacity": (C.c_int, [C.c_int]),
-    "coevo_mpe_rollout_persistent": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
-                                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "coevo_mpe_final_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                        C.c_void_p]),
     "coevo_fc_perturb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,

@@ -10,7 +10,7 @@ cycle's policy launch (each row derives its game's state from the previous buffe
 ``RolloutPlan``   static description of a batch: which net plays which slot of which game -> task/row tables on device,
                   optionally partitioned into independent game cohorts
 ``DeviceRollout`` env state + action buffers + the cycle loop, env on the device: one merged launch per env-cycle (and
-                  cohort), cohort chains on their own streams, or the opt-in persistent one-launch rollout
+                  cohort), cohort chains on their own streams
 ``HostEnvRollout`` the same plan with the env stepped on the host cores (north_star's first configuration)
 """
 from __future__ import annotations
@@ -286,44 +286,6 @@ class DeviceRollout:
         if self.time_light:
             self._pending_stamps = int(n_cycles)
 
-    def persistent_ok(self):
-        """can / should the whole rollout run as ONE persistent launch (coevo_mpe_rollout_persistent)?  Lean kernel only,
-        every workgroup resident at once; queried here, outside any graph capture.  Opt-in (COEVO_PERSISTENT=1): it is
-        bit-identical and its execute-once code runs warm, but on cfg2 it reaches 398 generations/s against 520 for the
-        per-cycle launches of two pipelined cohorts."""
-        if getattr(self, "_persistent_ok", None) is None:
-            p = self.plan
-            ok = (bool(self.desc.merged) and len(p.heavy_np) > 0 and len(p.light_np) > 0 and p.heavy_max <= 16
-                  and p.light_max <= 8 and os.environ.get("COEVO_PERSISTENT", "0") == "1")
-            if ok:
-                cap = L.load().coevo_mpe_rollout_persistent_capacity(p.light_max)
-                ok = cap >= len(p.heavy_np) + len(p.light_np)
-            if ok:
-                self.arrive = torch.zeros(32 * (1 + 8), dtype=torch.int32, device=p.device)  # COEVO_PERSIST_WORDS
-            self._persistent_ok = ok
-        return self._persistent_ok
-
-    def enqueue_persistent(self, n_cycles):
-        """the whole rollout as one launch + the closing step, on the current stream"""
-        assert self.persistent_ok()
-        p, n = self.plan, int(n_cycles)
-        assert n <= self.stamp_cycles
-        stamps = None
-        if self.time_light:   # one launch: one stamp row
-            self.stamps[0, :, 0] = -1   # all ones = UINT64_MAX
-            self.stamps[0, :, 1] = 0
-            stamps = L._p(self.stamps)
-        K = self.n_cohorts
-        L.call("coevo_mpe_rollout_persistent", L._p(self.slab), L._p(p.heavy), len(p.heavy_np), p.heavy_max,
-               L._p(p.light), len(p.light_np), p.light_max, K, self._hb.ctypes.data if K > 1 else None,
-               self._lb.ctypes.data if K > 1 else None, L._p(self.state2[0]), self.state2[1].data_ptr(), p.n_games,
-               L._p(p.row_game), L._p(p.row_slot), L._p(self.actions_by_game), L._p(self.limits), n, self.pos_first,
-               L._p(self.status), L._p(self.arrive), stamps)
-        self.enqueue_final_step(n)
-        if self.time_light:
-            self._pending_stamps = 1
-            self._persistent_cycles = n
-
     def enqueue_cohort(self, k, n_cycles, stream):
         """the cycle chain of cohort k alone on `stream` (a torch stream), without the closing step: callers that breed
         and reset cohort by cohort run one such call per cohort on its own stream, then enqueue_final_step() once"""
@@ -359,13 +321,13 @@ class DeviceRollout:
         """after the replay has finished (the caller synchronised): fold this replay's clock stamps into the log"""
         n = getattr(self, "_pending_stamps", 0)
         if n:
-            rows = 1 if getattr(self, "_persistent_cycles", 0) else n * self.n_cohorts
-            st = self.stamps[:rows].cpu().numpy()  # [cohort * n + cycle][slots][2]; one row for a persistent launch
+            rows = n * self.n_cohorts
+            st = self.stamps[:rows].cpu().numpy()  # [cohort * n + cycle][slots][2]
             dur = st[:, :, 1].max(axis=1) - st[:, :, 0].min(axis=1)  # first workgroup start .. last workgroup end
             self._timed_ms.extend((dur * 1e-5).tolist())  # 100 MHz ticks -> ms
             # first start .. last end over every policy launch of this rollout (cohorts overlap; gaps included)
             self._span_ms.append(float(st[:, :, 1].max() - st[:, :, 0].min()) * 1e-5)
-            self._span_cycles = getattr(self, "_persistent_cycles", 0) or n
+            self._span_cycles = n
             self._pending_stamps = 0
 
     def _read_light_times(self, max_out=100000):

@@ -30,8 +30,7 @@ extern "C" {
 #define COEVO_OK 0
 #define COEVO_ERR_ARG (-1)   /* bad size / null pointer / unsupported shape */
 #define COEVO_ERR_HIP (-2)   /* a HIP runtime call failed (hipGetLastError has the detail) */
-#define COEVO_ERR_UNSUPPORTED (-3)  /* valid arguments this entry point cannot serve (e.g. not all workgroups of a
-                                       persistent launch would be resident): use the general entry point instead */
+#define COEVO_ERR_UNSUPPORTED (-3)  /* valid arguments this entry point cannot serve: use the general entry point instead */
 
 /* device status word bits (MPE/fcnetwork.py:39,49,57,65,87; utils/game_logic_functions.py:172-177) */
 #define COEVO_ST_BAD_INPUT 1
@@ -39,8 +38,6 @@ extern "C" {
 #define COEVO_ST_BAD_FC2 4
 #define COEVO_ST_BAD_OUT 8
 #define COEVO_ST_NO_ACTION 16
-#define COEVO_ST_TIMEOUT 32     /* coevo_mpe_rollout_persistent: a workgroup waited too long for its cohort - the
-                                   launch was abandoned, its results are invalid */
 
 /* FCNetwork geometry (MPE/fcnetwork.py:14-22) */
 #define COEVO_FC_H1 512
@@ -200,22 +197,6 @@ int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_task *heavy_
                                   int32_t *act_cur, const int32_t *game_limit, int cycle, int pos_first,
                                   int32_t *status, uint64_t *stamps, int concurrent_launches, int heavy_max_rows,
                                   void *stream);
-/* The whole rollout in ONE persistent launch (lean kernel: shared-opponent tasks of <= 16 rows, per-individual tasks of
- * <= 8 rows, fused env step): every workgroup keeps its task for all n_cycles env-cycles, the cycle boundary is an
- * arrival counter + "go" word per cohort in device memory (`arrive`, COEVO_PERSIST_WORDS ints, zeroed here), so the execute-once code of a
- * cycle stays in the instruction cache and no launch gap separates the cycles.  Same results as n_cycles merged
- * launches per cohort.  Returns COEVO_ERR_UNSUPPORTED when the n_heavy + n_light workgroups would not all be resident
- * (they wait for each other); nothing has been enqueued then.  Nothing else should occupy the device's CUs for long
- * while it runs.  A workgroup that waits ~0.2 s sets COEVO_ST_TIMEOUT in *status and the launch drains.
- * The caller closes the books with coevo_mpe_final_step(cycle = n_cycles - 1). */
-int coevo_mpe_rollout_persistent_capacity(int light_max_rows);  /* workgroups resident at once (cached; >= 0) */
-int coevo_mpe_rollout_persistent(const float *slab, const coevo_fc_task *heavy_tasks, int n_heavy, int heavy_max_rows,
-                                 const coevo_fc_task *light_tasks, int n_light, int light_max_rows, int n_cohorts,
-                                 const int32_t *heavy_begin /* host, n_cohorts+1 */, const int32_t *light_begin,
-                                 double *state, double *state_alt, int n_games, const int32_t *row_game,
-                                 const int32_t *row_slot, int32_t *actions_by_game, const int32_t *game_limit,
-                                 int n_cycles, int pos_first, int32_t *status, int32_t *arrive, uint64_t *stamps,
-                                 void *stream);
 int coevo_mpe_final_step(const double *state, int n_games, const int32_t *actions_by_game, int cycle,
                          const int32_t *game_limit, int pos_first, double *rewards, void *stream);
 

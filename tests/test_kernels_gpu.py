@@ -243,11 +243,11 @@ def test_device_rollout_matches_oracle_play_game(limit, max_cycles):
     ("two_launches", 2, 32), ("merged", 2, 32), ("cohorts2", 2, 32), ("cohorts3_eager", 2, 32),
     # the lean kernel (16-row shared-opponent tiles) and every per-individual row-count instantiation (1, 2, 5, 8)
     ("merged", 1, 16), ("merged", 2, 16), ("merged", 5, 16), ("merged", 8, 16), ("cohorts2", 5, 16),
-    ("merged", 5, 32), ("merged", 8, 32), ("persistent", 5, 16), ("persistent_cohorts2", 3, 16)])
-def test_rollout_variants_match_oracle(mode, nh, heavy_rows, monkeypatch):
+    ("merged", 5, 32), ("merged", 8, 32)])
+def test_rollout_variants_match_oracle(mode, nh, heavy_rows):
     """A GA-shaped batch (per-individual nets against shared opponents) through DeviceRollout: the two-launch cycle,
-    the merged one-launch cycle (32-row and lean 16-row tiles), the cohort chains and the persistent one-launch rollout
-    all give the oracle's rewards bit for bit."""
+    the merged one-launch cycle (32-row and lean 16-row tiles) and the cohort chains all give the oracle's rewards bit
+    for bit."""
     from coevonet_amd.rollout import RolloutPlan, DeviceRollout
     npop, limit, max_cycles = 20, 40, 25
     nets10 = make_nets(npop + nh, 10, seed=91, mutate=False)      # individuals (agent_0) + opponents for agent_1
@@ -257,9 +257,7 @@ def test_rollout_variants_match_oracle(mode, nh, heavy_rows, monkeypatch):
     off = [i * s10 for i in range(npop + nh)] + [(npop + nh) * s10 + k * s8 for k in range(nh)]
     D = [10] * (npop + nh) + [8] * nh
     games = [(npop + nh + k, i, npop + k) for i in range(npop) for k in range(nh)]   # (adversary, agent_0, agent_1)
-    K = {"two_launches": 1, "merged": 1, "cohorts2": 2, "cohorts3_eager": 3, "persistent": 1,
-         "persistent_cohorts2": 2}[mode]
-    monkeypatch.setenv("COEVO_PERSISTENT", "1" if mode.startswith("persistent") else "0")
+    K = {"two_launches": 1, "merged": 1, "cohorts2": 2, "cohorts3_eager": 3}[mode]
     plan = RolloutPlan(np.array(games), off, D, device=DEV, n_cohorts=K, heavy_rows=heavy_rows)
     assert plan.n_cohorts == K and len(plan.heavy_np) > 0 and len(plan.light_np) == npop
     assert plan.light_max == nh and plan.heavy_max <= heavy_rows
@@ -269,11 +267,7 @@ def test_rollout_variants_match_oracle(mode, nh, heavy_rows, monkeypatch):
     ro.set_limits(np.full(plan.n_games, T))
     first = 3
     ro.reset(0, plan.n_games, first)
-    if mode.startswith("persistent"):
-        assert ro.persistent_ok()
-        ro.enqueue_persistent((T + 2) // 3)
-    else:
-        ro.run((T + 2) // 3)
+    ro.run((T + 2) // 3)
     torch.cuda.synchronize()
     ro.check_status()
     r = ro.rewards.cpu().numpy()

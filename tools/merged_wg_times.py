@@ -19,10 +19,7 @@ eng, ro = tr.eng, tr.eng.ro
 tr.step()
 ro.use_graph = False
 for i in range(2):
-    if ro.persistent_ok():
-        ro.enqueue_persistent(eng.n_cycles)
-    else:
-        ro.run(eng.n_cycles)
+    ro.run(eng.n_cycles)
 torch.cuda.synchronize()
 nh, nl = len(eng.plan.heavy_np), len(eng.plan.light_np)
 lean = eng.plan.heavy_max <= 16 and nh + nl <= 1024
@@ -57,13 +54,6 @@ if len(light):
     idx = [(1, 8), (8, 9), (9, 10), (10, 11), (11, 12)]
     for nm, (i, j) in zip(names, idx):
         print(f"  light {nm:34s} {np.mean(f[:, j] - f[:, i]) / 100.0:6.2f} us")
-
-if st[:, 14].max() > 0:   # persistent rollout kernel: the last cycle's wait
-    wait = (st[:, 14] - st[:, 13]) / 100.0
-    print(f"persistent: wait for the cohort (last cycle) mean {wait.mean():.1f} us, min {wait.min():.1f}, max {wait.max():.1f}; "
-          f"body (stamp 0 -> 6) mean {np.mean(st[:, 6] - st[:, 0]) / 100.0:.1f} us")
-    print("  spin exit spread (us):", round(float(st[:, 14].max() - st[:, 14].min()) / 100.0, 1),
-          " body end spread:", round(float(st[:, 6].max() - st[:, 6].min()) / 100.0, 1))
 
 # per-wave stamps of the compact per-individual body: arrival at / release from each barrier of fc1 + LayerNorm(512)
 try:
