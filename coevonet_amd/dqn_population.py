@@ -84,9 +84,17 @@ class SynthRollout:
             lane["frames"] = torch.zeros(m * FRAME * C, dtype=torch.uint8, device=device)
             lane["actions"] = torch.zeros(2, m, dtype=torch.int32, device=device)
             lane["ws"] = torch.zeros(int(L.load().coevo_dqn_workspace_bytes(m)) // 4, dtype=torch.float32, device=device)
-            lane["stream"] = None if not self.lanes else torch.cuda.Stream(device=device)
+            lane["stream"] = None
             lane["done"] = torch.cuda.Event() if self.lanes else None
             self.lanes.append(lane)
+        if len(self.lanes) > 1:
+            # the cohorts' own streams: created by the library with hipStreamNonBlocking (streams from torch's pool landed
+            # on the caller's hardware queue here - the kernel trace showed both cohorts' launches back to back on it)
+            self._lane_ctx = L.load().coevo_rollout_ctx_create(0)
+            L.call("coevo_rollout_ctx_reserve_cohorts", self._lane_ctx, len(self.lanes))
+            for k in range(1, len(self.lanes)):
+                self.lanes[k]["stream"] = torch.cuda.ExternalStream(
+                    L.load().coevo_rollout_ctx_cohort_stream(self._lane_ctx, k), device=device)
         self.tasks_np = [np.concatenate([ln["tasks_np"][p] for ln in self.lanes]) for p in range(2)]
         self._fork = torch.cuda.Event() if len(self.lanes) > 1 else None
         self.timing_ctx = None      # set by start_timing(): HIP events around sampled launches (eager only)
