@@ -39,8 +39,11 @@ class DistContext:
         if self.world > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            backend = backend or os.environ.get("COEVO_DIST_BACKEND") or \
-                ("nccl" if torch.cuda.is_available() else "gloo")
+            # RCCL needs one device per rank ("Duplicate GPU detected" otherwise): with more local ranks than GPUs (a
+            # rehearsal on a one-GPU box) the ranks share the device and the gathers go through gloo
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(self.world)))
+            one_gpu_per_rank = torch.cuda.is_available() and torch.cuda.device_count() >= local_world
+            backend = backend or os.environ.get("COEVO_DIST_BACKEND") or ("nccl" if one_gpu_per_rank else "gloo")
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank % max(torch.cuda.device_count(), 1))
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
