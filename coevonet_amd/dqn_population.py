@@ -91,7 +91,7 @@ class SynthRollout:
             # the cohorts' own streams: created by the library with hipStreamNonBlocking (streams from torch's pool landed
             # on the caller's hardware queue here - the kernel trace showed both cohorts' launches back to back on it)
             self._lane_ctx = L.load().coevo_rollout_ctx_create(0)
-            L.call("coevo_rollout_ctx_reserve_cohorts", self._lane_ctx, len(self.lanes))
+            L._check(L.load().coevo_rollout_ctx_reserve_cohorts(self._lane_ctx, len(self.lanes)), "coevo_rollout_ctx_reserve_cohorts")
             for k in range(1, len(self.lanes)):
                 self.lanes[k]["stream"] = torch.cuda.ExternalStream(
                     L.load().coevo_rollout_ctx_cohort_stream(self._lane_ctx, k), device=device)

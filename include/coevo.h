@@ -158,7 +158,6 @@ typedef struct {
                                     cohort); 0 = none.  Only sizes the merged launch (coevo_mpe_policy_cycle_merged) */
 } coevo_rollout_desc;
 #define COEVO_MAX_COHORTS 8
-#define COEVO_PERSIST_WORDS (32 * (1 + COEVO_MAX_COHORTS))
 void *coevo_rollout_ctx_create(int n_timing_pairs);
 void coevo_rollout_ctx_destroy(void *ctx);
 /* create the streams for rollouts with up to n_cohorts cohorts; must not be called during graph capture */
