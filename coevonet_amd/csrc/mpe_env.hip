@@ -52,15 +52,29 @@ __device__ inline u128 pcg_advance(u128 state, u128 inc, uint64_t delta)
 // numpy Generator semantics of one PettingZoo reset: choice(2) = one buffered 32-bit draw (the low half of a
 // 64-bit output for even ordinals, the kept high half for odd ones; Lemire range 2 => top bit), then ten
 // uniform(-1,1) doubles.  Two resets consume 21 raw 64-bit outputs.
+__device__ __forceinline__ void mpe_reset_game(double *st, int n, int g, coevo_pcg64 rng, uint64_t ordinal);
+
 __global__ void mpe_reset_kernel(double *st, int n, int game_first, int count, coevo_pcg64 rng,
                                  int64_t first_ordinal, const int32_t *gen_dev, int64_t ordinals_per_gen)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    const int g = game_first + i;
     int64_t first = first_ordinal + (gen_dev ? (int64_t)(*gen_dev) * ordinals_per_gen : 0);
     if (first < 0) first = 0;  // a batch that is disabled in this generation (e.g. no previous evaluation yet)
-    const uint64_t ordinal = (uint64_t)first + (uint64_t)i;
+    mpe_reset_game(st, n, game_first + i, rng, (uint64_t)first + (uint64_t)i);
+}
+
+struct ResetSegs { coevo_reset_seg s[COEVO_MAX_JOBS]; };
+__global__ void mpe_reset_multi_kernel(double *st, int n, ResetSegs segs, coevo_pcg64 rng)
+{
+    const coevo_reset_seg &sg = segs.s[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sg.count) return;
+    mpe_reset_game(st, n, sg.game_first + i, rng, sg.first_ordinal + (uint64_t)i);
+}
+
+__device__ __forceinline__ void mpe_reset_game(double *st, int n, int g, coevo_pcg64 rng, uint64_t ordinal)
+{
     const u128 inc = ((u128)rng.pcg_inc_hi << 64) | rng.pcg_inc_lo;
     u128 s = ((u128)rng.pcg_state_hi << 64) | rng.pcg_state_lo;
     s = pcg_advance(s, inc, (ordinal >> 1) * 21);
@@ -204,6 +218,24 @@ extern "C" int coevo_mpe_reset_gen(double *state, int n_games, int game_first, i
     if (count == 0) return COEVO_OK;
     hipLaunchKernelGGL(coevo::mpe_reset_kernel, dim3((count + 127) / 128), dim3(128), 0, (hipStream_t)stream,
                        state, n_games, game_first, count, rng, first_ordinal, gen_dev, ordinals_per_gen);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_mpe_reset_multi(double *state, int n_games, const coevo_reset_seg *segs, int n_segs, coevo_pcg64 rng,
+                                     void *stream)
+{
+    if (!state || n_games <= 0 || !segs || n_segs < 1 || n_segs > COEVO_MAX_JOBS) return COEVO_ERR_ARG;
+    coevo::ResetSegs rs{};
+    int cmax = 0;
+    for (int i = 0; i < n_segs; ++i) {
+        if (segs[i].game_first < 0 || segs[i].count < 0 || segs[i].game_first + segs[i].count > n_games) return COEVO_ERR_ARG;
+        rs.s[i] = segs[i];
+        cmax = segs[i].count > cmax ? segs[i].count : cmax;
+    }
+    if (cmax == 0) return COEVO_OK;
+    hipLaunchKernelGGL(coevo::mpe_reset_multi_kernel, dim3((cmax + 127) / 128, n_segs), dim3(128), 0, (hipStream_t)stream,
+                       state, n_games, rs, rng);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

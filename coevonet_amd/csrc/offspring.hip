@@ -42,16 +42,14 @@ __device__ inline void slab_quad_normals(uint64_t seed, uint32_t slo, uint32_t s
     }
 }
 
-__global__ __launch_bounds__(256) void fc_perturb_kernel(const float *parent_slab, const int32_t *parent_idx,
-                                                          float *child_slab, int child_first, int D,
-                                                          const float *sigma_dev, uint64_t seed,
-                                                          uint32_t stream_lo_first, uint32_t stream_hi,
-                                                          int skip_layernorm, const int32_t *gen_dev,
-                                                          const float *dist_ref, double *dist_partial)
+// one workgroup's 1024 slab positions of child c (block bx of nblocks); shared by the single- and the multi-role launch
+__device__ __forceinline__ void fc_perturb_block(const float *parent_slab, const int32_t *parent_idx, float *child_slab,
+                                                 int child_first, int D, const float *sigma_dev, uint64_t seed,
+                                                 uint32_t stream_lo_first, uint32_t stream_hi, int skip_layernorm,
+                                                 const int32_t *gen_dev, const float *dist_ref, double *dist_partial,
+                                                 int c, int bx, int nblocks, double *scratch)
 {
-    __shared__ double scratch[4];
     if (gen_dev) stream_hi += 4u * (uint32_t)(*gen_dev);  // generation-indexed noise stream without a host argument
-    const int c = blockIdx.y;
     // flags: bit 0 = leave LayerNorm affine untouched (ES), bit 1 = antithetic pairs (extension mode): individuals 2m and
     // 2m+1 share noise stream m, the odd one takes -eps
     const bool antithetic = (skip_layernorm & 2) != 0;
@@ -60,7 +58,7 @@ __global__ __launch_bounds__(256) void fc_perturb_kernel(const float *parent_sla
     const uint32_t slo = antithetic ? (ind >> 1) : ind;
     const bool negate = antithetic && (ind & 1u);
     const int64_t stride = fc_stride(D), P = fc_params(D);
-    const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int64_t s0 = ((int64_t)bx * 256 + threadIdx.x) * 4;
     double d2 = 0.0;
     if (s0 < stride) {
         const float sigma = *sigma_dev;
@@ -110,8 +108,34 @@ __global__ __launch_bounds__(256) void fc_perturb_kernel(const float *parent_sla
     }
     if (dist_partial) {  // wave-uniform
         const double tot = block_sum_f64(d2, scratch);
-        if (threadIdx.x == 0) dist_partial[(size_t)c * gridDim.x + blockIdx.x] = tot;
+        if (threadIdx.x == 0) dist_partial[(size_t)c * nblocks + bx] = tot;
     }
+}
+
+__global__ __launch_bounds__(256) void fc_perturb_kernel(const float *parent_slab, const int32_t *parent_idx,
+                                                          float *child_slab, int child_first, int D,
+                                                          const float *sigma_dev, uint64_t seed,
+                                                          uint32_t stream_lo_first, uint32_t stream_hi,
+                                                          int skip_layernorm, const int32_t *gen_dev,
+                                                          const float *dist_ref, double *dist_partial)
+{
+    __shared__ double scratch[4];
+    fc_perturb_block(parent_slab, parent_idx, child_slab, child_first, D, sigma_dev, seed, stream_lo_first, stream_hi,
+                     skip_layernorm, gen_dev, dist_ref, dist_partial, blockIdx.y, blockIdx.x, gridDim.x, scratch);
+}
+
+struct PerturbJobs { coevo_fc_perturb_job j[COEVO_MAX_JOBS]; };
+// blockIdx.z = job (role); the grid covers the largest job, the surplus workgroups of the others leave at once
+__global__ __launch_bounds__(256) void fc_perturb_multi_kernel(PerturbJobs jobs, uint64_t seed, int skip_layernorm,
+                                                                const int32_t *gen_dev)
+{
+    __shared__ double scratch[4];
+    const coevo_fc_perturb_job &jb = jobs.j[blockIdx.z];
+    const int nblocks = (int)((fc_stride(jb.D) / 4 + 255) / 256);
+    if ((int)blockIdx.x >= nblocks || (int)blockIdx.y >= jb.n_children) return;   // workgroup-uniform
+    fc_perturb_block(jb.parent_slab, jb.parent_idx, jb.child_slab, jb.child_first, jb.D, jb.sigma_dev, seed,
+                     jb.stream_lo_first, jb.stream_hi, skip_layernorm, gen_dev, jb.dist_ref, jb.dist_partial, blockIdx.y,
+                     blockIdx.x, nblocks, scratch);
 }
 
 // New elites without gathering them from whichever GPU evaluated them: elite e of this generation is individual
@@ -421,6 +445,29 @@ extern "C" int coevo_fc_perturb_dist(const float *parent_slab, const int32_t *pa
     hipLaunchKernelGGL(fc_perturb_kernel, grid, dim3(256), 0, (hipStream_t)stream, parent_slab, parent_idx,
                        child_slab, child_first, D, sigma_dev, seed, stream_lo_first, stream_hi, skip_layernorm, gen_dev,
                        dist_ref, dist_partial);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_fc_perturb_dist_multi(const coevo_fc_perturb_job *jobs, int n_jobs, uint64_t seed, int skip_layernorm,
+                                           const int32_t *gen_dev, void *stream)
+{
+    if (!jobs || n_jobs < 1 || n_jobs > COEVO_MAX_JOBS || skip_layernorm < 0 || skip_layernorm > 3) return COEVO_ERR_ARG;
+    PerturbJobs pj{};
+    unsigned gx = 0, gy = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const coevo_fc_perturb_job &j = jobs[i];
+        if ((j.dist_ref == nullptr) != (j.dist_partial == nullptr)) return COEVO_ERR_ARG;
+        if (!j.parent_slab || !j.parent_idx || !j.child_slab || !j.sigma_dev || !fc_dim_ok(j.D)) return COEVO_ERR_ARG;
+        if (j.n_children < 0 || j.child_first < 0 || j.n_children > 65535) return COEVO_ERR_ARG;
+        pj.j[i] = j;
+        const unsigned nb = (unsigned)((fc_stride(j.D) / 4 + 255) / 256);
+        gx = nb > gx ? nb : gx;
+        gy = (unsigned)j.n_children > gy ? (unsigned)j.n_children : gy;
+    }
+    if (gy == 0) return COEVO_OK;
+    hipLaunchKernelGGL(fc_perturb_multi_kernel, dim3(gx, gy, (unsigned)n_jobs), dim3(256), 0, (hipStream_t)stream, pj, seed,
+                       skip_layernorm, gen_dev);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

@@ -53,6 +53,22 @@ __global__ __launch_bounds__(64) void dist_finalize_kernel(const double *partial
     }
 }
 
+struct FinalizeJobs { coevo_fc_finalize_job j[COEVO_MAX_JOBS]; };
+__global__ __launch_bounds__(64) void dist_finalize_multi_kernel(FinalizeJobs jobs)
+{
+    const coevo_fc_finalize_job &jb = jobs.j[blockIdx.y];
+    const int c = blockIdx.x, l = threadIdx.x;
+    if (c >= jb.n) return;
+    double v = 0.0;
+    for (int b = l; b < jb.n_blocks; b += 64) v += jb.dist_partial[(size_t)c * jb.n_blocks + b];
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = v + __shfl_xor(v, m, 64);
+    if (l == 0) {
+        jb.dist[jb.first + c] = (float)sqrt(v);
+        if (c == 0 && jb.head) jb.dist[jb.first - 1] = *jb.head;
+    }
+}
+
 __global__ void gather_f32_kernel(float *dst, const float *src, const int32_t *idx, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -293,6 +309,23 @@ extern "C" int coevo_fc_distance_finalize(const double *partial, int n_blocks, i
     if (!partial || !dist || n_blocks <= 0 || n <= 0 || first < 0 || (head && first < 1)) return COEVO_ERR_ARG;
     hipLaunchKernelGGL(dist_finalize_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, partial, n_blocks, dist, first,
                        head);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_fc_distance_finalize_multi(const coevo_fc_finalize_job *jobs, int n_jobs, void *stream)
+{
+    if (!jobs || n_jobs < 1 || n_jobs > COEVO_MAX_JOBS) return COEVO_ERR_ARG;
+    FinalizeJobs fj{};
+    int nmax = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const coevo_fc_finalize_job &j = jobs[i];
+        if (!j.dist_partial || !j.dist || j.n_blocks <= 0 || j.n < 0 || j.first < 0 || (j.head && j.first < 1)) return COEVO_ERR_ARG;
+        fj.j[i] = j;
+        nmax = j.n > nmax ? j.n : nmax;
+    }
+    if (nmax == 0) return COEVO_OK;
+    hipLaunchKernelGGL(dist_finalize_multi_kernel, dim3(nmax, n_jobs), dim3(64), 0, (hipStream_t)stream, fj);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

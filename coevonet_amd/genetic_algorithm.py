@@ -450,30 +450,37 @@ class GAEngine:
 
     def _breed_cohort(self, k, noise_gen):
         """children of the individuals of cohort k (child c = individual c + 1; individual 0 is the unchanged best),
-        bred from the elites of generation `noise_gen` with that generation's noise streams"""
+        bred from the elites of generation `noise_gen` with that generation's noise streams: the three roles in ONE
+        perturb launch and one distance reduction (as six launches they queued in front of the cohort's chain)"""
         lo_k, hi_k = self._cohort_individuals(k)
         c_lo, c_hi = max(lo_k, 1) - 1, hi_k - 1
-        for ri, r in enumerate(ROLES):
-            D = ROLE_D[r]
-            if c_hi > c_lo:
+        if c_hi > c_lo:
+            import ctypes as ct
+            pj = (L.PerturbJob * 3)()
+            fj = (L.FinalizeJob * 3)()
+            for ri, r in enumerate(ROLES):
                 part = self.dist_partial[r].data_ptr() + 8 * c_lo * self.pblocks[r]
-                L.call("coevo_fc_perturb_dist", self._ptr(r, "elite"), self.parent_idx.data_ptr() + 4 * c_lo,
-                       self._ptr(r, "pop"), 1 + c_lo, c_hi - c_lo, D, self.sigma32.data_ptr() + 4 * ri,
-                       self.philox_seed, c_lo, noise_gen * 4 + ri, 0, None, self._ptr(r, "stale"), part)
-                L.call("coevo_fc_distance_finalize", part, self.pblocks[r], c_hi - c_lo, L._p(self.dist[r]), 1 + c_lo,
-                       L._p(self.best_dist[r]) if c_lo == 0 else None)
-            elif lo_k == 0:
+                pj[ri] = L.PerturbJob(self._ptr(r, "elite"), self.parent_idx.data_ptr() + 4 * c_lo, self._ptr(r, "pop"),
+                                      self.sigma32.data_ptr() + 4 * ri, self._ptr(r, "stale"), part, 1 + c_lo,
+                                      c_hi - c_lo, ROLE_D[r], c_lo, noise_gen * 4 + ri, 0)
+                fj[ri] = L.FinalizeJob(part, self.dist[r].data_ptr(),
+                                       self.best_dist[r].data_ptr() if c_lo == 0 else None, self.pblocks[r],
+                                       c_hi - c_lo, 1 + c_lo, 0)
+            L.call("coevo_fc_perturb_dist_multi", ct.cast(pj, ct.c_void_p), 3, self.philox_seed, 0, None)
+            L.call("coevo_fc_distance_finalize_multi", ct.cast(fj, ct.c_void_p), 3)
+        elif lo_k == 0:
+            for r in ROLES:
                 self.dist[r][0:1].copy_(self.best_dist[r])
 
     def _reset_cohort(self, k, gen):
         lo_k, hi_k = self._cohort_individuals(k)
         base, M = self._ordinal_base(gen), 3 * self.pop * self.hof
         per_phase = self.n_local * self.hof
-        for ph in range(3):
-            self.ro.reset(ph * per_phase + (lo_k - self.lo) * self.hof, (hi_k - lo_k) * self.hof,
-                          base + ph * self.pop * self.hof + lo_k * self.hof)
+        segs = [(ph * per_phase + (lo_k - self.lo) * self.hof, (hi_k - lo_k) * self.hof,
+                 base + ph * self.pop * self.hof + lo_k * self.hof) for ph in range(3)]
         if k == self.K - 1 and gen > 0:
-            self.ro.reset(self.n_main, N_EVAL, self._ordinal_base(gen - 1) + M)
+            segs.append((self.n_main, N_EVAL, self._ordinal_base(gen - 1) + M))
+        self.ro.reset_segments(segs)
 
     def flush_breeding(self):
         """the pipelined loop breeds generation g+1's population at the start of call g+1; anything that reads the

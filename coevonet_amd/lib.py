@@ -42,6 +42,22 @@ class PCG64State(C.Structure):
         return cls(st["state"] >> 64, st["state"] & m, st["inc"] >> 64, st["inc"] & m)
 
 
+class PerturbJob(C.Structure):   # coevo_fc_perturb_job
+    _fields_ = [("parent_slab", C.c_void_p), ("parent_idx", C.c_void_p), ("child_slab", C.c_void_p),
+                ("sigma_dev", C.c_void_p), ("dist_ref", C.c_void_p), ("dist_partial", C.c_void_p),
+                ("child_first", C.c_int32), ("n_children", C.c_int32), ("D", C.c_int32),
+                ("stream_lo_first", C.c_uint32), ("stream_hi", C.c_uint32), ("pad", C.c_int32)]
+
+
+class FinalizeJob(C.Structure):  # coevo_fc_finalize_job
+    _fields_ = [("dist_partial", C.c_void_p), ("dist", C.c_void_p), ("head", C.c_void_p), ("n_blocks", C.c_int32),
+                ("n", C.c_int32), ("first", C.c_int32), ("pad", C.c_int32)]
+
+
+class ResetSeg(C.Structure):     # coevo_reset_seg
+    _fields_ = [("game_first", C.c_int32), ("count", C.c_int32), ("first_ordinal", C.c_uint64)]
+
+
 class RolloutDesc(C.Structure):
     _fields_ = [("slab", C.c_void_p), ("heavy", C.c_void_p), ("n_heavy", C.c_int32), ("heavy_max_rows", C.c_int32),
                 ("light", C.c_void_p), ("n_light", C.c_int32), ("light_max_rows", C.c_int32),
@@ -78,6 +94,9 @@ _SIGS = {
     "coevo_fc_forward_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "coevo_mpe_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, PCG64State, C.c_uint64, C.c_void_p]),
+    "coevo_mpe_reset_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, PCG64State, C.c_void_p]),
+    "coevo_fc_perturb_dist_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]),
+    "coevo_fc_distance_finalize_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "coevo_mpe_reset_gen": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, PCG64State, C.c_int64, C.c_void_p,
                                       C.c_int64, C.c_void_p]),
     "coevo_mpe_observe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

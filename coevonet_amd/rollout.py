@@ -15,6 +15,8 @@ cycle's policy launch (each row derives its game's state from the previous buffe
 """
 from __future__ import annotations
 
+import ctypes as _ct
+
 import os
 
 import numpy as np
@@ -249,6 +251,11 @@ class DeviceRollout:
         """games [game_first, game_first+n_games) take reset ordinals first_ordinal.. of the seeded stream"""
         L.call("coevo_mpe_reset", L._p(self.state), self.plan.n_games, int(game_first), int(n_games), self.rng,
                int(first_ordinal))
+
+    def reset_segments(self, segs):
+        """several (game_first, n_games, first_ordinal) resets in ONE launch (<= 4 segments)"""
+        arr = (L.ResetSeg * len(segs))(*[L.ResetSeg(int(a), int(b), int(c)) for a, b, c in segs])
+        L.call("coevo_mpe_reset_multi", L._p(self.state), self.plan.n_games, _ct.cast(arr, _ct.c_void_p), len(segs), self.rng)
 
     def run(self, n_cycles):
         """enqueue n_cycles world cycles + the rewards kernel.  With use_graph the enqueue is captured once per

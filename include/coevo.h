@@ -97,6 +97,11 @@ typedef struct {
  * utils/game_logic_functions.py:54); each game jumps straight to its ordinal, so shards need no common prefix. */
 int coevo_mpe_reset(double *state, int n_games, int game_first, int count, coevo_pcg64 rng, uint64_t first_ordinal,
                     void *stream);
+/* up to COEVO_MAX_JOBS (game range, first ordinal) segments in one launch (a cohort's three role phases + the evaluation
+ * games); same results as one coevo_mpe_reset per segment */
+typedef struct { int32_t game_first, count; uint64_t first_ordinal; } coevo_reset_seg;
+int coevo_mpe_reset_multi(double *state, int n_games, const coevo_reset_seg *segs /* host */, int n_segs,
+                          coevo_pcg64 rng, void *stream);
 /* the same with the generation taken from a device counter: first ordinal = first_ordinal + (*gen_dev) *
  * ordinals_per_gen (clamped at 0), so a captured hipGraph of a whole generation can be replayed unchanged */
 int coevo_mpe_reset_gen(double *state, int n_games, int game_first, int count, coevo_pcg64 rng, int64_t first_ordinal,
@@ -235,6 +240,22 @@ int coevo_fc_perturb_dist(const float *parent_slab, const int32_t *parent_idx, f
 int coevo_fc_distance_finalize(const double *dist_partial, int n_blocks, int n, float *dist, int first,
                                const float *head, void *stream);
 int coevo_gather_f32(float *dst, const float *src, const int32_t *idx, int n, void *stream);  /* dst[i]=src[idx[i]] */
+/* The breeding of several roles in ONE launch each (a generation of genetic_algorithm.py:296-321 breeds every role
+ * right after the other; as nine separate 10-40 us launches per cohort they sat in front of every rollout chain).
+ * Job j = the arguments of one coevo_fc_perturb_dist / coevo_fc_distance_finalize call; results are identical to the
+ * per-role calls.  `jobs` is host memory, n_jobs <= COEVO_MAX_JOBS. */
+#define COEVO_MAX_JOBS 4
+typedef struct {
+    const float *parent_slab; const int32_t *parent_idx; float *child_slab; const float *sigma_dev;
+    const float *dist_ref; double *dist_partial;
+    int32_t child_first, n_children, D; uint32_t stream_lo_first, stream_hi; int32_t pad;
+} coevo_fc_perturb_job;
+int coevo_fc_perturb_dist_multi(const coevo_fc_perturb_job *jobs, int n_jobs, uint64_t seed, int skip_layernorm,
+                                const int32_t *gen_dev, void *stream);
+typedef struct {
+    const double *dist_partial; float *dist; const float *head; int32_t n_blocks, n, first, pad;
+} coevo_fc_finalize_job;
+int coevo_fc_distance_finalize_multi(const coevo_fc_finalize_job *jobs, int n_jobs, void *stream);
 /* Multi-GPU Co-GA: this generation's elites (ids order[0..E-1] on the device) rebuilt from LAST generation's elites
  * and the counter-based noise their children were bred with (id 0 = last best unchanged, id >= 1 = elite_prev[(id-1)%E]
  * + sigma_prev*eps(stream (id-1, stream_hi_prev))): no weight crosses xGMI, every rank gets identical bits.
