@@ -4,11 +4,12 @@
 // per-sample, per-channel statistics over the spatial positions: batching must not mix samples.
 //
 // Three launches per env step:
-//   dqn_conv_kernel   one workgroup (8 waves) per frame: the uint8 HWC frame is staged in LDS once (coalesced 16-byte
-//                     loads), /255 as an exact two-term product (u8_over_255), the three convolutions run as
-//                     implicit GEMMs on v_mfma_f32_16x16x4_f32 (A = im2col gather out of LDS, B = weights [tap][cout]
-//                     from L2), BatchNorm statistics are reduced channel by channel in the canonical tree order by packed
-//                     butterflies, activations stay in LDS between layers; conv3's output goes to HBM as act[row][3136].
+//   dqn_conv_kernel   one workgroup (8 waves) per frame, three per CU: the uint8 HWC frame is staged in LDS once (coalesced
+//                     16-byte loads), /255 as an exact two-term product (u8_over_255), the three convolutions run as
+//                     implicit GEMMs on v_mfma_f32_16x16x4_f32 (A = im2col gather out of LDS, B = weights in lane
+//                     order from L2: dqn_conv_slab_to_flat), BatchNorm statistics are reduced in the canonical tree order
+//                     by packed butterflies (a wave's channels together), activations stay in LDS between layers (one
+//                     region, each layer's output written over its input); conv3's output goes to HBM as act[row][3136].
 //   dqn_fc1_kernel    the 6.4 MB fc1 matrix of each net is streamed exactly once per task (<= 16 rows): a grouped GEMV
 //                     like fc2 of the MPE net, [8][784][64][4] tiling, lane = output, rows in groups of four on
 //                     v_mfma_f32_4x4x1_16B_f32 with the activations of a chunk staged in LDS.
@@ -53,8 +54,8 @@ __global__ __launch_bounds__(256) void dqn_pack_kernel(const float *flat, float 
 // of 16, N = output channels in pairs of 16-wide tiles, K = taps, four per instruction.  A unit = (position tile, channel
 // tile pair): one LDS gather per lane feeds two MFMAs.  Unit u = w + 8 i belongs to wave w (8 waves, two per SIMD: one
 // wave's gathers hide behind the other's MFMAs), so all units of a wave share their channel pair and the pair's weight
-// operands are loaded once per k-step (8 k-steps ahead, from L2: the 16 frames of a task and every task of the same net
-// read the same 0.3 MB).  Tile padding: 400 = 25 x 16 positions (0 %), 81 -> 96 (16 %), 49 -> 64 (23 %); the 32 x 32 tiles
+// operands are loaded once per k-step pair (a chunk of QU k-steps ahead, from L2: the 16 frames of a task and every task
+// of the same net read the same 0.3 MB).  Tile padding: 400 = 25 x 16 positions (0 %), 81 -> 96 (16 %), 49 -> 64 (23 %); the 32 x 32 tiles
 // this replaces padded 400 -> 512, 81 -> 128, 49 -> 64 and left half of the waves idle in conv3.
 //   operands of one MFMA: lane (c = l % 16, kk = l / 16): A[position c of the tile][tap 4 q + kk], B[tap 4 q + kk][channel c];
 //   accumulator register r of lane (c, g = l / 16): position 4 g + r of the tile, channel c.
@@ -68,19 +69,16 @@ __device__ __forceinline__ float u8_over_255(unsigned b)
 {
     constexpr float HEAD = (float)(1.0 / 255.0), TAIL = (float)(1.0 / 255.0 - (double)HEAD);
     const float x = (float)b;
-#ifdef DQ_DIV255
-    return x / 255.0f;
-#endif
     return __builtin_fmaf(x, HEAD, x * TAIL);
 }
 
-// Addressing is organised per chunk of QU = 8 k-steps (32 taps) so that the MFMA loop issues almost no address arithmetic
+// Addressing is organised per chunk of QU k-steps (4 QU taps) so that the MFMA loop issues almost no address arithmetic
 // (SQ counters of the first 16x16x4 version: 4 VALU instructions per MFMA - 64-bit weight addresses, tap decoding - kept
 // the matrix pipe at 46 %): within a chunk the tap of k-step j, lane group kk is
 //   conv1 (8 x 8 window, t = 4 q + kk):  ci = q0 / 16, ky = (q0 / 2) % 8 + j / 2, kx = kk + 4 (j % 2)
 //   conv2 (4 x 4):                        ci = q0 / 4 + j / 4, ky = j % 4, kx = kk
 // i.e. one per-lane chunk base + a compile-time offset per j (an instruction immediate); conv3's 3 x 3 window does not
-// decompose that way: its offsets come from a 16-bit table in LDS (1.1 KB: still two workgroups per CU).
+// decompose that way: its offsets come from a 16-bit table in LDS (1.1 KB).
 template <int KS, int HIN, bool U8IN, int IN_PITCH, int CT>
 struct TapAddr {
     // offset of tap (chunk q0, step j, lane group kk) = chunk_base(q0, kk) + rel(j)
@@ -105,11 +103,7 @@ struct Conv16 {
     static constexpr int NPOS = HOUT * HOUT, NM = (NPOS + 15) / 16, NP = COUT / 32, NUNITS = NM * NP;
     // SPLIT (conv1: 25 units on 8 waves): every wave takes three whole units and the 25th is halved between waves 0 and 1
     // (they sit on different SIMDs), one channel tile each: 7 MFMAs per k-step on the critical waves instead of 8
-#ifdef DQ_NO_SPLIT
-    static constexpr bool SPLIT = false;
-#else
     static constexpr bool SPLIT = (NP == 1) && (NUNITS % 8 == 1);
-#endif
     static constexpr int NFULL = NUNITS / 8, REM = SPLIT ? 0 : NUNITS % 8;   // waves w < REM carry NFULL + 1 units
     static_assert(8 % NP == 0, "all units of a wave share their channel pair");
     using Tap = TapAddr<KS, HIN, U8IN, IN_PITCH, CT>;
@@ -373,11 +367,7 @@ __global__ __launch_bounds__(512, DQ_WPE) void dqn_conv_kernel(const float *slab
     if (row >= n_rows) return;   // workgroup-uniform
 #endif
     const coevo_dqn_task task = tasks[task_of_row(tasks, n_tasks, row)];
-#ifdef DQ_NO_RFL
-    const int t = threadIdx.x, w = t >> 6, l = t & 63;
-#else
     const int t = threadIdx.x, w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;   // w: scalar (wave-uniform branches)
-#endif
     const float *net = slab + task.net_off;
     const DqnLayout L = dqn_layout(C, n_actions);
     // stage the frame (84*84*C bytes, a multiple of 16)
@@ -393,15 +383,9 @@ __global__ __launch_bounds__(512, DQ_WPE) void dqn_conv_kernel(const float *slab
     conv16_mfma<8, 4, 84, 20, 32, true, 0, DQ_P1, CT, DQ_QU1, true>(sm.frame, sm.lut, C, C * 64, net + L.w1, net + L.b1, sm.a1, nullptr, w, l);
     __syncthreads();
     DQ_STAMP(2);
-#if defined(DQ_DUMP)
-    if (DQ_DUMP == 2) { if (row == 0) for (int i = t; i < 32 * DQ_P1; i += 512) act[i] = sm.a1[i]; return; }
-#endif
     bn_relu_rows<400, DQ_P1, 32>(sm.a1, net + L.b1 + 32, net + L.b1 + 64, w, l);
     __syncthreads();
     DQ_STAMP(3);
-#if defined(DQ_DUMP)
-    if (DQ_DUMP == 1) { if (row == 0) for (int i = t; i < 32 * DQ_P1; i += 512) act[i] = sm.a1[i]; return; }
-#endif
     conv16_mfma<4, 2, 20, 9, 64, false, DQ_P1, DQ_P2, 0, DQ_QU2, true>(sm.a1, nullptr, 32, 512, net + L.w2, net + L.b2, sm.a2, nullptr, w, l);
     __syncthreads();
     DQ_STAMP(4);
