@@ -491,11 +491,19 @@ __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &
 // ([784][64][4] tile) exactly once for the task's <= 16 rows, 28 KiB in flight (only 8 wavefronts exist per net, so the
 // memory-level parallelism has to come from depth).  The activations of a chunk (rows x 14 k-quads) are staged in LDS
 // with coalesced loads and read back as broadcasts (scalar loads of them serialise: 12 500 dependent s_loads per wave).
-__global__ __launch_bounds__(64) void dqn_fc1_kernel(const float *slab, const coevo_dqn_task *tasks, int C,
+__global__ __launch_bounds__(64) void dqn_fc1_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int C,
                                                       int n_actions, const float *act, float *hid)
 {
     __shared__ __attribute__((aligned(16))) float xs[2][DQ_RMAX][14 * 4];
-    const coevo_dqn_task task = tasks[blockIdx.x];
+    // XCD x takes a contiguous range of tasks (gridDim.x is a multiple of 8, so the output block blockIdx.y does not change
+    // the XCD): the several <= 16-row tasks of a net that acts in many games stream the same matrix block through ONE L2
+#ifdef DQ_NO_XCD_MAP
+    const int ti = blockIdx.x;
+#else
+    const int ti = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+#endif
+    if (ti >= n_tasks) return;
+    const coevo_dqn_task task = tasks[ti];
     const float *net = slab + task.net_off;
     const DqnLayout L = dqn_layout(C, n_actions);
     const int ob = blockIdx.y, l = threadIdx.x;
@@ -615,7 +623,7 @@ extern "C" int coevo_dqn_forward_argmax_timed(const float *slab, const coevo_dqn
     else hipLaunchKernelGGL((dqn_conv_kernel<6, 0>), cg, cb, 0, s, slab, tasks, n_tasks, n_rows_total, C, n_actions, frames, act);
     if (timing_ctx && timed_kernel == 0 && coevo_timing_end(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     if (timing_ctx && timed_kernel == 1 && coevo_timing_begin(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
-    hipLaunchKernelGGL(dqn_fc1_kernel, dim3(n_tasks, 8), dim3(64), 0, s, slab, tasks, C, n_actions, act, hid);
+    hipLaunchKernelGGL(dqn_fc1_kernel, dim3(8 * ((n_tasks + 7) / 8), 8), dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, act, hid);
     if (timing_ctx && timed_kernel == 1 && coevo_timing_end(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     hipLaunchKernelGGL(dqn_out_kernel, dim3(n_rows_total), dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, hid,
                        actions, logits, status);
