@@ -24,6 +24,9 @@ namespace coevo {
 #ifndef DQ_LUT
 #define DQ_LUT 0   // 1: /255 through a 256-entry LDS table instead of u8_over_255 (measured equal at 3 workgroups per CU)
 #endif
+#ifndef DQ_FC1_U
+#define DQ_FC1_U 14   // fc1: k-quads per chunk of the weight stream (two chunks in flight)
+#endif
 #ifndef DQ_WPE
 #define DQ_WPE 6   // waves per SIMD the register budget is set for: 3 workgroups x 8 waves / 4 SIMDs
 #endif
@@ -409,9 +412,10 @@ constexpr int DQ_RMAX = 16;
 // MFMAs.  One launch serves tasks of every size: the kernel picks the instantiation by the task's own row count.
 template <int NG>
 __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &L, const coevo_dqn_task &task,
-                                             const float *act, float *hid, float (*xs)[DQ_RMAX][14 * 4], int ob, int l)
+                                             const float *act, float *hid, float (*xs)[DQ_RMAX][DQ_FC1_U * 4], int ob, int l)
 {
-    constexpr int U = 14;  // k-quads per chunk; 784 = 56 * 14; two chunks in flight (ping-pong)
+    constexpr int U = DQ_FC1_U;  // k-quads per chunk; 784 = 56 * 14; two chunks in flight (ping-pong)
+    static_assert(784 % (2 * U) == 0, "whole ping-pong rounds");
     const int nrows = task.n_rows;
     const float bb = net[L.bf + 64 * ob + l];
     // rows in groups of four on v_mfma_f32_4x4x1_16B_f32 (16 blocks x 4 columns = the wave's 64 outputs, one k per
@@ -445,7 +449,7 @@ __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &
                         : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto consume = [&](const float4 (&wv)[U], const float4 (&xr)[XI], float (*x_lds)[14 * 4]) {
+    auto consume = [&](const float4 (&wv)[U], const float4 (&xr)[XI], float (*x_lds)[DQ_FC1_U * 4]) {
 #pragma unroll
         for (int j = 0; j < XI; ++j) {
             const int i = l + 64 * j;
@@ -494,7 +498,7 @@ __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &
 __global__ __launch_bounds__(64) void dqn_fc1_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int C,
                                                       int n_actions, const float *act, float *hid)
 {
-    __shared__ __attribute__((aligned(16))) float xs[2][DQ_RMAX][14 * 4];
+    __shared__ __attribute__((aligned(16))) float xs[2][DQ_RMAX][DQ_FC1_U * 4];
     // XCD x takes a contiguous range of tasks (gridDim.x is a multiple of 8, so the output block blockIdx.y does not change
     // the XCD): the several <= 16-row tasks of a net that acts in many games stream the same matrix block through ONE L2
 #ifdef DQ_NO_XCD_MAP
