@@ -329,7 +329,7 @@ def extras(a, ctx, dev):
             ex[name] = {"error": repr(e)}
         gc.collect()
         torch.cuda.empty_cache()
-    b.steps, b.warmup = 2, 1
+    b.steps, b.warmup = 5, 2   # (two timed generations under-reported cfg5 by 15 %: the first ones carry one-off host work)
     for name, algo in (("cfg4_coga_deepqn_per_gpu_shard", "ga"), ("cfg5_coes_deepqn_per_gpu_shard", "es")):
         try:
             r = run_dqn(b, ctx, dev, algo)
