@@ -16,6 +16,11 @@ import os
 import sys
 import time
 
+# HIP maps streams onto this many hardware queues round robin (default 4): after the headline engine's cohort streams the
+# cohort stream of a later workload in the same process landed on the caller's queue and its launches serialised (cfg5 in
+# the `extra` block: 8.3 instead of 10.1 generations/s).  Read by the runtime when it starts: set before torch loads it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
