@@ -12,7 +12,7 @@ from tests.util import load_golden, sha
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("C,n_actions,rows", [(4, 6, [3, 1, 10]), (6, 18, [16, 2])])
+@pytest.mark.parametrize("C,n_actions,rows", [(4, 6, [3, 1, 10]), (6, 18, [16, 2]), (3, 6, [2, 5]), (5, 18, [4])])
 def test_dqn_forward_bit_exact_vs_oracle(C, n_actions, rows):
     torch.manual_seed(C * 10 + n_actions)
     nets = []
