@@ -509,3 +509,50 @@ def test_fused_select_and_promote_equal_separate_launches(pop):
     for slabs, ref, _ in checks:
         for got, exp in zip(slabs, ref[:3]):
             assert torch.equal(got, exp)
+
+
+def test_multi_job_launches_equal_per_role_launches():
+    """coevo_fc_perturb_dist_multi / coevo_fc_distance_finalize_multi / coevo_mpe_reset_multi (one launch for the three
+    roles / several game ranges) write the same bits as one coevo_fc_perturb_dist / coevo_fc_distance_finalize /
+    coevo_mpe_reset per role or range"""
+    roles_D, E, n, child_first = (8, 10, 10), 2, 7, 1
+    jobs_p, jobs_f, keep = (L.PerturbJob * 3)(), (L.FinalizeJob * 3)(), []
+    single, multi = [], []
+    sigma = torch.tensor([0.05, 0.02, 0.11], dtype=torch.float32, device=DEV)
+    pidx = (torch.arange(n, dtype=torch.int32, device=DEV) % E).contiguous()
+    for ri, D in enumerate(roles_D):
+        stride, nb = L.fc_slab_stride(D), int(L.load().coevo_fc_perturb_blocks(D))
+        elite = to_slab(make_nets(E, D, seed=40 + ri), D).contiguous()
+        stale = to_slab(make_nets(1, D, seed=50 + ri), D).contiguous()
+        head = torch.tensor([0.25 + ri], dtype=torch.float32, device=DEV)
+        out = []
+        for _ in range(2):
+            pop = torch.zeros(child_first + n, stride, dtype=torch.float32, device=DEV)
+            part = torch.zeros(n * nb, dtype=torch.float64, device=DEV)
+            dist = torch.zeros(child_first + n, dtype=torch.float32, device=DEV)
+            out.append((pop, part, dist))
+        (pop1, part1, dist1), (pop2, part2, dist2) = out
+        L.call("coevo_fc_perturb_dist", L._p(elite), L._p(pidx), L._p(pop1), child_first, n, D, sigma.data_ptr() + 4 * ri,
+               1234, 3, 8 + ri, 0, None, L._p(stale), L._p(part1))
+        L.call("coevo_fc_distance_finalize", L._p(part1), nb, n, L._p(dist1), child_first, L._p(head))
+        jobs_p[ri] = L.PerturbJob(L._p(elite), L._p(pidx), L._p(pop2), sigma.data_ptr() + 4 * ri, L._p(stale), L._p(part2),
+                                  child_first, n, D, 3, 8 + ri, 0)
+        jobs_f[ri] = L.FinalizeJob(L._p(part2), L._p(dist2), L._p(head), nb, n, child_first, 0)
+        keep += [elite, stale, head]
+        single.append((pop1, dist1)); multi.append((pop2, dist2))
+    L.call("coevo_fc_perturb_dist_multi", C.cast(jobs_p, C.c_void_p), 3, 1234, 0, None)
+    L.call("coevo_fc_distance_finalize_multi", C.cast(jobs_f, C.c_void_p), 3)
+    torch.cuda.synchronize()
+    for (p1, d1), (p2, d2) in zip(single, multi):
+        assert torch.equal(p1, p2) and torch.equal(d1, d2) and float(d1[1:].min()) > 0.0
+    # resets: three ranges with their own first ordinals
+    n_games, rng = 50, L.PCG64State.from_seed(1870300)
+    segs = [(0, 13, 5), (13, 20, 1000), (40, 10, 77)]
+    a = torch.zeros(L.MPE_STATE_DOUBLES, n_games, dtype=torch.float64, device=DEV)
+    b = torch.zeros_like(a)
+    for g0, cnt, first in segs:
+        L.call("coevo_mpe_reset", L._p(a), n_games, g0, cnt, rng, first)
+    arr = (L.ResetSeg * len(segs))(*[L.ResetSeg(*s) for s in segs])
+    L.call("coevo_mpe_reset_multi", L._p(b), n_games, C.cast(arr, C.c_void_p), len(segs), rng)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and float(a[:, :33].abs().sum()) > 0.0
