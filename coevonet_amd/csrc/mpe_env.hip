@@ -64,6 +64,7 @@ __global__ void mpe_reset_kernel(double *st, int n, int game_first, int count, c
     mpe_reset_game(st, n, game_first + i, rng, (uint64_t)first + (uint64_t)i);
 }
 
+static_assert(sizeof(coevo_reset_seg) == 16, "layout mirrored by coevonet_amd/lib.py ResetSeg");
 struct ResetSegs { coevo_reset_seg s[COEVO_MAX_JOBS]; };
 __global__ void mpe_reset_multi_kernel(double *st, int n, ResetSegs segs, coevo_pcg64 rng)
 {

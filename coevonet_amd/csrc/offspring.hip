@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256) void fc_perturb_kernel(const float *parent_sla
                      skip_layernorm, gen_dev, dist_ref, dist_partial, blockIdx.y, blockIdx.x, gridDim.x, scratch);
 }
 
+static_assert(sizeof(coevo_fc_perturb_job) == 72, "layout mirrored by coevonet_amd/lib.py PerturbJob");
 struct PerturbJobs { coevo_fc_perturb_job j[COEVO_MAX_JOBS]; };
 // blockIdx.z = job (role); the grid covers the largest job, the surplus workgroups of the others leave at once
 __global__ __launch_bounds__(256) void fc_perturb_multi_kernel(PerturbJobs jobs, uint64_t seed, int skip_layernorm,

@@ -53,6 +53,7 @@ __global__ __launch_bounds__(64) void dist_finalize_kernel(const double *partial
     }
 }
 
+static_assert(sizeof(coevo_fc_finalize_job) == 40, "layout mirrored by coevonet_amd/lib.py FinalizeJob");
 struct FinalizeJobs { coevo_fc_finalize_job j[COEVO_MAX_JOBS]; };
 __global__ __launch_bounds__(64) void dist_finalize_multi_kernel(FinalizeJobs jobs)
 {

@@ -233,3 +233,13 @@ def test_dqn_conv_slab_layout_is_a_permutation():
         flat = co * taps + tap
         assert co.max() == cout - 1 and tap.max() == taps - 1
         assert np.array_equal(np.sort(flat), i)
+
+
+def test_job_struct_layouts_match_the_header():
+    """the ctypes mirrors of coevo_fc_perturb_job / coevo_fc_finalize_job / coevo_reset_seg have the sizes the C side
+    static_asserts (csrc/offspring.hip, select.hip, mpe_env.hip)"""
+    import ctypes as C
+    from coevonet_amd import lib as L
+    assert (C.sizeof(L.PerturbJob), C.sizeof(L.FinalizeJob), C.sizeof(L.ResetSeg)) == (72, 40, 16)
+    assert L.PerturbJob.child_first.offset == 48 and L.FinalizeJob.n_blocks.offset == 24
+    assert L.ResetSeg.first_ordinal.offset == 8
