@@ -168,8 +168,16 @@ def main():
         out = run_dqn(a, ctx, dev, a.workload[4:])
     out.update({"n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "dist_backend": (torch.distributed.get_backend() if ctx.world > 1 else None),
                 "rccl_ranks": (torch.distributed.get_world_size() if ctx.world > 1 else 1)})
+    if ctx.world > 1:
+        us = ctx.gather_times_us()
+        # collectives of the timed region on this rank's stream (HIP events): separates exchange from compute in a scaling
+        # record.  RCCL: the stream-ordered all-gather itself; gloo (ranks sharing a device): host-staged, not xGMI.
+        out["allgather_us"] = {"per_generation": float(np.sum(us)) / max(a.steps, 1), "calls_per_generation":
+                               len(us) / max(a.steps, 1), "max_call": float(np.max(us)) if us else 0.0,
+                               "transport": "rccl" if torch.distributed.get_backend() == "nccl" else "gloo (host-staged)"}
     if ctx.rank == 0:
         if a.workload == "ga" and ctx.world == 1 and not a.no_extra:
             out["extra"] = extras(a, ctx, dev)
@@ -183,6 +191,8 @@ def _timed_steps(step, a, ctx, dev, before_timed=None):
         step()
     if before_timed:
         before_timed()
+    if ctx.world > 1:
+        ctx.start_gather_timing()   # HIP events around every collective of the timed region -> "allgather_us"
     ctx.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -308,6 +318,7 @@ def run_dqn(a, ctx, dev, algo, pop_per_gpu=None, T=None):
                                          "frac": gen_bytes * gens / 1e9 / HBM_PEAK_GBS,
                                          "note": "SURVEY 8d cfg 4/5 byte model: every distinct acting weight set once "
                                                  "per agent-step + frames"}
+    tr.close()   # cohort streams + timing events back to the library
     return out
 
 
@@ -377,6 +388,8 @@ def run_ga(a, ctx, dev):
         torch.cuda.synchronize()
         eng.ro.collect_stamps()
         eng.ro.reset_timing()
+    if ctx.world > 1:
+        ctx.start_gather_timing()
     ctx.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

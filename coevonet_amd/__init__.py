@@ -1,6 +1,16 @@
 """MI355X-native accelerator for CoEvoNet's population-evaluation hot path."""
 import os as _os
+import sys as _sys
 
-# More hardware queues for the cohort streams (HIP's default of 4 lets a later engine's cohort stream share the caller's
-# queue, which serialises its launches); only effective when set before the HIP runtime starts - bench.py sets it itself.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# GPU_MAX_HW_QUEUES: HIP maps streams onto this many hardware queues round robin (default 4).  With several engines in
+# one process a later engine's cohort stream then shares the caller's queue and its launches serialise (cfg 5 after the
+# headline engine: 8.3 instead of 10.1 generations/s), so the package asks for 8 - which only counts when the variable is
+# set BEFORE the HIP runtime starts.  Under rocprofv3 the profiler's library starts the runtime first: export it in the
+# shell (tools/profile_round.sh, tools/pmc_kernel.sh do).  bench.py records the value it ran with.
+if "GPU_MAX_HW_QUEUES" not in _os.environ:
+    _t = _sys.modules.get("torch")
+    if _t is not None and _t.cuda.is_initialized():
+        import warnings as _w
+        _w.warn("coevonet_amd: the HIP runtime started before this import, so GPU_MAX_HW_QUEUES=8 cannot take effect; "
+                "export it before the process starts (cohort streams otherwise share hardware queues)")
+    _os.environ["GPU_MAX_HW_QUEUES"] = "8"

@@ -33,8 +33,19 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _extra_flags():
+    return os.environ.get("COEVO_EXTRA_FLAGS", "").split()  # tuning experiments only, e.g. -DCOEVO_LIGHT_U=32
+
+
+def _flag_signature():
+    return " ".join(FLAGS + _extra_flags())
+
+
 def needs_build():
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    flag_file = os.path.join(OBJ, "flags.txt")
+    if not os.path.exists(flag_file) or open(flag_file).read() != _flag_signature():
+        return True   # same sources, other switches: the library on disk is another variant
     return _stale(LIB, srcs + _headers())
 
 
@@ -42,10 +53,12 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("COEVO_EXTRA_FLAGS", "").split()  # tuning experiments only, e.g. -DCOEVO_LIGHT_U=32
+    extra = _extra_flags()
+    if extra:   # reported by coevo_build_flags(); lib.load() refuses such a library outside tools/
+        extra = extra + ['-DCOEVO_TU_FLAGS="' + " ".join(extra).replace('"', "'") + '"']
     os.makedirs(OBJ, exist_ok=True)
     flag_file = os.path.join(OBJ, "flags.txt")
-    flag_sig = " ".join(FLAGS + extra)
+    flag_sig = _flag_signature()
     if not os.path.exists(flag_file) or open(flag_file).read() != flag_sig:
         force = True
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]

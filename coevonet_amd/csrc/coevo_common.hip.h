@@ -363,6 +363,15 @@ __device__ inline float relu_keep_nan(float y) { return !(y <= 0.0f) ? y : 0.0f;
 
 }  // namespace coevo
 
+// Build switches (COEVO_EXTRA_FLAGS / tools/build_variant.sh) exist for A/B measurements only.  The build passes them to every
+// translation unit it compiles under them as COEVO_TU_FLAGS; coevo_build_flags() reports the union, and
+// coevonet_amd.lib.load() refuses a library with a non-empty answer unless COEVO_ALLOW_VARIANT=1 (tools/ set it).
+#ifndef COEVO_TU_FLAGS
+#define COEVO_TU_FLAGS ""
+#endif
+#define COEVO_DEFINE_TU_FLAGS(tu) \
+    namespace coevo { const char *tu_flags_##tu() { return COEVO_TU_FLAGS; } }
+
 #define COEVO_HIP_CHECK(expr)                        \
     do {                                             \
         hipError_t _e = (expr);                      \

@@ -159,11 +159,7 @@ struct Conv16 {
             const float4 *wq = wlane + (size_t)(q0 >> 1) * (NP * 64);
 #pragma unroll
             for (int jp = 0; jp < QU / 2; ++jp) {
-#if defined(DQ_EXP) && (DQ_EXP & 2)
-                const float4 v = make_float4(__int_as_float(q0 + jp + l), __int_as_float(q0 + jp + l + 16), 0.f, 1.f);
-#else
                 const float4 v = wq[jp * NP * 64];
-#endif
                 bv[2 * jp][0] = v.x;
                 bv[2 * jp][1] = v.y;
                 bv[2 * jp + 1][0] = v.z;
@@ -183,13 +179,9 @@ struct Conv16 {
                     int off;
                     if constexpr (KS == 3) off = b0 + to[j];
                     else off = b0 + cb + Tap::rel(j, cin);
-#if defined(DQ_EXP) && (DQ_EXP & 1)
-                    return __int_as_float(off);
-#else
                     if constexpr (U8IN) return DQ_LUT ? lut[static_cast<const unsigned char *>(in_lds)[off]]
                                               : u8_over_255(static_cast<const unsigned char *>(in_lds)[off]);
                     else return static_cast<const float *>(in_lds)[off];
-#endif
                 };
 #pragma unroll
                 for (int i = 0; i < NU; ++i) {
@@ -241,6 +233,8 @@ __device__ __forceinline__ void conv16_mfma(const void *in_lds, const float *lut
                                             const float *bias, float *out, const unsigned short *tap3, int w, int l)
 {
     using K = Conv16<KS, STRIDE, HIN, HOUT, COUT, U8IN, IN_PITCH, OUT_PITCH, CT, QU, OVER>;
+    // every wave must enter run<> exactly once: the barrier of an OVER layer sits inside it
+    static_assert(K::SPLIT || K::REM == 0 || K::NFULL > 0, "a wave without units would skip run<>'s barrier");
     if constexpr (K::SPLIT) {
         if (w < 2) K::template run<K::NFULL, true>(in_lds, lut, cin, taps, wt, bias, out, tap3, w, l);
         else K::template run<K::NFULL, false>(in_lds, lut, cin, taps, wt, bias, out, tap3, w, l);
@@ -273,9 +267,6 @@ __device__ __forceinline__ void bn_relu_rows(float *x, const float *gamma, const
 {
     constexpr int NB = (NPOS + 63) / 64, CPW = COUT / 8, G = (16 / NB < CPW) ? 16 / NB : CPW, NG = CPW / G;
     static_assert(CPW % G == 0 && G * NB <= 16, "groups of G channels fill one packed butterfly");
-#if defined(DQ_EXP) && (DQ_EXP & 4)
-    return;
-#endif
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         float v[G * NB], sq[G * NB];
@@ -367,8 +358,8 @@ __global__ __launch_bounds__(512, DQ_WPE) void dqn_conv_kernel(const float *slab
 #else
     const int per = gridDim.x >> 3;
     const int row = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (row >= n_rows) return;   // workgroup-uniform
 #endif
+    if (row >= n_rows) return;   // workgroup-uniform (the grid is rounded up to a multiple of 8)
     const coevo_dqn_task task = tasks[task_of_row(tasks, n_tasks, row)];
     const int t = threadIdx.x, w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;   // w: scalar (wave-uniform branches)
     const float *net = slab + task.net_off;
@@ -642,3 +633,5 @@ extern "C" int coevo_debug_read_dqn_stamps(unsigned long long *host_out, int n_w
                    hipSuccess ? 0 : -2;
 }
 #endif
+
+COEVO_DEFINE_TU_FLAGS(deepqn)

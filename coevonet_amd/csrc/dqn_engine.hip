@@ -232,3 +232,5 @@ extern "C" int coevo_synth_step(int32_t *game_state, double *acc, int n_games, c
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }
+
+COEVO_DEFINE_TU_FLAGS(dqn_engine)

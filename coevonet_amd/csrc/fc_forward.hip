@@ -1563,3 +1563,5 @@ extern "C" int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_t
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }
+
+COEVO_DEFINE_TU_FLAGS(fc_forward)

@@ -292,3 +292,5 @@ extern "C" int coevo_mpe_rewards(const double *state, int n_games, double *rewar
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }
+
+COEVO_DEFINE_TU_FLAGS(mpe_env)

@@ -191,34 +191,56 @@ struct GaPromoteArgs {
 };
 constexpr int PROMOTE_MAX_E = 8, PROMOTE_MAX_HOF = 16;
 
+// A thread's 16-byte pieces are held in the frames of a compile-time recursion - every load on the way down, every store
+// on the way back - not in arrays: as float4 e[8], h[16] filled by unrolled loops the compiler left both in scratch
+// (400 bytes per lane).  Loads take clamped indices and stores are unconditional; a surplus level (index >= count)
+// rewrites the last slot with the value it holds anyway or that the caller overwrites next (same thread, same address,
+// program order).
+template <int I>
+__device__ __forceinline__ void promote_hof_shift(float *hof, int64_t stride, int64_t s0, int n)
+{
+    if constexpr (I < PROMOTE_MAX_HOF) {
+        const float4 v = *reinterpret_cast<const float4 *>(hof + (int64_t)(I < n ? I : n - 1) * stride + s0);
+        promote_hof_shift<I + 1>(hof, stride, s0, n);
+        *reinterpret_cast<float4 *>(hof + (int64_t)(I < n ? I - 1 : n - 1) * stride + s0) = v;
+    }
+}
+
+// elite[k] = src[idx(k)] for k < E (k descending on the way back); returns src[idx(0)]
+template <int K>
+__device__ __forceinline__ float4 promote_elites(const float *src, const int32_t *order, float *elite, bool store,
+                                                 int64_t stride, int64_t s0, int E)
+{
+    if constexpr (K < PROMOTE_MAX_E) {
+        const int kc = K < E ? K : E - 1;
+        const float4 v = *reinterpret_cast<const float4 *>(src + (int64_t)(order ? order[kc] : kc) * stride + s0);
+        promote_elites<K + 1>(src, order, elite, store, stride, s0, E);
+        if (store) *reinterpret_cast<float4 *>(elite + (int64_t)kc * stride + s0) = v;
+        return v;
+    } else {
+        return make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 __global__ __launch_bounds__(256) void ga_promote_kernel(GaPromoteArgs a)
 {
-    const coevo_ga_promote_role R = a.role[blockIdx.y];
-    const int64_t stride = fc_stride(R.D);
+    // (field-wise scalar selects: indexing the by-value argument array dynamically copies it to scratch)
+    const unsigned y = blockIdx.y;
+#define PROMOTE_SEL(f) (y == 0 ? a.role[0].f : (y == 1 ? a.role[1].f : a.role[2].f))
+    float *pop = PROMOTE_SEL(pop), *hof = PROMOTE_SEL(hof), *elite = PROMOTE_SEL(elite);
+    const int32_t *order = PROMOTE_SEL(order);
+    const int D = PROMOTE_SEL(D), from_pop = PROMOTE_SEL(elites_from_pop), to_pop0 = PROMOTE_SEL(best_to_pop0);
+#undef PROMOTE_SEL
+    const int64_t stride = fc_stride(D);
     const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (s0 >= stride) return;
-    float4 e[PROMOTE_MAX_E];
-#pragma unroll
-    for (int k = 0; k < PROMOTE_MAX_E; ++k) {
-        if (k < a.E) {
-            const float *src = R.elites_from_pop ? R.pop + (int64_t)R.order[k] * stride : R.elite + (int64_t)k * stride;
-            e[k] = *reinterpret_cast<const float4 *>(src + s0);
-        }
-    }
-    float4 h[PROMOTE_MAX_HOF];
-#pragma unroll
-    for (int i = 1; i < PROMOTE_MAX_HOF; ++i)
-        if (i < a.hof) h[i] = *reinterpret_cast<const float4 *>(R.hof + (int64_t)i * stride + s0);
-#pragma unroll
-    for (int i = 1; i < PROMOTE_MAX_HOF; ++i)
-        if (i < a.hof) *reinterpret_cast<float4 *>(R.hof + (int64_t)(i - 1) * stride + s0) = h[i];
-    *reinterpret_cast<float4 *>(R.hof + (int64_t)(a.hof - 1) * stride + s0) = e[0];
-    if (R.elites_from_pop) {
-#pragma unroll
-        for (int k = 0; k < PROMOTE_MAX_E; ++k)
-            if (k < a.E) *reinterpret_cast<float4 *>(R.elite + (int64_t)k * stride + s0) = e[k];
-    }
-    if (R.best_to_pop0) *reinterpret_cast<float4 *>(R.pop + s0) = e[0];
+    // every source piece is read before the first store that could alias it (a best individual that already sits in
+    // pop[0], the in-place HoF shift)
+    const float4 e0 = from_pop ? promote_elites<0>(pop, order, elite, true, stride, s0, a.E)
+                               : *reinterpret_cast<const float4 *>(elite + s0);
+    promote_hof_shift<1>(hof, stride, s0, a.hof);
+    *reinterpret_cast<float4 *>(hof + (int64_t)(a.hof - 1) * stride + s0) = e0;
+    if (to_pop0) *reinterpret_cast<float4 *>(pop + s0) = e0;
 }
 
 // theta[p] += lr/(n*sigma) * sum_i fitness[i] * (pert_i[p] - theta[p]), i ascending, one fmaf per term.
@@ -617,3 +639,5 @@ extern "C" int coevo_net_gather(const float *src_slab, const int32_t *src_idx, f
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }
+
+COEVO_DEFINE_TU_FLAGS(offspring)

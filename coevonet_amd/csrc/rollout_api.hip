@@ -260,3 +260,5 @@ extern "C" int coevo_mpe_rollout(const coevo_rollout_desc *d, void *ctx, int tim
     if (d->rewards) return coevo_mpe_rewards(d->state, d->n_games, d->rewards, main_s);
     return COEVO_OK;
 }
+
+COEVO_DEFINE_TU_FLAGS(rollout_api)

@@ -4,6 +4,7 @@
 // genetic_algorithm.py:131-133 / evolutionary_strategy.py:128; the GA fitness expression
 // (genetic_algorithm.py:140-146, :172-178, :205-211) and np.argsort(fitness)[::-1] (:223-225).
 #include "coevo_common.hip.h"
+#include <stdio.h>
 
 namespace coevo {
 
@@ -387,3 +388,31 @@ extern "C" int coevo_ga_select(const coevo_ga_select_role *roles, int n_roles, i
 }
 
 extern "C" int coevo_version(void) { return COEVO_VERSION; }
+
+COEVO_DEFINE_TU_FLAGS(select)
+namespace coevo {
+const char *tu_flags_fc_forward(); const char *tu_flags_mpe_env(); const char *tu_flags_offspring();
+const char *tu_flags_rollout_api(); const char *tu_flags_deepqn(); const char *tu_flags_dqn_engine();
+}
+
+extern "C" const char *coevo_build_flags(void)
+{
+    static char buf[1024];
+    static bool done = false;
+    if (!done) {   // (idempotent: a race between first callers writes the same bytes)
+        const char *names[] = {"fc_forward", "mpe_env", "offspring", "select", "rollout_api", "deepqn", "dqn_engine"};
+        const char *flags[] = {coevo::tu_flags_fc_forward(), coevo::tu_flags_mpe_env(), coevo::tu_flags_offspring(),
+                               coevo::tu_flags_select(), coevo::tu_flags_rollout_api(), coevo::tu_flags_deepqn(),
+                               coevo::tu_flags_dqn_engine()};
+        size_t n = 0;
+        buf[0] = 0;
+        for (int i = 0; i < 7; ++i) {
+            if (!flags[i][0]) continue;
+            const int w = snprintf(buf + n, sizeof(buf) - n, "%s%s: %s", n ? "; " : "", names[i], flags[i]);
+            if (w < 0 || (size_t)w >= sizeof(buf) - n) break;
+            n += (size_t)w;
+        }
+        done = true;
+    }
+    return buf;
+}

@@ -10,6 +10,7 @@ no weight ever crosses xGMI.
 from __future__ import annotations
 
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -41,16 +42,55 @@ class DistContext:
             os.environ.setdefault("MASTER_PORT", "29500")
             # RCCL needs one device per rank ("Duplicate GPU detected" otherwise): with more local ranks than GPUs (a
             # rehearsal on a one-GPU box) the ranks share the device and the gathers go through gloo
-            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(self.world)))
-            one_gpu_per_rank = torch.cuda.is_available() and torch.cuda.device_count() >= local_world
-            backend = backend or os.environ.get("COEVO_DIST_BACKEND") or ("nccl" if one_gpu_per_rank else "gloo")
+            # (only a KNOWN local world size can say so: launchers that do not export LOCAL_WORLD_SIZE - srun, mpirun -
+            # may spread WORLD_SIZE over several nodes, where comparing it with this node's device count would send every
+            # gather through the host)
+            lws = os.environ.get("LOCAL_WORLD_SIZE")
+            shared_device = lws is not None and torch.cuda.is_available() and int(lws) > torch.cuda.device_count()
+            backend = backend or os.environ.get("COEVO_DIST_BACKEND") or ("gloo" if shared_device else "nccl")
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank % max(torch.cuda.device_count(), 1))
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+            if self.rank == 0:
+                print(f"[coevonet_amd.dist] backend={backend} world={self.world}"
+                      + (" (ranks share a device: gathers go through the host)" if shared_device else ""),
+                      file=sys.stderr, flush=True)
+        self._timed = None   # start_gather_timing(): [(start event, end event)] around every gather_* call
+
+    # ---- HIP events around the collectives (bench.py's "allgather_us"): on the caller's stream, so a pair brackets the
+    # stream-ordered collective itself (RCCL) or the host-staged copy + gloo exchange (rehearsals)
+    def start_gather_timing(self):
+        self._timed = []
+
+    def gather_times_us(self):
+        """durations of the gather_* calls since start_gather_timing(), after a device synchronize"""
+        torch.cuda.synchronize()
+        return [1e3 * a.elapsed_time(b) for a, b in (self._timed or [])]
+
+    def _bracket(self, fn, *args):
+        if self._timed is None:
+            return fn(*args)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn(*args)
+        b.record()
+        self._timed.append((a, b))
 
     def gather_ga(self, eng):
         """fills eng.dist[role][:] and eng.last_reward[:, :, :] for the whole population from every rank's shard"""
-        from .genetic_algorithm import ROLES
+        self._bracket(self._gather_ga, eng)
+
+    def gather_ga2(self, eng):
+        """the same exchange for the two-role DeepQN engine (dqn_population.DQNGAEngine)"""
+        self._bracket(self._gather_ga2, eng)
+
+    def gather_es(self, eng, what):
+        """Co-ES exchanges (evolutionary_strategy.ESEngine.update_device): "stats" = per role and individual the reward
+        in the role's slot + the distance to the base net (fp64 pairs, 16 bytes per individual and role); "partials" =
+        this rank's chunk partial sums of the update (fp32, chunks/world * P per role), rank-major in eng.partials"""
+        self._bracket(self._gather_es, eng, what)
+
+    def _gather_ga(self, eng):
         lo, hi = eng.lo, eng.hi
         local = torch.empty(3, hi - lo, 4, dtype=torch.float64, device=eng.last_reward.device)
         local[:, :, :3] = eng.last_reward[:, lo:hi]
@@ -59,8 +99,7 @@ class DistContext:
         eng.last_reward.copy_(full[:, :, :3])
         eng.dist_all.copy_(full[:, :, 3])               # back to fp32 (exact: they were fp32 values)
 
-    def gather_ga2(self, eng):
-        """the same exchange for the two-role DeepQN engine (dqn_population.DQNGAEngine)"""
+    def _gather_ga2(self, eng):
         lo, hi = eng.lo, eng.hi
         local = torch.empty(2, hi - lo, 4, dtype=torch.float64, device=eng.last_reward.device)
         local[:, :, :3] = eng.last_reward[:, lo:hi]
@@ -69,10 +108,7 @@ class DistContext:
         eng.last_reward.copy_(full[:, :, :3])
         eng.dist_all.copy_(full[:, :, 3])
 
-    def gather_es(self, eng, what):
-        """Co-ES exchanges (evolutionary_strategy.ESEngine.update_device): "stats" = per role and individual the reward
-        in the role's slot + the distance to the base net (fp64 pairs, 16 bytes per individual and role); "partials" =
-        this rank's chunk partial sums of the update (fp32, chunks/world * P per role), rank-major in eng.partials"""
+    def _gather_es(self, eng, what):
         if what == "stats":
             full = allgather_shards(eng.stats[:, eng.lo:eng.hi].contiguous(), self.world)
             eng.stats.copy_(full)

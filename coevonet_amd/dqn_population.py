@@ -95,6 +95,8 @@ class SynthRollout:
             for k in range(1, len(self.lanes)):
                 self.lanes[k]["stream"] = torch.cuda.ExternalStream(
                     L.load().coevo_rollout_ctx_cohort_stream(self._lane_ctx, k), device=device)
+        else:
+            self._lane_ctx = None
         self.tasks_np = [np.concatenate([ln["tasks_np"][p] for ln in self.lanes]) for p in range(2)]
         self._fork = torch.cuda.Event() if len(self.lanes) > 1 else None
         self.timing_ctx = None      # set by start_timing(): HIP events around sampled launches (eager only)
@@ -102,8 +104,32 @@ class SynthRollout:
 
     def start_timing(self, pairs=512, every=7):
         """sample the conv-stack launch (and, on other steps, the fc1 launch) of the first cohort with HIP events"""
+        self._destroy_timing()
         self.timing_ctx = [L.load().coevo_rollout_ctx_create(int(pairs)) for _ in range(2)]
         self.timing_every = int(every)
+
+    def _destroy_timing(self):
+        for c in self.timing_ctx or []:
+            L.load().coevo_rollout_ctx_destroy(c)
+        self.timing_ctx = None
+
+    def close(self):
+        """gives the cohort streams and the timing events back (library contexts); idempotent"""
+        if getattr(self, "_lane_ctx", None) or getattr(self, "timing_ctx", None):
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()   # nothing may still run on a stream that is about to be destroyed
+            self._destroy_timing()
+            if getattr(self, "_lane_ctx", None):
+                for ln in self.lanes[1:]:
+                    ln["stream"] = None
+                L.load().coevo_rollout_ctx_destroy(self._lane_ctx)
+                self._lane_ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def reset_timing(self):
         for c in self.timing_ctx or []:
@@ -470,6 +496,9 @@ class DQNGATrainer:
             self.env.n_resets = self.first_ordinal + self.gen * eng.per_gen
         return res
 
+    def close(self):
+        self.eng.ro.close()
+
 
 def dqn_genetic_algorithm_train(env, agent, args, output_dir, collect=True, dist_ctx=None):
     """genetic_algorithm_train for the two-player Atari games (main.py:181 with --game pong_v3 / boxing_v2)"""
@@ -647,6 +676,10 @@ class DQNESTrainer:
         if hasattr(self.env, "n_resets"):
             self.env.n_resets = self.first_ordinal + self.gen * self.eng.per_gen
         return self.res
+
+    def close(self):
+        self.eng.ro.close()
+        self.eng.eval_ro.close()
 
 
 def dqn_evolution_strategy_train(env, args, output_dir, collect=True, dist_ctx=None):

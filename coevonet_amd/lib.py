@@ -87,6 +87,7 @@ class CoevoError(RuntimeError):
 _lib = None
 _SIGS = {
     "coevo_version": (C.c_int, []),
+    "coevo_build_flags": (C.c_char_p, []),
     "coevo_fc_param_count": (C.c_int64, [C.c_int]),
     "coevo_fc_slab_stride": (C.c_int64, [C.c_int]),
     "coevo_fc_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -201,6 +202,10 @@ def load():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        flags = (L.coevo_build_flags() or b"").decode()
+        if flags and os.environ.get("COEVO_ALLOW_VARIANT") != "1":
+            raise CoevoError(f"{LIB_PATH} was built with non-default switches ({flags}): a measurement variant, not the "
+                             "product (rebuild with python -m coevonet_amd.build, or set COEVO_ALLOW_VARIANT=1 in tools/)")
         _lib = L
     return _lib
 

@@ -54,6 +54,9 @@ extern "C" {
 #define COEVO_SLOT_AGENT_1 2
 
 int coevo_version(void);
+/* "" for the shipped configuration; otherwise the non-default build switches (A/B measurement builds), per translation unit.
+ * A binding should refuse a library whose answer is not empty: some switches change results. */
+const char *coevo_build_flags(void);
 
 /* ---------------------------------------------------------------- weight slab ------------------------------ */
 /* Canonical flat order = torch parameters() order of FCNetwork (fc1.w, fc1.b, ln1.w, ln1.b, fc2.w, fc2.b, ln2.w,

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 name=$1; src=$2; shift 2
 mkdir -p variants
 base="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 $base "$@" -c coevonet_amd/csrc/$src -o variants/${src%.hip}_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 $base "$@" "-DCOEVO_TU_FLAGS=\"$*\"" -c coevonet_amd/csrc/$src -o variants/${src%.hip}_$name.o
 objs=""
 for o in coevonet_amd/csrc/_obj/*.o; do
   if [ "$(basename $o)" == "${src%.hip}.o" ]; then objs="$objs variants/${src%.hip}_$name.o"; else objs="$objs $o"; fi
