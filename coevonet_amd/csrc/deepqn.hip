@@ -25,7 +25,13 @@ namespace coevo {
 #define DQ_LUT 0   // 1: /255 through a 256-entry LDS table instead of u8_over_255 (measured equal at 3 workgroups per CU)
 #endif
 #ifndef DQ_FC1_U
-#define DQ_FC1_U 14   // fc1: k-quads per chunk of the weight stream (two chunks in flight)
+#define DQ_FC1_U 14   // fc1: k-quads per chunk of the weight stream
+#endif
+#ifndef DQ_FC1_DEEP
+#define DQ_FC1_DEEP 4   // fc1: ring depth of the launches with at most DQ_FC1_DEEP_MAX_WAVES waves
+#endif
+#ifndef DQ_FC1_DEEP_MAX_WAVES
+#define DQ_FC1_DEEP_MAX_WAVES 1024   // one wave per SIMD
 #endif
 #ifndef DQ_WPE
 #define DQ_WPE 6   // waves per SIMD the register budget is set for: 3 workgroups x 8 waves / 4 SIMDs
@@ -401,12 +407,15 @@ __global__ __launch_bounds__(512, DQ_WPE) void dqn_conv_kernel(const float *slab
 constexpr int DQ_RMAX = 16;
 // NG = row groups of four this task needs (ceil(rows / 4)): a one-frame task (Co-ES) issues a quarter of a 16-frame task's
 // MFMAs.  One launch serves tasks of every size: the kernel picks the instantiation by the task's own row count.
-template <int NG>
+// NB = chunks of the weight stream in the wave's register ring: NB - 1 of them (14 KiB each) are in flight while one feeds
+// the matrix pipe.
+template <int NG, int NB>
 __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &L, const coevo_dqn_task &task,
                                              const float *act, float *hid, float (*xs)[DQ_RMAX][DQ_FC1_U * 4], int ob, int l)
 {
-    constexpr int U = DQ_FC1_U;  // k-quads per chunk; 784 = 56 * 14; two chunks in flight (ping-pong)
-    static_assert(784 % (2 * U) == 0, "whole ping-pong rounds");
+    constexpr int U = DQ_FC1_U;  // k-quads per chunk; 784 = 56 * 14
+    constexpr int NCHUNK = 784 / U;
+    static_assert(784 % U == 0 && NCHUNK % NB == 0 && NB >= 2, "whole rounds of the ring");
     const int nrows = task.n_rows;
     const float bb = net[L.bf + 64 * ob + l];
     // rows in groups of four on v_mfma_f32_4x4x1_16B_f32 (16 blocks x 4 columns = the wave's 64 outputs, one k per
@@ -423,28 +432,28 @@ __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &
     const float4 *wp = reinterpret_cast<const float4 *>(net + L.wf) + (size_t)ob * 784 * 64 + l;
     const float *arow = act + (size_t)task.row_begin * DQ_FC1_IN;
     constexpr int XI = (4 * NG * U + 63) / 64;
-    float4 wA[U], wB[U], xA[XI], xB[XI];
+    float4 wv[NB][U], xr[NB][XI];
     // a chunk's weight pieces (read once per launch: non-temporal, keeps the conv weights / activations in L2) and its
     // activations (rows x 14 float4 pieces, coalesced per row; pad rows: zeros), all requested together
-    auto issue = [&](float4 (&wv)[U], float4 (&xr)[XI], int kq) {
+    auto issue = [&](float4 (&w)[U], float4 (&x)[XI], int kq) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt *>(wp + (size_t)(kq + u) * 64));
-            wv[u] = make_float4(v[0], v[1], v[2], v[3]);
+            w[u] = make_float4(v[0], v[1], v[2], v[3]);
         }
 #pragma unroll
         for (int j = 0; j < XI; ++j) {
             const int i = l + 64 * j, r = i / U, q = i % U;
-            xr[j] = (i < 4 * NG * U && r < nrows)
-                        ? *reinterpret_cast<const float4 *>(arow + (size_t)r * DQ_FC1_IN + 4 * (kq + q))
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
+            x[j] = (i < 4 * NG * U && r < nrows)
+                       ? *reinterpret_cast<const float4 *>(arow + (size_t)r * DQ_FC1_IN + 4 * (kq + q))
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto consume = [&](const float4 (&wv)[U], const float4 (&xr)[XI], float (*x_lds)[DQ_FC1_U * 4]) {
+    auto consume = [&](const float4 (&w)[U], const float4 (&xin)[XI], float (*x_lds)[DQ_FC1_U * 4]) {
 #pragma unroll
         for (int j = 0; j < XI; ++j) {
             const int i = l + 64 * j;
-            if (i < 4 * NG * U) *reinterpret_cast<float4 *>(&x_lds[i / U][4 * (i % U)]) = xr[j];
+            if (i < 4 * NG * U) *reinterpret_cast<float4 *>(&x_lds[i / U][4 * (i % U)]) = xin[j];
         }
         __syncthreads();   // one wave per workgroup: orders the LDS round trip
 #pragma unroll
@@ -453,26 +462,30 @@ __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &
 #pragma unroll
             for (int g = 0; g < NG; ++g) x[g] = *reinterpret_cast<const float4 *>(&x_lds[4 * g + (l & 3)][4 * u]);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].x, wv[u].x, acc[g], 0, 0, 0);
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].x, w[u].x, acc[g], 0, 0, 0);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].y, wv[u].y, acc[g], 0, 0, 0);
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].y, w[u].y, acc[g], 0, 0, 0);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].z, wv[u].z, acc[g], 0, 0, 0);
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].z, w[u].z, acc[g], 0, 0, 0);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].w, wv[u].w, acc[g], 0, 0, 0);
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].w, w[u].w, acc[g], 0, 0, 0);
         }
     };
-    // ping-pong: while one chunk feeds the matrix pipe the next chunk's 14 KiB are in flight (the order pinned with
-    // sched_barrier; serially - load, wait, compute - the 56 memory latencies of a wave added up to half the kernel)
-    issue(wA, xA, 0);
+    // the ring: chunk c lives in buffer c % NB; before chunk c is consumed chunk c + NB - 1 is requested into the buffer
+    // chunk c - 1 has just left (the order pinned with sched_barrier; serially - load, wait, compute - the 56 memory
+    // latencies of a wave added up to half the kernel, and with two buffers a wave that is alone on its SIMD - a Co-GA
+    // launch has fewer waves than the chip has SIMDs - still waited out most of each HBM round trip)
+#pragma unroll
+    for (int b = 0; b < NB - 1; ++b) issue(wv[b], xr[b], b * U);
 #pragma nounroll
-    for (int kq = 0; kq < 784; kq += 2 * U) {
-        issue(wB, xB, kq + U);
-        __builtin_amdgcn_sched_barrier(0);
-        consume(wA, xA, xs[0]);
-        if (kq + 2 * U < 784) issue(wA, xA, kq + 2 * U);   // wave-uniform
-        __builtin_amdgcn_sched_barrier(0);
-        consume(wB, xB, xs[1]);
+    for (int c0 = 0; c0 < NCHUNK; c0 += NB) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int nxt = c0 + b + NB - 1;
+            if (nxt < NCHUNK) issue(wv[(b + NB - 1) % NB], xr[(b + NB - 1) % NB], nxt * U);   // wave-uniform
+            __builtin_amdgcn_sched_barrier(0);
+            consume(wv[b], xr[b], xs[b & 1]);
+        }
     }
 #pragma unroll
     for (int g = 0; g < NG; ++g)
@@ -483,11 +496,16 @@ __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &
 }
 
 // fc1 + ReLU: grid (task, 8), ONE wavefront per workgroup: it owns outputs [64*ob, +64) and streams their 802 KB
-// ([784][64][4] tile) exactly once for the task's <= 16 rows, 28 KiB in flight (only 8 wavefronts exist per net, so the
-// memory-level parallelism has to come from depth).  The activations of a chunk (rows x 14 k-quads) are staged in LDS
-// with coalesced loads and read back as broadcasts (scalar loads of them serialise: 12 500 dependent s_loads per wave).
-__global__ __launch_bounds__(64) void dqn_fc1_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int C,
-                                                      int n_actions, const float *act, float *hid)
+// ([784][64][4] tile) exactly once for the task's <= 16 rows (only 8 wavefronts exist per net, so the memory-level
+// parallelism has to come from depth).  The activations of a chunk (rows x 14 k-quads) are staged in LDS with coalesced
+// loads and read back as broadcasts (scalar loads of them serialise: 12 500 dependent s_loads per wave).
+// NB = 2 (28 KiB in flight per wave, <= 128 registers: several waves per SIMD) serves launches with more waves than the
+// chip has SIMDs (Co-ES: 250 one-frame tasks per cohort); NB = 4 (42 KiB in flight, one wave per SIMD) the launches with
+// fewer (Co-GA shard: 90 tasks = 720 waves on 1024 SIMDs), where nothing else hides a wave's HBM round trips.
+template <int NB>
+__global__ __launch_bounds__(64) void dqn_fc1_kernel(const float *slab, const coevo_dqn_task *tasks,
+                                                                      int n_tasks, int C, int n_actions, const float *act,
+                                                                      float *hid)
 {
     __shared__ __attribute__((aligned(16))) float xs[2][DQ_RMAX][DQ_FC1_U * 4];
     // XCD x takes a contiguous range of tasks (gridDim.x is a multiple of 8, so the output block blockIdx.y does not change
@@ -503,10 +521,10 @@ __global__ __launch_bounds__(64) void dqn_fc1_kernel(const float *slab, const co
     const DqnLayout L = dqn_layout(C, n_actions);
     const int ob = blockIdx.y, l = threadIdx.x;
     switch ((task.n_rows + 3) >> 2) {   // workgroup-uniform
-    case 1: dqn_fc1_body<1>(net, L, task, act, hid, xs, ob, l); break;
-    case 2: dqn_fc1_body<2>(net, L, task, act, hid, xs, ob, l); break;
-    case 3: dqn_fc1_body<3>(net, L, task, act, hid, xs, ob, l); break;
-    default: dqn_fc1_body<4>(net, L, task, act, hid, xs, ob, l); break;
+    case 1: dqn_fc1_body<1, NB>(net, L, task, act, hid, xs, ob, l); break;
+    case 2: dqn_fc1_body<2, NB>(net, L, task, act, hid, xs, ob, l); break;
+    case 3: dqn_fc1_body<3, NB>(net, L, task, act, hid, xs, ob, l); break;
+    default: dqn_fc1_body<4, NB>(net, L, task, act, hid, xs, ob, l); break;
     }
 }
 
@@ -618,7 +636,9 @@ extern "C" int coevo_dqn_forward_argmax_timed(const float *slab, const coevo_dqn
     else hipLaunchKernelGGL((dqn_conv_kernel<6, 0>), cg, cb, 0, s, slab, tasks, n_tasks, n_rows_total, C, n_actions, frames, act);
     if (timing_ctx && timed_kernel == 0 && coevo_timing_end(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     if (timing_ctx && timed_kernel == 1 && coevo_timing_begin(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
-    hipLaunchKernelGGL(dqn_fc1_kernel, dim3(8 * ((n_tasks + 7) / 8), 8), dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, act, hid);
+    const dim3 fg(8 * ((n_tasks + 7) / 8), 8);
+    if (n_tasks * 8 <= DQ_FC1_DEEP_MAX_WAVES) hipLaunchKernelGGL(dqn_fc1_kernel<DQ_FC1_DEEP>, fg, dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, act, hid);
+    else hipLaunchKernelGGL(dqn_fc1_kernel<2>, fg, dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, act, hid);
     if (timing_ctx && timed_kernel == 1 && coevo_timing_end(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     hipLaunchKernelGGL(dqn_out_kernel, dim3(n_rows_total), dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, hid,
                        actions, logits, status);
