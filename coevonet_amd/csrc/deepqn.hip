@@ -25,13 +25,16 @@ namespace coevo {
 #define DQ_LUT 0   // 1: /255 through a 256-entry LDS table instead of u8_over_255 (measured equal at 3 workgroups per CU)
 #endif
 #ifndef DQ_FC1_U
-#define DQ_FC1_U 14   // fc1: k-quads per chunk of the weight stream
+#define DQ_FC1_U 7    // fc1: k-quads per chunk of the weight stream (784 = 112 x 7)
 #endif
-#ifndef DQ_FC1_DEEP
-#define DQ_FC1_DEEP 4   // fc1: ring depth of the launches with at most DQ_FC1_DEEP_MAX_WAVES waves
+#ifndef DQ_FC1_NB
+#define DQ_FC1_NB 8    // fc1: chunks in the wave's register ring (NB - 1 in flight)
 #endif
-#ifndef DQ_FC1_DEEP_MAX_WAVES
-#define DQ_FC1_DEEP_MAX_WAVES 1024   // one wave per SIMD
+#ifndef DQ_FC1_ALLNT
+#define DQ_FC1_ALLNT 0   // 1: non-temporal weight loads for every task (A/B)
+#endif
+#ifndef DQ_FC1_NB_MANY
+#define DQ_FC1_NB_MANY 2   // ... of a launch with more waves than the chip has SIMDs (fewer registers: several waves per SIMD)
 #endif
 #ifndef DQ_WPE
 #define DQ_WPE 6   // waves per SIMD the register budget is set for: 3 workgroups x 8 waves / 4 SIMDs
@@ -409,7 +412,7 @@ constexpr int DQ_RMAX = 16;
 // MFMAs.  One launch serves tasks of every size: the kernel picks the instantiation by the task's own row count.
 // NB = chunks of the weight stream in the wave's register ring: NB - 1 of them (14 KiB each) are in flight while one feeds
 // the matrix pipe.
-template <int NG, int NB>
+template <int NG, int NB, bool SHARED_NET>
 __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &L, const coevo_dqn_task &task,
                                              const float *act, float *hid, float (*xs)[DQ_RMAX][DQ_FC1_U * 4], int ob, int l)
 {
@@ -423,7 +426,7 @@ __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &
     // the B operand as is, the A operand x[4g + l%4][4q..4q+3] is one ds_read_b128 per group.  (As VALU FMAs fed by one
     // LDS broadcast per row this kernel ran at 1.4 TB/s.)
     typedef float f32x4_acc1 __attribute__((ext_vector_type(4)));
-    typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+    typedef float f32x4_nt __attribute__((ext_vector_type(4))) __attribute__((unused));
     f32x4_acc1 acc[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g)
@@ -433,13 +436,19 @@ __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &
     const float *arow = act + (size_t)task.row_begin * DQ_FC1_IN;
     constexpr int XI = (4 * NG * U + 63) / 64;
     float4 wv[NB][U], xr[NB][XI];
-    // a chunk's weight pieces (read once per launch: non-temporal, keeps the conv weights / activations in L2) and its
-    // activations (rows x 14 float4 pieces, coalesced per row; pad rows: zeros), all requested together
+    // a chunk's weight pieces (read once per launch: non-temporal, keeps the conv weights / activations in L2 - unless the
+    // neighbouring task streams the same net: then plain loads, so that the siblings' requests meet in the XCD's L2.
+    // FETCH_SIZE of the Co-GA launch, 400 MB of distinct weights in 90 tasks: 481 MB non-temporal, 440 MB plain, and the
+    // launch's time follows those bytes; plain loads for every task cost the conv launch 4 - 20 %) and its activations (rows x 14 float4 pieces, coalesced per row; pad rows: zeros), all requested together
     auto issue = [&](float4 (&w)[U], float4 (&x)[XI], int kq) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt *>(wp + (size_t)(kq + u) * 64));
-            w[u] = make_float4(v[0], v[1], v[2], v[3]);
+            if constexpr (SHARED_NET) {
+                w[u] = wp[(size_t)(kq + u) * 64];
+            } else {
+                const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt *>(wp + (size_t)(kq + u) * 64));
+                w[u] = make_float4(v[0], v[1], v[2], v[3]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < XI; ++j) {
@@ -497,15 +506,15 @@ __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &
 
 // fc1 + ReLU: grid (task, 8), ONE wavefront per workgroup: it owns outputs [64*ob, +64) and streams their 802 KB
 // ([784][64][4] tile) exactly once for the task's <= 16 rows (only 8 wavefronts exist per net, so the memory-level
-// parallelism has to come from depth).  The activations of a chunk (rows x 14 k-quads) are staged in LDS with coalesced
+// parallelism has to come from depth).  The activations of a chunk (rows x U k-quads) are staged in LDS with coalesced
 // loads and read back as broadcasts (scalar loads of them serialise: 12 500 dependent s_loads per wave).
-// NB = 2 (28 KiB in flight per wave, <= 128 registers: several waves per SIMD) serves launches with more waves than the
-// chip has SIMDs (Co-ES: 250 one-frame tasks per cohort); NB = 4 (42 KiB in flight, one wave per SIMD) the launches with
-// fewer (Co-GA shard: 90 tasks = 720 waves on 1024 SIMDs), where nothing else hides a wave's HBM round trips.
+// The ring, two instantiations: a launch with at most one wave per SIMD (Co-GA shard: 90 tasks = 720 waves) keeps 8 chunks
+// of 7 KiB (~300 registers, nothing else would hide a lone wave's round trips); a launch with more waves than SIMDs (a
+// Co-ES cohort: 133 tasks = 1064 waves) keeps two (< 256 registers: every wave resident; with the deep ring its last 40
+// waves ran as a second round, 171 against 141 us).  Chunks of 7 instead of 14 pieces: 170 -> 141 us for that launch.
 template <int NB>
-__global__ __launch_bounds__(64) void dqn_fc1_kernel(const float *slab, const coevo_dqn_task *tasks,
-                                                                      int n_tasks, int C, int n_actions, const float *act,
-                                                                      float *hid)
+__global__ __launch_bounds__(64, NB <= DQ_FC1_NB_MANY ? 2 : 1) void dqn_fc1_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int C,
+                                                      int n_actions, const float *act, float *hid)
 {
     __shared__ __attribute__((aligned(16))) float xs[2][DQ_RMAX][DQ_FC1_U * 4];
     // XCD x takes a contiguous range of tasks (gridDim.x is a multiple of 8, so the output block blockIdx.y does not change
@@ -517,14 +526,23 @@ __global__ __launch_bounds__(64) void dqn_fc1_kernel(const float *slab, const co
 #endif
     if (ti >= n_tasks) return;
     const coevo_dqn_task task = tasks[ti];
+    // a net that acts in more than 16 games owns several tasks, adjacent in the table (workgroup-uniform)
+    const bool shared_net = !DQ_FC1_ALLNT && ((ti > 0 && tasks[ti - 1].net_off == task.net_off) ||
+                                              (ti + 1 < n_tasks && tasks[ti + 1].net_off == task.net_off));
     const float *net = slab + task.net_off;
     const DqnLayout L = dqn_layout(C, n_actions);
     const int ob = blockIdx.y, l = threadIdx.x;
-    switch ((task.n_rows + 3) >> 2) {   // workgroup-uniform
-    case 1: dqn_fc1_body<1, NB>(net, L, task, act, hid, xs, ob, l); break;
-    case 2: dqn_fc1_body<2, NB>(net, L, task, act, hid, xs, ob, l); break;
-    case 3: dqn_fc1_body<3, NB>(net, L, task, act, hid, xs, ob, l); break;
-    default: dqn_fc1_body<4, NB>(net, L, task, act, hid, xs, ob, l); break;
+    const int ng = (task.n_rows + 3) >> 2;   // workgroup-uniform, as is shared_net: one straight-line instantiation each
+    if (shared_net) {
+        if (ng == 1) dqn_fc1_body<1, NB, true>(net, L, task, act, hid, xs, ob, l);
+        else if (ng == 2) dqn_fc1_body<2, NB, true>(net, L, task, act, hid, xs, ob, l);
+        else if (ng == 3) dqn_fc1_body<3, NB, true>(net, L, task, act, hid, xs, ob, l);
+        else dqn_fc1_body<4, NB, true>(net, L, task, act, hid, xs, ob, l);
+    } else {
+        if (ng == 1) dqn_fc1_body<1, NB, false>(net, L, task, act, hid, xs, ob, l);
+        else if (ng == 2) dqn_fc1_body<2, NB, false>(net, L, task, act, hid, xs, ob, l);
+        else if (ng == 3) dqn_fc1_body<3, NB, false>(net, L, task, act, hid, xs, ob, l);
+        else dqn_fc1_body<4, NB, false>(net, L, task, act, hid, xs, ob, l);
     }
 }
 
@@ -637,8 +655,8 @@ extern "C" int coevo_dqn_forward_argmax_timed(const float *slab, const coevo_dqn
     if (timing_ctx && timed_kernel == 0 && coevo_timing_end(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     if (timing_ctx && timed_kernel == 1 && coevo_timing_begin(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     const dim3 fg(8 * ((n_tasks + 7) / 8), 8);
-    if (n_tasks * 8 <= DQ_FC1_DEEP_MAX_WAVES) hipLaunchKernelGGL(dqn_fc1_kernel<DQ_FC1_DEEP>, fg, dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, act, hid);
-    else hipLaunchKernelGGL(dqn_fc1_kernel<2>, fg, dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, act, hid);
+    if (n_tasks * 8 <= 1024) hipLaunchKernelGGL(dqn_fc1_kernel<DQ_FC1_NB>, fg, dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, act, hid);
+    else hipLaunchKernelGGL(dqn_fc1_kernel<DQ_FC1_NB_MANY>, fg, dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, act, hid);
     if (timing_ctx && timed_kernel == 1 && coevo_timing_end(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     hipLaunchKernelGGL(dqn_out_kernel, dim3(n_rows_total), dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, hid,
                        actions, logits, status);

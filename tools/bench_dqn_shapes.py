@@ -19,21 +19,28 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="cfg4")
 ap.add_argument("--C", type=int, default=4)
 ap.add_argument("--reps", type=int, default=40)
+ap.add_argument("--task-rows", type=int, default=L.DQN_MAX_ROWS, help="rows per task of a net that acts in many games")
 a = ap.parse_args()
 dev = "cuda"
 lib = L.load()
+
+
+def _cut(rows):
+    return [min(a.task_rows, rows - i) for i in range(0, rows, a.task_rows)]
+
+
 if a.shape == "cfg4":      # pop 50 x 10 HoF games, 10 HoF nets x 50 games (+ 10 evaluation games for the newest)
     n_act = 6
     layout = [(i, 10) for i in range(50)]
     for j in range(10):
-        layout += [(50 + j, r) for r in ((16, 16, 16, 12) if j == 0 else (16, 16, 16, 2))]
+        layout += [(50 + j, r) for r in (_cut(60) if j == 0 else _cut(50))]
     n_nets = 60
 else:                      # one cohort of cfg 5: 125 perturbed nets x 1 game, the base net x 125 games
     n_act = 18
     layout = []
     for j in range(125):
         layout += [(1 + j, 1)]
-    layout += [(0, r) for r in (16,) * 7 + (13,)]
+    layout += [(0, r) for r in _cut(125)]
     n_nets = 126
 stride = int(lib.coevo_dqn_slab_stride(a.C, n_act))
 P = int(lib.coevo_dqn_param_count(a.C, n_act))
@@ -53,7 +60,7 @@ stream = torch.cuda.current_stream().cuda_stream
 
 
 def run(which=None):
-    L._check(lib.coevo_dqn_forward_argmax_timed(L._p(slab), L._p(d_tasks), len(layout), 16, row, a.C, n_act, L._p(frames),
+    L._check(lib.coevo_dqn_forward_argmax_timed(L._p(slab), L._p(d_tasks), len(layout), a.task_rows, row, a.C, n_act, L._p(frames),
                                                 L._p(actions), None, L._p(status), L._p(ws),
                                                 tc[which] if which is not None else None, which or 0, stream), "fwd")
 
