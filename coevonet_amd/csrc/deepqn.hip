@@ -331,17 +331,6 @@ struct DqnSmem {
 };
 static_assert(sizeof(DqnSmem<6>) * 3 <= 160 * 1024, "three workgroups per CU");
 
-// the task that holds row `row`: the tasks partition the rows in ascending row_begin order (include/coevo.h)
-__device__ __forceinline__ int task_of_row(const coevo_dqn_task *tasks, int n_tasks, int row)
-{
-    int lo = 0, hi = n_tasks - 1;
-    while (lo < hi) {   // workgroup-uniform: scalar loads
-        const int mid = (lo + hi + 1) >> 1;
-        if (tasks[mid].row_begin <= row) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-}
-
 #ifdef COEVO_PHASE_STAMPS
 // diagnostic build only (tools/dqn_conv_phases.py): wave 0's arrival at each phase boundary, 100 MHz constant clock
 __device__ unsigned long long g_dqn_stamps[2048 * 16];
@@ -546,53 +535,19 @@ __global__ __launch_bounds__(64, NB <= DQ_FC1_NB_MANY ? 2 : 1) void dqn_fc1_kern
     }
 }
 
-// output layer + first-max action: one 64-thread workgroup per (task, row).  Lane o < n_actions runs the canonical
-// sequential-k chain of its logit; the hidden row is staged in LDS once (every lane reads the same element: a broadcast)
-// and the lane's weight row comes in 16-byte pieces, 16 of them in flight (as a dword-at-a-time loop this kernel took as
-// long as a tenth of the conv stack).
+// output layer + first-max action: one 64-thread workgroup per (task, row) (dqn_out_row, dqn_common.hip.h).  The
+// population engine does not launch it: there the output layer rides in the env-step launch (coevo_dqn_out_synth_step).
 __global__ __launch_bounds__(64) void dqn_out_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int C,
                                                       int n_actions, const float *hid, int32_t *actions,
                                                       float *logits, int32_t *status)
 {
     __shared__ __attribute__((aligned(16))) float xs[DQ_FC1_OUT];
     __shared__ float lg[64];
-    const int row = blockIdx.x, o = threadIdx.x;
+    const int row = blockIdx.x;
     const coevo_dqn_task task = tasks[task_of_row(tasks, n_tasks, row)];
-    const float *net = slab + task.net_off;
-    const DqnLayout L = dqn_layout(C, n_actions);
-    const float4 *x4 = reinterpret_cast<const float4 *>(hid + (size_t)row * DQ_FC1_OUT);
-    reinterpret_cast<float4 *>(xs)[o] = x4[o];
-    reinterpret_cast<float4 *>(xs)[o + 64] = x4[o + 64];
-    __syncthreads();
-    if (o < n_actions) {
-        float y = net[L.bo + o];
-        const float4 *w4 = reinterpret_cast<const float4 *>(net + L.wo + (size_t)o * DQ_FC1_OUT);
-        constexpr int B = 16;
-        for (int k0 = 0; k0 < DQ_FC1_OUT / 4; k0 += B) {
-            float4 wv[B];
-#pragma unroll
-            for (int i = 0; i < B; ++i) wv[i] = w4[k0 + i];
-#pragma unroll
-            for (int i = 0; i < B; ++i) {
-                const float4 xv = reinterpret_cast<const float4 *>(xs)[k0 + i];
-                y = __builtin_fmaf(wv[i].x, xv.x, y);
-                y = __builtin_fmaf(wv[i].y, xv.y, y);
-                y = __builtin_fmaf(wv[i].z, xv.z, y);
-                y = __builtin_fmaf(wv[i].w, xv.w, y);
-            }
-        }
-        lg[o] = y;
-        if (logits) logits[(size_t)row * COEVO_DQN_LOGIT_STRIDE + o] = y;
-    }
-    __syncthreads();
-    if (o == 0) {
-        int best = -1;
-        float cur = -__builtin_inff();
-        for (int i = 0; i < n_actions; ++i)
-            if (lg[i] > cur) { cur = lg[i]; best = i; }
-        if (best < 0) { atomicOr(status, COEVO_ST_NO_ACTION); best = 0; }
-        actions[row] = best;
-    }
+    const int a = dqn_out_row(slab + task.net_off, dqn_layout(C, n_actions), n_actions, hid + (size_t)row * DQ_FC1_OUT,
+                              logits ? logits + (size_t)row * COEVO_DQN_LOGIT_STRIDE : nullptr, status, xs, lg, threadIdx.x);
+    if (threadIdx.x == 0) actions[row] = a;
 }
 
 }  // namespace coevo
@@ -634,12 +589,12 @@ extern "C" int coevo_dqn_forward_argmax(const float *slab, const coevo_dqn_task 
                                           actions, logits, status, workspace, nullptr, 0, stream);
 }
 
-extern "C" int coevo_dqn_forward_argmax_timed(const float *slab, const coevo_dqn_task *tasks, int n_tasks,
-                                              int max_rows_per_task, int n_rows_total, int C, int n_actions,
-                                              const uint8_t *frames, int32_t *actions, float *logits, int32_t *status,
-                                              void *workspace, void *timing_ctx, int timed_kernel, void *stream)
+// conv stack + fc1 (+ the output layer when `actions` is given)
+static int dqn_forward_launch(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int max_rows_per_task,
+                              int n_rows_total, int C, int n_actions, const uint8_t *frames, int32_t *actions, float *logits,
+                              int32_t *status, void *workspace, void *timing_ctx, int timed_kernel, void *stream)
 {
-    if (!slab || !tasks || !frames || !actions || !status || !workspace) return COEVO_ERR_ARG;
+    if (!slab || !tasks || !frames || !workspace) return COEVO_ERR_ARG;
     if (n_tasks <= 0 || n_rows_total <= 0 || !dqn_shape_ok(C, n_actions)) return COEVO_ERR_ARG;
     if (max_rows_per_task < 1 || max_rows_per_task > DQ_RMAX) return COEVO_ERR_ARG;
     float *act = static_cast<float *>(workspace);
@@ -658,10 +613,30 @@ extern "C" int coevo_dqn_forward_argmax_timed(const float *slab, const coevo_dqn
     if (n_tasks * 8 <= 1024) hipLaunchKernelGGL(dqn_fc1_kernel<DQ_FC1_NB>, fg, dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, act, hid);
     else hipLaunchKernelGGL(dqn_fc1_kernel<DQ_FC1_NB_MANY>, fg, dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, act, hid);
     if (timing_ctx && timed_kernel == 1 && coevo_timing_end(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
-    hipLaunchKernelGGL(dqn_out_kernel, dim3(n_rows_total), dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, hid,
-                       actions, logits, status);
+    if (actions)
+        hipLaunchKernelGGL(dqn_out_kernel, dim3(n_rows_total), dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, hid,
+                           actions, logits, status);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
+}
+
+extern "C" int coevo_dqn_forward_argmax_timed(const float *slab, const coevo_dqn_task *tasks, int n_tasks,
+                                              int max_rows_per_task, int n_rows_total, int C, int n_actions,
+                                              const uint8_t *frames, int32_t *actions, float *logits, int32_t *status,
+                                              void *workspace, void *timing_ctx, int timed_kernel, void *stream)
+{
+    if (!actions || !status) return COEVO_ERR_ARG;
+    return dqn_forward_launch(slab, tasks, n_tasks, max_rows_per_task, n_rows_total, C, n_actions, frames, actions, logits,
+                              status, workspace, timing_ctx, timed_kernel, stream);
+}
+
+extern "C" int coevo_dqn_forward_hidden_timed(const float *slab, const coevo_dqn_task *tasks, int n_tasks,
+                                              int max_rows_per_task, int n_rows_total, int C, int n_actions,
+                                              const uint8_t *frames, void *workspace, void *timing_ctx, int timed_kernel,
+                                              void *stream)
+{
+    return dqn_forward_launch(slab, tasks, n_tasks, max_rows_per_task, n_rows_total, C, n_actions, frames, nullptr, nullptr,
+                              nullptr, workspace, timing_ctx, timed_kernel, stream);
 }
 
 #ifdef COEVO_PHASE_STAMPS

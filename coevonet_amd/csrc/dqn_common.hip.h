@@ -80,4 +80,62 @@ __host__ __device__ inline bool dqn_slab_is_batchnorm(int64_t s, const DqnLayout
     return (s >= L.b1 + 32 && s < L.w2) || (s >= L.b2 + 64 && s < L.w3) || (s >= L.b3 + 64 && s < L.wf);
 }
 
+// the task that holds row `row`: the tasks partition the rows in ascending row_begin order (include/coevo.h)
+__device__ __forceinline__ int task_of_row(const coevo_dqn_task *tasks, int n_tasks, int row)
+{
+    int lo = 0, hi = n_tasks - 1;
+    while (lo < hi) {   // workgroup-uniform: scalar loads
+        const int mid = (lo + hi + 1) >> 1;
+        if (tasks[mid].row_begin <= row) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// Output layer (512 -> n logits) + first-max action of one row, by the first wavefront of the calling workgroup (lane =
+// threadIdx.x < 64; the other threads only take part in the barriers).  Lane o < n_actions runs the canonical sequential-k
+// chain of its logit; the hidden row is staged in LDS once (every lane reads the same element: a broadcast) and the
+// lane's weight row comes in 16-byte pieces, 16 of them in flight (as a dword-at-a-time loop this took as long as a
+// tenth of the conv stack).  Returns the action to every thread.  xs: 512 floats, 16-byte aligned; lg: 64 floats.
+__device__ __forceinline__ int dqn_out_row(const float *net, const DqnLayout L, int n_actions, const float *hid_row,
+                                           float *logits_row, int32_t *status, float *xs, float *lg, int tid)
+{
+    if (tid < 64) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(hid_row);
+        reinterpret_cast<float4 *>(xs)[tid] = x4[tid];
+        reinterpret_cast<float4 *>(xs)[tid + 64] = x4[tid + 64];
+    }
+    __syncthreads();
+    if (tid < n_actions) {
+        float y = net[L.bo + tid];
+        const float4 *w4 = reinterpret_cast<const float4 *>(net + L.wo + (size_t)tid * DQ_FC1_OUT);
+        constexpr int B = 16;
+        for (int k0 = 0; k0 < DQ_FC1_OUT / 4; k0 += B) {
+            float4 wv[B];
+#pragma unroll
+            for (int i = 0; i < B; ++i) wv[i] = w4[k0 + i];
+#pragma unroll
+            for (int i = 0; i < B; ++i) {
+                const float4 xv = reinterpret_cast<const float4 *>(xs)[k0 + i];
+                y = __builtin_fmaf(wv[i].x, xv.x, y);
+                y = __builtin_fmaf(wv[i].y, xv.y, y);
+                y = __builtin_fmaf(wv[i].z, xv.z, y);
+                y = __builtin_fmaf(wv[i].w, xv.w, y);
+            }
+        }
+        lg[tid] = y;
+        if (logits_row) logits_row[tid] = y;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int best = -1;
+        float cur = -__builtin_inff();
+        for (int i = 0; i < n_actions; ++i)
+            if (lg[i] > cur) { cur = lg[i]; best = i; }
+        if (best < 0) { atomicOr(status, COEVO_ST_NO_ACTION); best = 0; }
+        lg[63] = __int_as_float(best);   // (n_actions <= 32: slot 63 is free)
+    }
+    __syncthreads();
+    return __float_as_int(lg[63]);
+}
+
 }  // namespace coevo

@@ -134,25 +134,43 @@ __device__ inline uint32_t synth_target(uint64_t seed, int64_t ordinal, int t, i
     return o.v[0] % (uint32_t)n_actions;
 }
 
+// FUSED = the output layer of step t-1 rides in this launch (coevo_dqn_out_synth_step): the workgroup of game g first
+// turns the hidden row of its actor (hid[row_prev[g]], left by conv stack + fc1) into logits and the first-max action, then
+// books that action and writes the next frame - one launch per agent-step less than output-layer launch + env launch.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void synth_step_kernel(int32_t *gstate, double *acc, int n_games,
                                                           const int64_t *game_ordinal0, const int32_t *gen_dev,
                                                           int64_t ordinals_per_gen, int t, const int32_t *limit,
-                                                          const int32_t *row_prev, const int32_t *actions_prev,
+                                                          const int32_t *row_prev, int32_t *actions_prev,
                                                           const int32_t *row_cur, uint8_t *frames, int C,
-                                                          int n_actions, uint64_t seed)
+                                                          int n_actions, uint64_t seed, const float *slab,
+                                                          const coevo_dqn_task *tasks_prev, int n_tasks_prev,
+                                                          const float *hid, int32_t *status)
 {
     const int g = blockIdx.x;
     if (g >= n_games) return;
     int64_t ordinal = game_ordinal0[g] + (gen_dev ? (int64_t)(*gen_dev) * ordinals_per_gen : 0);
     const int lim = (ordinal < 0) ? 0 : limit[g];   // a negative ordinal disables the game
     __shared__ int s_last;
+    __shared__ __attribute__((aligned(16))) float xs[FUSED ? DQ_FC1_OUT : 4];
+    __shared__ float lg[FUSED ? 64 : 1];
+    int action = 0;
+    if constexpr (FUSED) {
+        if (t - 1 < lim) {   // workgroup-uniform; (a finished game's row holds a stale frame: its action is never booked)
+            const int row = row_prev[g];
+            const coevo_dqn_task task = tasks_prev[task_of_row(tasks_prev, n_tasks_prev, row)];
+            action = dqn_out_row(slab + task.net_off, dqn_layout(C, n_actions), n_actions, hid + (size_t)row * DQ_FC1_OUT,
+                                 nullptr, status, xs, lg, threadIdx.x);
+            if (threadIdx.x == 0) actions_prev[row] = action;
+        }
+    }
     if (threadIdx.x == 0) {
         int last = gstate[4 * g], prev_hit = gstate[4 * g + 1];
         if (t == 0) {
             last = 0xFF; prev_hit = 0;
             acc[3 * (size_t)g] = 0.0; acc[3 * (size_t)g + 1] = 0.0; acc[3 * (size_t)g + 2] = 0.0;
         } else if (t - 1 < lim) {   // book the action of step t-1 (actor = (t-1) & 1)
-            const int a = actions_prev[row_prev[g]];
+            const int a = FUSED ? action : actions_prev[row_prev[g]];
             const int hit = ((uint32_t)a == synth_target(seed, ordinal, t - 1, n_actions)) ? 1 : 0;
             const size_t slot = 3 * (size_t)g + ((t - 1) & 1);
             acc[slot] = acc[slot] + (double)(prev_hit - hit);
@@ -226,9 +244,27 @@ extern "C" int coevo_synth_step(int32_t *game_state, double *acc, int n_games, c
     if (!dqn_shape_ok2(C, n_actions)) return COEVO_ERR_ARG;
     if (t > 0 && (!row_prev || !actions_prev)) return COEVO_ERR_ARG;
     if (frames && !row_cur) return COEVO_ERR_ARG;
-    hipLaunchKernelGGL(synth_step_kernel, dim3(n_games), dim3(256), 0, (hipStream_t)stream, game_state, acc, n_games,
+    hipLaunchKernelGGL(synth_step_kernel<false>, dim3(n_games), dim3(256), 0, (hipStream_t)stream, game_state, acc, n_games,
+                       game_ordinal0, gen_dev, ordinals_per_gen, t, limit, row_prev, const_cast<int32_t *>(actions_prev),
+                       row_cur, frames, C, n_actions, seed, nullptr, nullptr, 0, nullptr, nullptr);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_dqn_out_synth_step(int32_t *game_state, double *acc, int n_games, const int64_t *game_ordinal0,
+                                        const int32_t *gen_dev, int64_t ordinals_per_gen, int t, const int32_t *limit,
+                                        const int32_t *row_prev, int32_t *actions_prev, const int32_t *row_cur,
+                                        uint8_t *frames, int C, int n_actions, uint64_t seed, const float *slab,
+                                        const coevo_dqn_task *tasks_prev, int n_tasks_prev, int n_rows_total,
+                                        const void *workspace, int32_t *status, void *stream)
+{
+    if (!game_state || !acc || !game_ordinal0 || !limit || n_games <= 0 || t < 1 || t > 65535) return COEVO_ERR_ARG;
+    if (!dqn_shape_ok2(C, n_actions) || !row_prev || !actions_prev || (frames && !row_cur)) return COEVO_ERR_ARG;
+    if (!slab || !tasks_prev || n_tasks_prev <= 0 || n_rows_total <= 0 || !workspace || !status) return COEVO_ERR_ARG;
+    const float *hid = static_cast<const float *>(workspace) + (size_t)n_rows_total * DQ_FC1_IN;   // (deepqn.hip's layout)
+    hipLaunchKernelGGL(synth_step_kernel<true>, dim3(n_games), dim3(256), 0, (hipStream_t)stream, game_state, acc, n_games,
                        game_ordinal0, gen_dev, ordinals_per_gen, t, limit, row_prev, actions_prev, row_cur, frames, C,
-                       n_actions, seed);
+                       n_actions, seed, slab, tasks_prev, n_tasks_prev, hid, status);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

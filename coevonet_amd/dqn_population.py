@@ -9,8 +9,9 @@ only the last HoF game counts (Q2), diversity against the stale agent (Q3), args
 play_atari crediting the actor with the NEXT agent's cumulative reward.  "Loop parity unpinned, forward pinned" (SURVEY
 8c): ``DeepQN.forward`` is pinned by the reference's logits, the loops are checked against ``oracle/ref_port.py``.
 
-Per agent-step every game advances together: one ``coevo_synth_step`` launch (books the previous action, writes the next
-frames) + the three launches of ``coevo_dqn_forward_argmax`` over (weight set x frames) tasks: an individual's HoF games
+Per agent-step every game advances together: one ``coevo_dqn_out_synth_step`` launch (output layer + first-max action of
+the previous step, books it, writes the next frames) + the conv-stack and fc1 launches of
+``coevo_dqn_forward_hidden_timed`` over (weight set x frames) tasks: an individual's HoF games
 share its 6.75 MB weight read, a HoF / base opponent's games are cut into 16-frame tasks.  Offspring are built on the
 device from counter-based noise (``coevo_dqn_perturb``), selection / sigma rule / HoF stay on the device; one GPU replays
 a whole generation as one hipGraph.  Sharded over GPUs by population index with one all-gather of (last-game reward,
@@ -156,22 +157,27 @@ class SynthRollout:
         lib = L.load()
         for t in range(T + 1):
             p, q = t & 1, (t - 1) & 1
-            L._check(lib.coevo_synth_step(gs, ac, m, o0, g, self.ordinals_per_gen, t, lim,
-                                          L._p(ln["rows"][q]) if t else None,
-                                          ln["actions"][q].data_ptr() if t else None,
-                                          L._p(ln["rows"][p]) if t < T else None,
-                                          L._p(ln["frames"]) if t < T else None, self.C, self.n_actions, self.env_seed,
-                                          stream), "coevo_synth_step")
+            if t == 0:
+                L._check(lib.coevo_synth_step(gs, ac, m, o0, g, self.ordinals_per_gen, t, lim, None, None,
+                                              L._p(ln["rows"][p]), L._p(ln["frames"]), self.C, self.n_actions,
+                                              self.env_seed, stream), "coevo_synth_step")
+            else:   # the output layer of step t-1 rides in the env-step launch
+                L._check(lib.coevo_dqn_out_synth_step(gs, ac, m, o0, g, self.ordinals_per_gen, t, lim, L._p(ln["rows"][q]),
+                                                      ln["actions"][q].data_ptr(),
+                                                      L._p(ln["rows"][p]) if t < T else None,
+                                                      L._p(ln["frames"]) if t < T else None, self.C, self.n_actions,
+                                                      self.env_seed, L._p(self.slab), L._p(ln["tasks"][q]),
+                                                      ln["n_tasks"][q], m, L._p(ln["ws"]), L._p(self.status), stream),
+                         "coevo_dqn_out_synth_step")
             if t < T:
                 tc, which = None, 0
                 if timed and self.timing_ctx and t % self.timing_every == 0:
                     which = (t // self.timing_every) & 1
                     tc = self.timing_ctx[which]
-                L._check(lib.coevo_dqn_forward_argmax_timed(L._p(self.slab), L._p(ln["tasks"][p]), ln["n_tasks"][p],
+                L._check(lib.coevo_dqn_forward_hidden_timed(L._p(self.slab), L._p(ln["tasks"][p]), ln["n_tasks"][p],
                                                             ln["max_rows"][p], m, self.C, self.n_actions,
-                                                            L._p(ln["frames"]), ln["actions"][p].data_ptr(), None,
-                                                            L._p(self.status), L._p(ln["ws"]), tc, which, stream),
-                         "coevo_dqn_forward_argmax_timed")
+                                                            L._p(ln["frames"]), L._p(ln["ws"]), tc, which, stream),
+                         "coevo_dqn_forward_hidden_timed")
 
     def enqueue(self, T, gen_dev):
         """T agent-steps of every game + the closing bookkeeping call; cohort 0 on the current stream, the others on

@@ -127,6 +127,12 @@ _SIGS = {
     "coevo_dqn_forward_argmax_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                  C.c_int, C.c_void_p]),
+    "coevo_dqn_forward_hidden_timed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "coevo_dqn_out_synth_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                           C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]),
     "coevo_timing_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "coevo_timing_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "coevo_dqn_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -382,6 +382,11 @@ int coevo_dqn_forward_argmax_timed(const float *slab, const coevo_dqn_task *task
                                    int n_rows_total, int C, int n_actions, const uint8_t *frames, int32_t *actions,
                                    float *logits, int32_t *status, void *workspace, void *timing_ctx, int timed_kernel,
                                    void *stream);
+/* conv stack + fc1 only: leaves the hidden rows (post-ReLU fc1 outputs) in the workspace for coevo_dqn_out_synth_step,
+ * which runs the output layer in the env-step launch (two launches instead of three per agent-step) */
+int coevo_dqn_forward_hidden_timed(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int max_rows_per_task,
+                                   int n_rows_total, int C, int n_actions, const uint8_t *frames, void *workspace,
+                                   void *timing_ctx, int timed_kernel, void *stream);
 /* bracket whatever is enqueued on `stream` between the two calls with the context's next timing event pair */
 int coevo_timing_begin(void *ctx, void *stream);
 int coevo_timing_end(void *ctx, void *stream);
@@ -438,6 +443,15 @@ int coevo_synth_step(int32_t *game_state, double *acc, int n_games, const int64_
                      int64_t ordinals_per_gen, int t, const int32_t *limit, const int32_t *row_prev,
                      const int32_t *actions_prev, const int32_t *row_cur, uint8_t *frames, int C, int n_actions,
                      uint64_t seed, void *stream);
+/* coevo_synth_step for t >= 1 with the output layer of step t-1 fused in: game g's workgroup turns the hidden row of its
+ * actor (row_prev[g] of the workspace coevo_dqn_forward_hidden_timed filled for tasks_prev / n_rows_total) into logits and
+ * the first-max action (Atari/deepqn.py:48 + the argmax rule of MPE/fcnetwork.py:78-85), stores it in actions_prev, books
+ * it and writes the next frame.  Same results as coevo_dqn_forward_argmax + coevo_synth_step. */
+int coevo_dqn_out_synth_step(int32_t *game_state, double *acc, int n_games, const int64_t *game_ordinal0,
+                             const int32_t *gen_dev, int64_t ordinals_per_gen, int t, const int32_t *limit,
+                             const int32_t *row_prev, int32_t *actions_prev, const int32_t *row_cur, uint8_t *frames, int C,
+                             int n_actions, uint64_t seed, const float *slab, const coevo_dqn_task *tasks_prev,
+                             int n_tasks_prev, int n_rows_total, const void *workspace, int32_t *status, void *stream);
 
 #ifdef __cplusplus
 }
