@@ -224,6 +224,8 @@ def run_es(a, ctx, dev, pop_per_gpu=None, extension=None):
     cyc = (eng.T_train + 2) // 3
     P4 = {10: 559124, 8: 555028}
     gb = pop * (1 + cyc) * (2 * P4[10] + P4[8])   # materialise-once model of SURVEY 8d: write n*4P, read C*n*4P
+    # the dominant launch of a Co-ES generation: one env-cycle of one cohort, every individual's weight set streamed once
+    es_traffic, es_src = pmc_traffic("cfg3_es_ext" if ext else "cfg3_es", "fc_cycle_kernel")
     return {"metric": "env-steps/sec (agent-steps of the whole job; generations/sec in gens_per_sec), Co-ES "
                       "simple_adversary_v3 pop=1000/GPU",
             "value": gens * eng.steps_per_generation, "unit": "env-steps/s", "gens_per_sec": gens,
@@ -237,8 +239,9 @@ def run_es(a, ctx, dev, pop_per_gpu=None, extension=None):
                        "parallelism": f"population shard x{ctx.world}" if ctx.world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "whole generation (materialise-once model: write n*4P, read C*n*4P)",
                          "achieved": gb * gens / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gb * gens / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_generation": gb}}
+                         "frac": gb * gens / 1e9 / HBM_PEAK_GBS, "traffic": es_traffic, "traffic_source": es_src,
+                         "traffic_note": "HBM bytes per launch of fc_cycle_kernel (one env-cycle of one cohort), not per "
+                                         "generation", "algorithmic_bytes_per_generation": gb}}
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-input MFMA = the f32 vector rate (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -295,14 +298,19 @@ def run_dqn(a, ctx, dev, algo, pop_per_gpu=None, T=None):
         fc1_gbs = fc1_bytes / (f_avg * 1e-3) / 1e9
         rounds = (T + 1) // 2
         gen_bytes = eng.ro.weight_bytes_per_round() * rounds
+        wl = ("cfg4_dqn_ga" if ga else "cfg5_dqn_es") + ("" if a.channels == 4 else f"_c{a.channels}")
+        conv_traffic, conv_src = pmc_traffic(wl, "dqn_conv_kernel")
+        fc1_traffic, fc1_src = pmc_traffic(wl, "dqn_fc1_kernel")
         conv_rl = {"bound": "mfma", "kernel": "dqn_conv_kernel (conv stack + per-sample BatchNorm of every frame of one "
                    "agent-step of one cohort on v_mfma_f32_16x16x4_f32; exact f32 = the reference's arithmetic)",
                    "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
-                   "traffic": None, "flops_per_launch": n_frames * 2 * mac, "avg_launch_ms": c_avg,
+                   "traffic": conv_traffic, "traffic_source": conv_src, "flops_per_launch": n_frames * 2 * mac,
+                   "avg_launch_ms": c_avg,
                    "launches_timed": len(conv_ms)}
         fc1_rl = {"bound": "hbm", "kernel": "dqn_fc1_kernel (every acting net's 6.4 MB fc1 matrix streamed once for its "
-                  "<= 16 frames, v_mfma_f32_4x4x1)", "achieved": fc1_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                  "frac": fc1_gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": fc1_bytes,
+                  "<= 16 frames per task, v_mfma_f32_4x4x1)", "achieved": fc1_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": fc1_gbs / HBM_PEAK_GBS, "traffic": fc1_traffic, "traffic_source": fc1_src,
+                  "algorithmic_bytes_per_launch": fc1_bytes,
                   "avg_launch_ms": f_avg, "launches_timed": len(fc1_ms)}
         dom, other = (conv_rl, fc1_rl) if c_avg >= f_avg else (fc1_rl, conv_rl)
         out["roofline"] = dict(dom)
@@ -327,34 +335,60 @@ def L_load():
     return L.load()
 
 
+def pmc_traffic(workload, kernel_substr):
+    """HBM bytes per launch of a kernel from the tracked PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter
+    per pass, gfx950 correction applied: tools/pmc_traffic.py): (bytes, source) or (None, None)"""
+    path = os.path.join(REPO, "profiles", "r03_pmc_hbm_traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        j = json.load(f)
+    for name, e in j.get("workloads", {}).get(workload, {}).get("kernels", {}).items():
+        if kernel_substr in name and "hbm_bytes_per_launch" in e:
+            return e["hbm_bytes_per_launch"], f"profiles/r03_pmc_hbm_traffic.json [{workload}] {name}"
+    return None, None
+
+
 def extras(a, ctx, dev):
     """short, bounded runs of the other BASELINE configs on the same GPU, carried in the headline JSON so that the
-    driver's record holds them (each is also its own --workload)"""
+    driver's record holds them (each is also its own --workload / flag set)"""
     import copy
     import gc
     ex = {}
-    b = copy.copy(a)
-    b.steps, b.warmup = 5, 2
-    for name, fn in (("cfg3_coes_reference_exact", lambda: run_es(b, ctx, dev, extension=False)),
-                     ("cfg3_coes_extension_antithetic_centered_rank", lambda: run_es(b, ctx, dev, extension=True))):
+    keep = ("value", "unit", "gens_per_sec", "ms_per_step", "roofline")
+
+    def leg(name, fn):
         try:
             r = fn()
-            ex[name] = {k: r[k] for k in ("value", "unit", "gens_per_sec", "ms_per_step", "roofline")}
+            ex[name] = {k: r[k] for k in keep if k in r}
             ex[name]["workload"] = r["config"]["workload"]
         except Exception as e:
             ex[name] = {"error": repr(e)}
         gc.collect()
         torch.cuda.empty_cache()
-    b.steps, b.warmup = 5, 2   # (two timed generations under-reported cfg5 by 15 %: the first ones carry one-off host work)
-    for name, algo in (("cfg4_coga_deepqn_per_gpu_shard", "ga"), ("cfg5_coes_deepqn_per_gpu_shard", "es")):
-        try:
-            r = run_dqn(b, ctx, dev, algo)
-            ex[name] = {k: r[k] for k in ("value", "unit", "gens_per_sec", "ms_per_step", "roofline") if k in r}
-            ex[name]["workload"] = r["config"]["workload"]
-        except Exception as e:
-            ex[name] = {"error": repr(e)}
-        gc.collect()
-        torch.cuda.empty_cache()
+
+    b = copy.copy(a)
+    b.steps, b.warmup, b.no_cpu_baseline = 5, 2, True
+    # SURVEY 8d "two variants, both reported": the env built with max_cycles >= 67 so that T = 200 binds
+    t200 = copy.copy(b)
+    t200.max_cycles = 67
+    leg("cfg2_T200_env_max_cycles_67", lambda: run_ga(t200, ctx, dev))
+    # north_star's literal first configuration: the env vectorised on the host cores, observations up / actions down over
+    # PCIe every cycle - the PCIe-and-Python-inclusive rate, never the headline
+    host = copy.copy(b)
+    host.env, host.steps, host.warmup = "host", 3, 1
+    leg("cfg2_host_env_mode", lambda: run_ga(host, ctx, dev))
+    leg("cfg3_coes_reference_exact", lambda: run_es(b, ctx, dev, extension=False))
+    leg("cfg3_coes_extension_antithetic_centered_rank", lambda: run_es(b, ctx, dev, extension=True))
+    # (two timed generations under-reported cfg5 by 15 %: the first ones carry one-off host work)
+    leg("cfg4_coga_deepqn_per_gpu_shard", lambda: run_dqn(b, ctx, dev, "ga"))
+    leg("cfg5_coes_deepqn_per_gpu_shard", lambda: run_dqn(b, ctx, dev, "es"))
+    # six frame planes: what the reference's wrapper stack yields (frame_stack_v1(4) + agent_indicator_v0,
+    # utils/game_logic_functions.py:50-53; Atari/atari_agent.py:20); BASELINE.json words the configs as 84x84x4
+    c6 = copy.copy(b)
+    c6.channels = 6
+    leg("cfg4_coga_deepqn_per_gpu_shard_6_planes", lambda: run_dqn(c6, ctx, dev, "ga"))
+    leg("cfg5_coes_deepqn_per_gpu_shard_6_planes", lambda: run_dqn(c6, ctx, dev, "es"))
     return ex
 
 
@@ -463,16 +497,17 @@ def run_ga(a, ctx, dev):
             else:
                 kernel_id = f"fc_policy_kernel<{R}, 2>"
             traffic, traffic_note = None, None
-            pmc = os.path.join(REPO, "profiles", "r02_pmc_hbm_traffic.json")
-            if a.pop_per_gpu == 200 and a.hof == 5 and os.path.exists(pmc):
+            if a.pop_per_gpu == 200 and a.hof == 5 and a.max_cycles == 25:
                 # HBM bytes per launch of this kernel from the PMC counters (FETCH_SIZE/WRITE_SIZE, separate rocprofv3
                 # passes of this same command, gfx950 correction applied) - collected offline, see the file
-                with open(pmc) as f:
-                    j = json.load(f)
-                want = kernel_id
-                if want in j.get("dominant_kernel", ""):
-                    traffic = j["dominant_kernel_hbm_bytes_per_launch"]
-                    traffic_note = "profiles/r02_pmc_hbm_traffic.json (rocprofv3 --pmc passes of this command)"
+                traffic, traffic_note = pmc_traffic("headline", kernel_id)
+                pmc = os.path.join(REPO, "profiles", "r02_pmc_hbm_traffic.json")
+                if traffic is None and os.path.exists(pmc):   # (last round's passes, same kernel)
+                    with open(pmc) as f:
+                        j = json.load(f)
+                    if kernel_id in j.get("dominant_kernel", ""):
+                        traffic = j["dominant_kernel_hbm_bytes_per_launch"]
+                        traffic_note = "profiles/r02_pmc_hbm_traffic.json (rocprofv3 --pmc passes of this command)"
             kname = (kernel_id +
                      " (one env-cycle of one cohort: per-individual weight sets streamed once + shared-opponent tasks "
                      "on the matrix cores, fused env step)" if merged else

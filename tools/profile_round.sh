@@ -1,11 +1,12 @@
 #!/bin/bash
 # rocprofv3 runs behind the numbers of DESIGN.md / bench.py (run on the GPU box through gpurun; results land in
 # gpurun_out/prof_<tag>/ and tools/summarise_profiles.py turns them into the tracked summaries under profiles/).
-#   tools/profile_round.sh <tag>         e.g. r02
+#   tools/profile_round.sh <tag>         e.g. r03
+# then: python tools/summarise_profiles.py ... and python tools/pmc_traffic_all.py gpurun_out/prof_<tag> profiles/<tag>_pmc_hbm_traffic.json
 # Separate passes: kernel trace + stats per workload; FETCH_SIZE and WRITE_SIZE (one counter per pass, never combined
 # with a trace domain other than --kernel-trace) for the headline.
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -25,8 +26,21 @@ run cfg3_es --workload es --steps 10 --warmup 3
 run cfg3_es_ext --workload es --extension --steps 10 --warmup 3
 run cfg4_dqn_ga --workload dqn-ga --steps 2 --warmup 1
 run cfg5_dqn_es --workload dqn-es --steps 2 --warmup 1
-for ctr in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_$ctr -- python3 $ROOT/bench.py --no-extra --no-cpu-baseline \
-        --steps 5 --warmup 2 > $OUT/pmc_$ctr.log 2>&1 || echo "FAILED: pmc $ctr"
-    echo "done pmc $ctr"
-done
+run cfg4_dqn_ga_c6 --workload dqn-ga --channels 6 --steps 2 --warmup 1
+run cfg5_dqn_es_c6 --workload dqn-es --channels 6 --steps 2 --warmup 1
+run cfg2_host_env --env host --steps 3 --warmup 1
+pmc() {  # workload name, bench args...: one pass per counter (never combined with a trace domain other than --kernel-trace)
+    local name=$1; shift
+    for ctr in FETCH_SIZE WRITE_SIZE; do
+        rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_${name}_$ctr -- python3 $ROOT/bench.py --no-extra \
+            --no-cpu-baseline "$@" > $OUT/pmc_${name}_$ctr.log 2>&1 || echo "FAILED: pmc $name $ctr"
+        grep -h '^{' $OUT/pmc_${name}_$ctr.log | tail -1 > $OUT/pmc_${name}_$ctr.bench.json
+        echo "done pmc $name $ctr"
+    done
+}
+pmc headline --steps 5 --warmup 2
+pmc cfg3_es --workload es --steps 3 --warmup 1
+pmc cfg4_dqn_ga --workload dqn-ga --steps 1 --warmup 1
+pmc cfg5_dqn_es --workload dqn-es --steps 1 --warmup 1
+pmc cfg4_dqn_ga_c6 --workload dqn-ga --channels 6 --steps 1 --warmup 1
+pmc cfg5_dqn_es_c6 --workload dqn-es --channels 6 --steps 1 --warmup 1
