@@ -1132,10 +1132,7 @@ __device__ __forceinline__ void fc_policy_mfma16_body(const FcArgs &a, FcMfma16S
             p_b1[T] = b1p[j]; p_g1[T] = b1p[H1 + j]; p_be1[T] = b1p[2 * H1 + j];
         }
 #pragma unroll
-        for (int T = 0; T < 4; ++T) {
-            const int j = 64 * w + 16 * T + lc;
-            p_b2[T] = b2p[j]; p_g2[T] = b2p[H2 + j]; p_be2[T] = b2p[2 * H2 + j];
-        }
+        for (int T = 0; T < 4; ++T) p_b2[T] = b2p[64 * w + 16 * T + lc];
     }
     const float p_b3 = (t < 16 * NACT) ? net[fc_off_b3(D) + t % NACT] : 0.0f;
 
@@ -1174,6 +1171,17 @@ __device__ __forceinline__ void fc_policy_mfma16_body(const FcArgs &a, FcMfma16S
     {
         const float *W3 = net + fc_off_w3(D);
         for (int i = t; i < NACT * H2; i += 256) sm.w3s[i >> 8][i & 255] = W3[i];
+    }
+    // the LayerNorm(256) affine is not needed before the end of the fc2 stream: requested after the env step (whose fp64
+    // state is the register peak of this body - held across it, these eight values were spilled to scratch), still long
+    // before the stream's own loads
+    {
+        const float *b2p = net + fc_off_b2(D);
+#pragma unroll
+        for (int T = 0; T < 4; ++T) {
+            const int j = 64 * w + 16 * T + lc;
+            p_g2[T] = b2p[H2 + j]; p_be2[T] = b2p[2 * H2 + j];
+        }
     }
     __syncthreads();
     COEVO_STAMP(1);

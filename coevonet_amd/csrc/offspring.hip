@@ -6,7 +6,7 @@
 // (evolutionary_strategy.py:120-148).
 //
 // Noise is counter-based so that no weight ever crosses PCIe: eps(seed, stream, p) for canonical flat index p is
-// element p%4 of Philox4x32-10(counter = (p/4, stream_lo, stream_hi, 'coev'), key = seed) pushed through a
+// element p%4 of Philox4x32-7(counter = (p/4, stream_lo, stream_hi, 'coev'), key = seed) pushed through a
 // Box-Muller transform whose log / sincos are fmaf-only polynomials (bit-identical with oracle/coevo_oracle.c).
 // A child is one streaming pass: read parent (L2/Infinity-Cache resident elite), write child once.
 #include "coevo_common.hip.h"

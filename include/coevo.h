@@ -208,7 +208,7 @@ int coevo_mpe_final_step(const double *state, int n_games, const int32_t *action
                          const int32_t *game_limit, int pos_first, double *rewards, void *stream);
 
 /* ---------------------------------------------------------------- K3/K4/K8: offspring on device ------------- */
-/* child = parent + sigma * eps(seed, stream, p), p = canonical flat index; Philox4x32-10 + Box-Muller with
+/* child = parent + sigma * eps(seed, stream, p), p = canonical flat index; Philox4x32-7 (the Crush-resistant minimum) + Box-Muller with
  * fmaf-only polynomials (bit-reproducible against the oracle).  Replaces clone()+Agent.mutate (agent.py:25-29,
  * genetic_algorithm.py:32-48) and Agent.mutate_ES (agent.py:51-53).
  *   parent_slab/child_slab: slabs in device layout; parent_idx[c] = net index of child c's parent in parent_slab

@@ -342,10 +342,11 @@ double oracle_diversity(const float *individual, const float *w, int n, size_t s
 }
 
 /* ------------------------------------------------------------------ counter-based Gaussian noise */
-static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
-                          uint32_t out[4])
+#define COEVO_NOISE_ROUNDS 7   /* offspring noise: Philox4x32-7 (csrc/philox.hip.h); the synthetic env keeps 10 rounds */
+static void philox4x32(int rounds, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                       uint32_t out[4])
 {
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < rounds; ++r) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
         uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
@@ -353,6 +354,12 @@ static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                          uint32_t out[4])
+{
+    philox4x32(10, c0, c1, c2, c3, k0, k1, out);
 }
 
 static float u32_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -427,7 +434,7 @@ static void box_muller(uint32_t a, uint32_t b, float *z0, float *z1)
 void oracle_philox_normal4(uint64_t seed, uint32_t stream_lo, uint32_t stream_hi, uint32_t q, float z[4])
 {
     uint32_t o[4];
-    philox4x32_10(q, stream_lo, stream_hi, 0x636f6576u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    philox4x32(COEVO_NOISE_ROUNDS, q, stream_lo, stream_hi, 0x636f6576u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
     box_muller(o[0], o[1], &z[0], &z[1]);
     box_muller(o[2], o[3], &z[2], &z[3]);
 }
