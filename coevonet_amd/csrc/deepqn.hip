@@ -30,6 +30,12 @@ namespace coevo {
 #ifndef DQ_FC1_NB
 #define DQ_FC1_NB 8    // fc1: chunks in the wave's register ring (NB - 1 in flight)
 #endif
+#ifndef DQ_FC1_NBN
+#define DQ_FC1_NBN 16   // ring depth of the narrow kernel (one dword per lane and piece: 112 pieces = 28 KiB per wave)
+#endif
+#ifndef DQ_FC1_NARROW_MAX_TASKS
+#define DQ_FC1_NARROW_MAX_TASKS 16   // launches of at most this many tasks take the 32-waves-per-task kernel
+#endif
 #ifndef DQ_FC1_ALLNT
 #define DQ_FC1_ALLNT 0   // 1: non-temporal weight loads for every task (A/B)
 #endif
@@ -535,6 +541,65 @@ __global__ __launch_bounds__(64, NB <= DQ_FC1_NB_MANY ? 2 : 1) void dqn_fc1_kern
     }
 }
 
+// fc1 + ReLU of a SMALL launch (a Co-ES generation's ten evaluation games: one task per agent-step, 600 dependent launches
+// per generation).  Such a launch is bound by the LATENCY of the k chain, not by throughput: 8 waves with 3 - 4 independent
+// accumulators each advance one k per dependent v_mfma_f32_4x4x1 (~40 cycles): 3136 x 40 cycles = 52 us + the stream =
+// 75 us per launch on an empty chip.  Here a wave owns 16 outputs x all <= 16 rows as ONE v_mfma_f32_16x16x4 tile, which
+// advances FOUR k per dependent instruction (784 x 40 cycles = 13 us; the same sequential-k bits, tools/mfma16_chain_probe),
+// and a task has 32 waves.  Operands: lane (c = l % 16, kk = l / 16): A = x[row c][4 q + kk] (LDS), B = W[16 jb + c][4 q + kk]
+// = element kk of the tile's 16-byte piece of lane 16 jb + c (one dword per lane, 256 contiguous bytes per wave).
+// Measured on the evaluation launch (1 task x 10 rows): 75.5 us (wide kernel) -> 54.7 (16 outputs per wave on 4x4x1, one
+// accumulator: the same 40-cycle chain) -> 37.1 (16x16x4, activations staged in LDS per chunk) -> this form.
+template <int NB>
+__global__ __launch_bounds__(64) void dqn_fc1_narrow_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int C,
+                                                             int n_actions, const float *act, float *hid)
+{
+    constexpr int U = DQ_FC1_U, NCHUNK = 784 / U;
+    static_assert(NCHUNK % NB == 0, "whole rounds of the ring");
+    const int ti = blockIdx.x;
+    const coevo_dqn_task task = tasks[ti];
+    const float *net = slab + task.net_off;
+    const DqnLayout L = dqn_layout(C, n_actions);
+    const int ob = blockIdx.y >> 2, jb = blockIdx.y & 3, l = threadIdx.x, c = l & 15, kk = l >> 4, col = 16 * jb + c;
+    const int nrows = task.n_rows;
+    f32x4_acc acc;
+    {
+        const float bb = net[L.bf + 64 * ob + col];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = bb;
+    }
+    // both operands straight from memory, one dword per lane and k-quad each, NB x U k-quads ahead of the chain (the
+    // activations are L2 hits; rows past the task's last repeat it - their sums are never stored): no LDS staging, no
+    // barrier between the 784 dependent matrix instructions
+    const float *wp = net + L.wf + ((size_t)ob * 784 * 64 + col) * 4 + kk;
+    const float *xp = act + (size_t)(task.row_begin + min(c, nrows - 1)) * DQ_FC1_IN + kk;
+    float wv[NB][U], xv[NB][U];
+    auto issue = [&](float (&w)[U], float (&x)[U], int kq) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            w[u] = wp[(size_t)(kq + u) * 256];   // (plain loads: the net is read by every step)
+            x[u] = xp[4 * (kq + u)];
+        }
+    };
+#pragma unroll
+    for (int b = 0; b < NB - 1; ++b) issue(wv[b], xv[b], b * U);
+#pragma nounroll
+    for (int c0 = 0; c0 < NCHUNK; c0 += NB) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int nxt = min(c0 + b + NB - 1, NCHUNK - 1);   // (clamped, unconditional: straight-line code)
+            issue(wv[(b + NB - 1) % NB], xv[(b + NB - 1) % NB], nxt * U);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[b][u], wv[b][u], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (4 * kk + i < nrows)
+            hid[(size_t)(task.row_begin + 4 * kk + i) * DQ_FC1_OUT + 64 * ob + col] = relu_keep_nan(acc[i]);
+}
+
 // output layer + first-max action: one 64-thread workgroup per (task, row) (dqn_out_row, dqn_common.hip.h).  The
 // population engine does not launch it: there the output layer rides in the env-step launch (coevo_dqn_out_synth_step).
 __global__ __launch_bounds__(64) void dqn_out_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int C,
@@ -610,7 +675,10 @@ static int dqn_forward_launch(const float *slab, const coevo_dqn_task *tasks, in
     if (timing_ctx && timed_kernel == 0 && coevo_timing_end(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     if (timing_ctx && timed_kernel == 1 && coevo_timing_begin(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     const dim3 fg(8 * ((n_tasks + 7) / 8), 8);
-    if (n_tasks * 8 <= 1024) hipLaunchKernelGGL(dqn_fc1_kernel<DQ_FC1_NB>, fg, dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, act, hid);
+    if (n_tasks <= DQ_FC1_NARROW_MAX_TASKS)
+        hipLaunchKernelGGL(dqn_fc1_narrow_kernel<DQ_FC1_NBN>, dim3(n_tasks, 32), dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions,
+                           act, hid);
+    else if (n_tasks * 8 <= 1024) hipLaunchKernelGGL(dqn_fc1_kernel<DQ_FC1_NB>, fg, dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, act, hid);
     else hipLaunchKernelGGL(dqn_fc1_kernel<DQ_FC1_NB_MANY>, fg, dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, act, hid);
     if (timing_ctx && timed_kernel == 1 && coevo_timing_end(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     if (actions)

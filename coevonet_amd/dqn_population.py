@@ -585,6 +585,8 @@ class DQNESEngine(_SlabMixin):
         self.partials = torch.zeros(self.world * self.part_block, **f32)
         self.game_idx = torch.stack([torch.arange(self.n_local, device=device) * 2 + ri for ri in range(2)])
         self.steps_per_generation = 2 * pop * self.T_train + N_EVAL * self.T_eval
+        self.eval_graph = os.environ.get("COEVO_DQN_EVAL_GRAPH", "1") != "0"
+        self._eval_graph = None
 
     def generation(self, gen, sigmas, lr, fitness_sharing):
         """perturb -> this rank's 2*n_local games -> (rewards, distances) gathered -> fitness -> chunk partial sums
@@ -625,7 +627,18 @@ class DQNESEngine(_SlabMixin):
             L.call("coevo_dqn_es_apply", self._ptr(r, "base"), self.partials.data_ptr() + 4 * self.part_off[r],
                    self.chunks, self.chunks_local, self.part_block, self.C, self.n_actions, self.pop,
                    self.sigma.data_ptr() + 4 * ri, L.C.c_float(lr))
-        self.eval_ro.enqueue(self.T_eval, self.gen_dev)
+        # the ten evaluation games of the updated base nets: a chain of 3 x T_eval small dependent launches (29 % of a cfg 5
+        # generation when enqueued one by one) - replayed as one hipGraph (the generation index is read from the device)
+        if self.eval_graph:
+            if self._eval_graph is None:
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, capture_error_mode="thread_local"):
+                    self.eval_ro.enqueue(self.T_eval, self.gen_dev)
+                self._eval_graph = gr
+            self._eval_graph.replay()
+        else:
+            self.eval_ro.enqueue(self.T_eval, self.gen_dev)
         torch.cuda.synchronize()
         L.raise_on_status(self.ro.status)
         L.raise_on_status(self.eval_ro.status)

@@ -35,6 +35,10 @@ if a.shape == "cfg4":      # pop 50 x 10 HoF games, 10 HoF nets x 50 games (+ 10
     for j in range(10):
         layout += [(50 + j, r) for r in (_cut(60) if j == 0 else _cut(50))]
     n_nets = 60
+elif a.shape == "eval":    # the evaluation games of a Co-ES generation: one base net x 10 games
+    n_act = 18
+    layout = [(0, 10)]
+    n_nets = 1
 else:                      # one cohort of cfg 5: 125 perturbed nets x 1 game, the base net x 125 games
     n_act = 18
     layout = []
