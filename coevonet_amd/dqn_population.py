@@ -559,9 +559,9 @@ class DQNESEngine(_SlabMixin):
         # two cohorts by default: one-frame tasks make this rollout fc1-bound (6.4 MB of weights per frame), and one
         # cohort's conv launch (matrix pipe) then runs under the other's fc1 stream (HBM): cfg 5 shard 9.5 vs 9.1
         # generations/s.  (Co-GA's 10-frame tasks are conv-bound: one cohort is faster there, 16.4 vs 15.6.)
-        K = int(os.environ.get("COEVO_DQN_COHORTS", "2"))
-        half = 2 * (self.n_local // 2)   # games are individual-major: the first half of the individuals / the rest
-        bounds = [0, half, self.n_main] if (K > 1 and 0 < half < self.n_main) else None
+        K = max(1, min(int(os.environ.get("COEVO_DQN_COHORTS", "2")), self.n_local))
+        # games are individual-major (two per individual): cohort k = individuals [k n / K, (k + 1) n / K)
+        bounds = [2 * (k * self.n_local // K) for k in range(K)] + [self.n_main] if K > 1 else None
         self.ro = SynthRollout(games, net_off, ordinal0, C, n_actions, self.slab, env_seed, self.per_gen, device,
                                bounds=bounds)
         self.ro.set_limits(np.full(self.n_main, self.T_train, dtype=np.int32))
