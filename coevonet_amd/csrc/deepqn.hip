@@ -17,6 +17,7 @@
 // fp32 arithmetic follows the canonical order of oracle/coevo_oracle.c (taps in (ci,ky,kx) order, sequential-k fc
 // chains), so logits equal the oracle's bit for bit.
 #include "dqn_common.hip.h"
+#include <type_traits>
 
 namespace coevo {
 
@@ -30,8 +31,14 @@ namespace coevo {
 #ifndef DQ_FC1_NB
 #define DQ_FC1_NB 8    // fc1: chunks in the wave's register ring (NB - 1 in flight)
 #endif
+#ifndef DQ_SMALL_QU
+#define DQ_SMALL_QU 16   // k-steps per chunk in the small-launch conv kernels: a wave is alone on its SIMD there, so the LDS
+#endif                   // latency of its gathers is hidden by depth (16 gathers in flight), not by other waves
+#ifndef DQ_SMALL_MAX_ROWS
+#define DQ_SMALL_MAX_ROWS 32   // launches of at most this many frames take the three-launch conv stack
+#endif
 #ifndef DQ_FC1_NBN
-#define DQ_FC1_NBN 16   // ring depth of the narrow kernel (one dword per lane and piece: 112 pieces = 28 KiB per wave)
+#define DQ_FC1_NBN 4    // ring depth of the narrow kernel: chunks of DQ_FC1_U x 4 k-quads, two 16-byte loads per lane each
 #endif
 #ifndef DQ_FC1_NARROW_MAX_TASKS
 #define DQ_FC1_NARROW_MAX_TASKS 16   // launches of at most this many tasks take the 32-waves-per-task kernel
@@ -128,11 +135,15 @@ struct Conv16 {
 
     // NU whole units (+ the half unit when XL) of wave w, as straight-line code: the unit count is a template argument so
     // that the k-loop has no branches and the scheduler can move a k-step's gathers above the previous step's MFMAs
+    // The units are given by the caller: channel pair np (all units of a wave share it), position tile mt[i] of unit i,
+    // xh = which channel tile of the last position tile the half unit takes (XL).  in_shift: elements by which `in_lds`
+    // starts inside the layer's input image (a kernel that stages only the rows its tile needs).
     template <int NU, bool XL>
     static __device__ __forceinline__ void run(const void *in_lds, const float *lut, int cin, int taps, const float *wt,
-                                               const float *bias, float *out, const unsigned short *tap3, int w, int l)
+                                               const float *bias, float *out, const unsigned short *tap3, int l, int np,
+                                               const int (&mt)[NU > 0 ? NU : 1], int xh, int in_shift)
     {
-        const int c = l & 15, kk = l >> 4, np = w % NP;
+        const int c = l & 15, kk = l >> 4;
         constexpr int NA = NU > 0 ? NU : 1;
         f32x4_acc acc[NA][2], accx;
         int base[NA], xbase = 0;
@@ -140,11 +151,11 @@ struct Conv16 {
             int p = 16 * m + c;
             if (p >= NPOS) p = 0;   // padded rows read position 0; their results are never stored
             const int oy = p / HOUT, ox = p % HOUT;
-            return U8IN ? ((oy * STRIDE) * HIN + ox * STRIDE) * (CT ? CT : cin) : (oy * STRIDE) * HIN + ox * STRIDE;
+            return (U8IN ? ((oy * STRIDE) * HIN + ox * STRIDE) * (CT ? CT : cin) : (oy * STRIDE) * HIN + ox * STRIDE) - in_shift;
         };
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-            base[i] = tile_base((w + 8 * i) / NP);
+            base[i] = tile_base(mt[i]);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const float bb = bias[32 * np + 16 * h + c];
@@ -158,7 +169,7 @@ struct Conv16 {
         }
         if constexpr (XL) {
             xbase = tile_base(NM - 1);
-            const float bb = bias[16 * (w & 1) + c];
+            const float bb = bias[16 * xh + c];
 #pragma unroll
             for (int r = 0; r < 4; ++r) accx[r] = bb;
             asm volatile("" : "+v"(accx));
@@ -206,7 +217,7 @@ struct Conv16 {
                 }
                 if constexpr (XL) {
                     const float av = gather(xbase);
-                    accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av, (w & 1) ? bv[j][1] : bv[j][0], accx, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xh ? bv[j][1] : bv[j][0], accx, 0, 0, 0);
                 }
             }
         };
@@ -222,7 +233,7 @@ struct Conv16 {
         if constexpr (OVER) __syncthreads();   // the output overwrites the input: every wave has gathered its last tap
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-            const int m = (w + 8 * i) / NP;
+            const int m = mt[i];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -235,14 +246,15 @@ struct Conv16 {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int p = 16 * (NM - 1) + 4 * kk + r;
-                if (p < NPOS) out[(16 * (w & 1) + c) * OUT_PITCH + p] = accx[r];
+                if (p < NPOS) out[(16 * xh + c) * OUT_PITCH + p] = accx[r];
             }
         }
     }
 };
 
-// w must be wave-uniform in an SGPR (readfirstlane): the dispatch below is a scalar branch (every wave runs exactly one
-// instantiation, so the barrier inside is reached once by all of them)
+// The whole layer on the eight waves of a frame's workgroup: unit u = w + 8 i belongs to wave w.  w must be wave-uniform in
+// an SGPR (readfirstlane): the dispatch below is a scalar branch (every wave runs exactly one instantiation, so the barrier
+// inside is reached once by all of them)
 template <int KS, int STRIDE, int HIN, int HOUT, int COUT, bool U8IN, int IN_PITCH, int OUT_PITCH, int CT, int QU, bool OVER>
 __device__ __forceinline__ void conv16_mfma(const void *in_lds, const float *lut, int cin, int taps, const float *wt,
                                             const float *bias, float *out, const unsigned short *tap3, int w, int l)
@@ -250,14 +262,23 @@ __device__ __forceinline__ void conv16_mfma(const void *in_lds, const float *lut
     using K = Conv16<KS, STRIDE, HIN, HOUT, COUT, U8IN, IN_PITCH, OUT_PITCH, CT, QU, OVER>;
     // every wave must enter run<> exactly once: the barrier of an OVER layer sits inside it
     static_assert(K::SPLIT || K::REM == 0 || K::NFULL > 0, "a wave without units would skip run<>'s barrier");
+    const int np = w % K::NP;
+    auto call = [&](auto nu, auto xl) {
+        constexpr int NU = decltype(nu)::value;
+        int mt[NU > 0 ? NU : 1];
+#pragma unroll
+        for (int i = 0; i < (NU > 0 ? NU : 1); ++i) mt[i] = (w + 8 * i) / K::NP;
+        K::template run<NU, decltype(xl)::value>(in_lds, lut, cin, taps, wt, bias, out, tap3, l, np, mt, w & 1, 0);
+    };
+    using std::integral_constant;
     if constexpr (K::SPLIT) {
-        if (w < 2) K::template run<K::NFULL, true>(in_lds, lut, cin, taps, wt, bias, out, tap3, w, l);
-        else K::template run<K::NFULL, false>(in_lds, lut, cin, taps, wt, bias, out, tap3, w, l);
+        if (w < 2) call(integral_constant<int, K::NFULL>{}, integral_constant<bool, true>{});
+        else call(integral_constant<int, K::NFULL>{}, integral_constant<bool, false>{});
     } else if constexpr (K::REM == 0) {
-        K::template run<K::NFULL, false>(in_lds, lut, cin, taps, wt, bias, out, tap3, w, l);
+        call(integral_constant<int, K::NFULL>{}, integral_constant<bool, false>{});
     } else {
-        if (w < K::REM) K::template run<K::NFULL + 1, false>(in_lds, lut, cin, taps, wt, bias, out, tap3, w, l);
-        else if constexpr (K::NFULL > 0) K::template run<K::NFULL, false>(in_lds, lut, cin, taps, wt, bias, out, tap3, w, l);
+        if (w < K::REM) call(integral_constant<int, K::NFULL + 1>{}, integral_constant<bool, false>{});
+        else call(integral_constant<int, K::NFULL>{}, integral_constant<bool, false>{});
     }
 }
 
@@ -400,6 +421,100 @@ __global__ __launch_bounds__(512, DQ_WPE) void dqn_conv_kernel(const float *slab
     float *dsta = act + (size_t)row * DQ_FC1_IN;
     for (int i = t; i < DQ_FC1_IN; i += 512) dsta[i] = sm.a3[i];
     DQ_STAMP(8);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The conv stack of a SMALL launch (a Co-ES generation's evaluation games: ten frames per agent-step, 200 dependent steps;
+// the reference's own population sizes of record are 20): one workgroup per frame leaves the chip empty and takes 51 us
+// (28.6 us of matrix issue on the four SIMDs of ONE CU, eight barriers).  Here a frame is spread over the chip in three
+// launches, the layers' images passing through L2:
+//   dqn_small_conv1_kernel  (frame, position tile): one wave stages the 12 input rows its 16 positions need and runs the
+//                           tile's 64 k-steps for all 32 channels; raw sums -> a1raw[frame][32][400]          (25 waves / frame)
+//   dqn_small_conv2_kernel  (frame, channel pair): BatchNorm(32) + ReLU of conv1's sums (statistics need every position,
+//                           so they are taken here, by each of the two workgroups), then conv2 + BatchNorm + ReLU of
+//                           32 of the 64 channels -> a2[frame][64][81]
+//   dqn_small_conv3_kernel  (frame, channel pair): conv3 + BatchNorm + ReLU of 32 channels -> act[frame][3136]
+// Same Conv16 / bn_relu_rows code, same order of every sum: the bits of dqn_conv_kernel.
+constexpr int DQ_SMALL_ROWS1 = 12;   // input rows a 16-position tile of conv1 touches: two output rows x stride 4 + 8 - 4
+
+template <int CMAX, int CT>
+__global__ __launch_bounds__(64) void dqn_small_conv1_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int C,
+                                                              int n_actions, const uint8_t *frames, float *a1raw)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char rows[DQ_SMALL_ROWS1 * 84 * CMAX + 16];
+    __shared__ float lut[DQ_LUT ? 256 : 1];
+    const int row = blockIdx.x, m = blockIdx.y, l = threadIdx.x;
+    const coevo_dqn_task task = tasks[task_of_row(tasks, n_tasks, row)];
+    const float *net = slab + task.net_off;
+    const DqnLayout L = dqn_layout(C, n_actions);
+    const int y0 = 4 * ((16 * m) / 20);                               // first input row of the tile's first output row
+    const int nrows = min(DQ_SMALL_ROWS1, 84 - y0), nbytes = nrows * 84 * C;   // (84 * C is a multiple of 16)
+    const uint4 *src = reinterpret_cast<const uint4 *>(frames + (size_t)row * (84 * 84 * C) + (size_t)y0 * 84 * C);
+    uint4 *dst = reinterpret_cast<uint4 *>(rows);
+    for (int i = l; i < nbytes / 16; i += 64) dst[i] = src[i];
+    if (DQ_LUT) for (int i = l; i < 256; i += 64) lut[i] = (float)i / 255.0f;
+    __syncthreads();
+    using K = Conv16<8, 4, 84, 20, 32, true, 0, 400, CT, DQ_SMALL_QU, false>;
+    const int mt[1] = {m};
+    K::template run<1, false>(rows, lut, C, C * 64, net + L.w1, net + L.b1, a1raw + (size_t)row * (32 * 400), nullptr, l, 0, mt, 0,
+                              y0 * 84 * C);
+}
+
+struct DqnSmallSmem2 {
+    union {
+        float a1[32 * DQ_P1];
+        float a2[64 * DQ_P2];
+    };
+};
+
+__global__ __launch_bounds__(512) void dqn_small_conv2_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int C,
+                                                               int n_actions, const float *a1raw, float *a2g)
+{
+    __shared__ __attribute__((aligned(16))) DqnSmallSmem2 sm;
+    const int row = blockIdx.x, pr = blockIdx.y;
+    const coevo_dqn_task task = tasks[task_of_row(tasks, n_tasks, row)];
+    const int t = threadIdx.x, w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;
+    const float *net = slab + task.net_off;
+    const DqnLayout L = dqn_layout(C, n_actions);
+    const float *src = a1raw + (size_t)row * (32 * 400);
+    for (int i = t; i < 32 * 400; i += 512) sm.a1[(i / 400) * DQ_P1 + i % 400] = src[i];
+    __syncthreads();
+    bn_relu_rows<400, DQ_P1, 32>(sm.a1, net + L.b1 + 32, net + L.b1 + 64, w, l);
+    __syncthreads();
+    using K = Conv16<4, 2, 20, 9, 64, false, DQ_P1, DQ_P2, 0, DQ_SMALL_QU, true>;
+    const int mt[1] = {w};
+    if (w < K::NM) K::template run<1, false>(sm.a1, nullptr, 32, 512, net + L.w2, net + L.b2, sm.a2, nullptr, l, pr, mt, 0, 0);
+    else K::template run<0, false>(sm.a1, nullptr, 32, 512, net + L.w2, net + L.b2, sm.a2, nullptr, l, pr, mt, 0, 0);
+    __syncthreads();
+    bn_relu_rows<81, DQ_P2, 32>(sm.a2 + 32 * pr * DQ_P2, net + L.b2 + 64 + 32 * pr, net + L.b2 + 128 + 32 * pr, w, l);
+    __syncthreads();
+    float *dst = a2g + (size_t)row * (64 * DQ_P2) + 32 * pr * DQ_P2;
+    for (int i = t; i < 32 * DQ_P2; i += 512) dst[i] = sm.a2[32 * pr * DQ_P2 + i];
+}
+
+__global__ __launch_bounds__(512) void dqn_small_conv3_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int C,
+                                                               int n_actions, const float *a2g, float *act)
+{
+    __shared__ __attribute__((aligned(16))) float a2[64 * DQ_P2];
+    __shared__ __attribute__((aligned(16))) float a3[64 * DQ_P3];
+    __shared__ unsigned short tap3[576];
+    const int row = blockIdx.x, pr = blockIdx.y;
+    const coevo_dqn_task task = tasks[task_of_row(tasks, n_tasks, row)];
+    const int t = threadIdx.x, w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;
+    const float *net = slab + task.net_off;
+    const DqnLayout L = dqn_layout(C, n_actions);
+    const float *src = a2g + (size_t)row * (64 * DQ_P2);
+    for (int i = t; i < 64 * DQ_P2; i += 512) a2[i] = src[i];
+    for (int i = t; i < 576; i += 512) tap3[i] = (unsigned short)((i / 9) * DQ_P2 + ((i % 9) / 3) * 9 + (i % 3));
+    __syncthreads();
+    using K = Conv16<3, 1, 9, 7, 64, false, DQ_P2, DQ_P3, 0, DQ_SMALL_QU, false>;
+    const int mt[1] = {w};
+    if (w < K::NM) K::template run<1, false>(a2, nullptr, 64, 576, net + L.w3, net + L.b3, a3, tap3, l, pr, mt, 0, 0);
+    __syncthreads();
+    bn_relu_rows<49, DQ_P3, 32>(a3 + 32 * pr * DQ_P3, net + L.b3 + 64 + 32 * pr, net + L.b3 + 128 + 32 * pr, w, l);
+    __syncthreads();
+    float *dst = act + (size_t)row * DQ_FC1_IN + 32 * pr * DQ_P3;   // CHW flatten: channel pitch 49 = the flat layout
+    for (int i = t; i < 32 * DQ_P3; i += 512) dst[i] = a3[32 * pr * DQ_P3 + i];
 }
 
 constexpr int DQ_RMAX = 16;
@@ -549,13 +664,13 @@ __global__ __launch_bounds__(64, NB <= DQ_FC1_NB_MANY ? 2 : 1) void dqn_fc1_kern
 // and a task has 32 waves.  Operands: lane (c = l % 16, kk = l / 16): A = x[row c][4 q + kk] (LDS), B = W[16 jb + c][4 q + kk]
 // = element kk of the tile's 16-byte piece of lane 16 jb + c (one dword per lane, 256 contiguous bytes per wave).
 // Measured on the evaluation launch (1 task x 10 rows): 75.5 us (wide kernel) -> 54.7 (16 outputs per wave on 4x4x1, one
-// accumulator: the same 40-cycle chain) -> 37.1 (16x16x4, activations staged in LDS per chunk) -> this form.
+// accumulator: the same 40-cycle chain) -> 37.1 (16x16x4, activations staged in LDS per chunk) -> 36.1 (both operands
+// as one dword per k-quad from memory) -> this form.
 template <int NB>
 __global__ __launch_bounds__(64) void dqn_fc1_narrow_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int C,
                                                              int n_actions, const float *act, float *hid)
 {
-    constexpr int U = DQ_FC1_U, NCHUNK = 784 / U;
-    static_assert(NCHUNK % NB == 0, "whole rounds of the ring");
+    constexpr int U = DQ_FC1_U;
     const int ti = blockIdx.x;
     const coevo_dqn_task task = tasks[ti];
     const float *net = slab + task.net_off;
@@ -568,30 +683,49 @@ __global__ __launch_bounds__(64) void dqn_fc1_narrow_kernel(const float *slab, c
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = bb;
     }
-    // both operands straight from memory, one dword per lane and k-quad each, NB x U k-quads ahead of the chain (the
-    // activations are L2 hits; rows past the task's last repeat it - their sums are never stored): no LDS staging, no
-    // barrier between the 784 dependent matrix instructions
-    const float *wp = net + L.wf + ((size_t)ob * 784 * 64 + col) * 4 + kk;
-    const float *xp = act + (size_t)(task.row_begin + min(c, nrows - 1)) * DQ_FC1_IN + kk;
-    float wv[NB][U], xv[NB][U];
-    auto issue = [&](float (&w)[U], float (&x)[U], int kq) {
+    // Both operands straight from memory (the activations are L2 hits; rows past the task's last repeat it - their sums
+    // are never stored): no LDS staging, no barrier between the 784 dependent matrix instructions.  A lane requests FOUR
+    // k-quads at a time - lane (c, g) the 16-byte pieces W[col c][4 (4 Q + g) ..+3] and x[row c][..] - and a 4x4 (register x
+    // 16-lane row) transpose (two v_permlane32_swap + two v_permlane16_swap each) turns them into the operands of k-quads
+    // 4 Q .. 4 Q + 3.  (One dword per lane and k-quad: 1568 loads per wave, and a wave's 63 countable outstanding loads
+    // covered 31 k-quads = 0.5 us of chain: 33 us per launch instead of the chain's 13.)
+    typedef unsigned u32x2_s __attribute__((ext_vector_type(2)));
+    constexpr int NSQ = 784 / 4, NCH = NSQ / U;   // super-quads (four k-quads), chunks of U of them
+    static_assert(NSQ % U == 0 && NCH % NB == 0, "whole rounds of the ring");
+    const float4 *wp = reinterpret_cast<const float4 *>(net + L.wf) + (size_t)ob * 784 * 64 + col + (size_t)kk * 64;
+    const float4 *xp = reinterpret_cast<const float4 *>(act + (size_t)(task.row_begin + min(c, nrows - 1)) * DQ_FC1_IN) + kk;
+    float4 wv[NB][U], xv[NB][U];
+    auto issue = [&](float4 (&w)[U], float4 (&x)[U], int sq) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            w[u] = wp[(size_t)(kq + u) * 256];   // (plain loads: the net is read by every step)
-            x[u] = xp[4 * (kq + u)];
+            w[u] = wp[(size_t)(sq + u) * 256];   // piece (k-quad 4 (sq + u) + kk, column col); plain loads: read every step
+            x[u] = xp[4 * (sq + u)];
         }
+    };
+    auto transpose4 = [](const float4 &v, float (&o)[4]) {
+        const u32x2_s s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v.x), __float_as_uint(v.z), false, false);
+        const u32x2_s s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v.y), __float_as_uint(v.w), false, false);
+        const u32x2_s y01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+        const u32x2_s y23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+        o[0] = __uint_as_float(y01[0]); o[1] = __uint_as_float(y01[1]); o[2] = __uint_as_float(y23[0]); o[3] = __uint_as_float(y23[1]);
     };
 #pragma unroll
     for (int b = 0; b < NB - 1; ++b) issue(wv[b], xv[b], b * U);
 #pragma nounroll
-    for (int c0 = 0; c0 < NCHUNK; c0 += NB) {
+    for (int c0 = 0; c0 < NCH; c0 += NB) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const int nxt = min(c0 + b + NB - 1, NCHUNK - 1);   // (clamped, unconditional: straight-line code)
+            const int nxt = min(c0 + b + NB - 1, NCH - 1);   // (clamped, unconditional: straight-line code)
             issue(wv[(b + NB - 1) % NB], xv[(b + NB - 1) % NB], nxt * U);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[b][u], wv[b][u], acc, 0, 0, 0);
+            for (int u = 0; u < U; ++u) {
+                float bq[4], aq[4];
+                transpose4(wv[b][u], bq);
+                transpose4(xv[b][u], aq);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[j], bq[j], acc, 0, 0, 0);
+            }
         }
     }
 #pragma unroll
@@ -631,9 +765,16 @@ extern "C" int64_t coevo_dqn_slab_stride(int C, int n_actions)
     return dqn_shape_ok(C, n_actions) ? dqn_layout(C, n_actions).stride : COEVO_ERR_ARG;
 }
 
+// conv3 activations + fc1 outputs of every row; a small launch also passes conv1's sums and conv2's activations through it
+static int64_t dqn_small_extra_floats(int n_rows_total)
+{
+    return n_rows_total <= DQ_SMALL_MAX_ROWS ? (int64_t)n_rows_total * (32 * 400 + 64 * DQ_P2) : 0;
+}
+
 extern "C" int64_t coevo_dqn_workspace_bytes(int n_rows_total)
 {
-    return n_rows_total > 0 ? (int64_t)n_rows_total * (DQ_FC1_IN + DQ_FC1_OUT) * 4 : COEVO_ERR_ARG;
+    return n_rows_total > 0 ? ((int64_t)n_rows_total * (DQ_FC1_IN + DQ_FC1_OUT) + dqn_small_extra_floats(n_rows_total)) * 4
+                            : COEVO_ERR_ARG;
 }
 
 extern "C" int coevo_dqn_pack(const float *flat, float *slab, int n, int C, int n_actions, void *stream)
@@ -668,7 +809,17 @@ static int dqn_forward_launch(const float *slab, const coevo_dqn_task *tasks, in
     if (timing_ctx && (timed_kernel < 0 || timed_kernel > 1)) return COEVO_ERR_ARG;
     if (timing_ctx && timed_kernel == 0 && coevo_timing_begin(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     const dim3 cg(8 * ((n_rows_total + 7) / 8)), cb(512);   // a multiple of 8: the kernel's XCD-aware row mapping
-    if (C == 4) hipLaunchKernelGGL((dqn_conv_kernel<4, 4>), cg, cb, 0, s, slab, tasks, n_tasks, n_rows_total, C, n_actions, frames, act);
+    if (n_rows_total <= DQ_SMALL_MAX_ROWS) {   // three launches that spread each frame over the chip
+        float *a1raw = hid + (size_t)n_rows_total * DQ_FC1_OUT, *a2g = a1raw + (size_t)n_rows_total * (32 * 400);
+        const dim3 g1(n_rows_total, 25), g2(n_rows_total, 2);
+        if (C == 4) hipLaunchKernelGGL((dqn_small_conv1_kernel<4, 4>), g1, dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, frames, a1raw);
+        else if (C < 4) hipLaunchKernelGGL((dqn_small_conv1_kernel<4, 0>), g1, dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, frames, a1raw);
+        else if (C == 6) hipLaunchKernelGGL((dqn_small_conv1_kernel<6, 6>), g1, dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, frames, a1raw);
+        else hipLaunchKernelGGL((dqn_small_conv1_kernel<6, 0>), g1, dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, frames, a1raw);
+        hipLaunchKernelGGL(dqn_small_conv2_kernel, g2, cb, 0, s, slab, tasks, n_tasks, C, n_actions, a1raw, a2g);
+        hipLaunchKernelGGL(dqn_small_conv3_kernel, g2, cb, 0, s, slab, tasks, n_tasks, C, n_actions, a2g, act);
+    }
+    else if (C == 4) hipLaunchKernelGGL((dqn_conv_kernel<4, 4>), cg, cb, 0, s, slab, tasks, n_tasks, n_rows_total, C, n_actions, frames, act);
     else if (C < 4) hipLaunchKernelGGL((dqn_conv_kernel<4, 0>), cg, cb, 0, s, slab, tasks, n_tasks, n_rows_total, C, n_actions, frames, act);
     else if (C == 6) hipLaunchKernelGGL((dqn_conv_kernel<6, 6>), cg, cb, 0, s, slab, tasks, n_tasks, n_rows_total, C, n_actions, frames, act);
     else hipLaunchKernelGGL((dqn_conv_kernel<6, 0>), cg, cb, 0, s, slab, tasks, n_tasks, n_rows_total, C, n_actions, frames, act);
