@@ -7,6 +7,7 @@
 # with a trace domain other than --kernel-trace) for the headline.
 set -o pipefail
 TAG=${1:-r03}
+PART=${2:-all}   # all | stats | pmc (a gpurun call is limited to 20 minutes: the two halves fit one call each)
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -20,6 +21,7 @@ run() {  # name, bench args...
     grep -h '^{' $OUT/$name.log | tail -1 > $OUT/$name.bench.json
     echo "done $name"
 }
+if [ "$PART" != "pmc" ]; then
 run headline --steps 20 --warmup 3
 run cfg2_T200 --steps 10 --warmup 3 --max-cycles 67
 run cfg3_es --workload es --steps 10 --warmup 3
@@ -29,6 +31,7 @@ run cfg5_dqn_es --workload dqn-es --steps 2 --warmup 1
 run cfg4_dqn_ga_c6 --workload dqn-ga --channels 6 --steps 2 --warmup 1
 run cfg5_dqn_es_c6 --workload dqn-es --channels 6 --steps 2 --warmup 1
 run cfg2_host_env --env host --steps 3 --warmup 1
+fi
 pmc() {  # workload name, bench args...: one pass per counter (never combined with a trace domain other than --kernel-trace)
     local name=$1; shift
     for ctr in FETCH_SIZE WRITE_SIZE; do
@@ -38,9 +41,11 @@ pmc() {  # workload name, bench args...: one pass per counter (never combined wi
         echo "done pmc $name $ctr"
     done
 }
+if [ "$PART" != "stats" ]; then
 pmc headline --steps 5 --warmup 2
 pmc cfg3_es --workload es --steps 3 --warmup 1
 pmc cfg4_dqn_ga --workload dqn-ga --steps 1 --warmup 1
 pmc cfg5_dqn_es --workload dqn-es --steps 1 --warmup 1
 pmc cfg4_dqn_ga_c6 --workload dqn-ga --channels 6 --steps 1 --warmup 1
 pmc cfg5_dqn_es_c6 --workload dqn-es --channels 6 --steps 1 --warmup 1
+fi
