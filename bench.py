@@ -225,7 +225,7 @@ def run_es(a, ctx, dev, pop_per_gpu=None, extension=None):
     P4 = {10: 559124, 8: 555028}
     gb = pop * (1 + cyc) * (2 * P4[10] + P4[8])   # materialise-once model of SURVEY 8d: write n*4P, read C*n*4P
     # the dominant launch of a Co-ES generation: one env-cycle of one cohort, every individual's weight set streamed once
-    es_traffic, es_src = pmc_traffic("cfg3_es_ext" if ext else "cfg3_es", "fc_cycle_kernel")
+    es_traffic, es_src = pmc_traffic("cfg3_es", "fc_cycle_kernel")   # (both modes launch the same kernel on the same bytes)
     return {"metric": "env-steps/sec (agent-steps of the whole job; generations/sec in gens_per_sec), Co-ES "
                       "simple_adversary_v3 pop=1000/GPU",
             "value": gens * eng.steps_per_generation, "unit": "env-steps/s", "gens_per_sec": gens,
