@@ -32,6 +32,17 @@ def allgather_shards(local: torch.Tensor, world: int) -> torch.Tensor:
     return out.to(dev).reshape(world, R, n_local, Cc).permute(1, 0, 2, 3).reshape(R, world * n_local, Cc)
 
 
+def choose_backend(requested, env, cuda_available, device_count):
+    """-> (backend, ranks_share_a_device).  RCCL needs one device per rank ("Duplicate GPU detected" otherwise): with more
+    local ranks than GPUs (a rehearsal on a one-GPU box) the ranks share the device and the gathers go through gloo.
+    Only a KNOWN local world size can say so: launchers that do not export LOCAL_WORLD_SIZE (srun, mpirun) may spread
+    WORLD_SIZE over several nodes, where comparing it with this node's device count would send every gather through
+    the host - they get nccl."""
+    lws = env.get("LOCAL_WORLD_SIZE")
+    shared = lws is not None and cuda_available and int(lws) > device_count
+    return requested or env.get("COEVO_DIST_BACKEND") or ("gloo" if shared else "nccl"), shared
+
+
 class DistContext:
     def __init__(self, backend=None):
         self.rank = int(os.environ.get("RANK", "0"))
@@ -40,14 +51,8 @@ class DistContext:
         if self.world > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            # RCCL needs one device per rank ("Duplicate GPU detected" otherwise): with more local ranks than GPUs (a
-            # rehearsal on a one-GPU box) the ranks share the device and the gathers go through gloo
-            # (only a KNOWN local world size can say so: launchers that do not export LOCAL_WORLD_SIZE - srun, mpirun -
-            # may spread WORLD_SIZE over several nodes, where comparing it with this node's device count would send every
-            # gather through the host)
-            lws = os.environ.get("LOCAL_WORLD_SIZE")
-            shared_device = lws is not None and torch.cuda.is_available() and int(lws) > torch.cuda.device_count()
-            backend = backend or os.environ.get("COEVO_DIST_BACKEND") or ("gloo" if shared_device else "nccl")
+            backend, shared_device = choose_backend(backend, os.environ, torch.cuda.is_available(),
+                                                    torch.cuda.device_count())
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank % max(torch.cuda.device_count(), 1))
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)

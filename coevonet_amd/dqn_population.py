@@ -522,6 +522,13 @@ def dqn_genetic_algorithm_train(env, agent, args, output_dir, collect=True, dist
 
 
 # ---------------------------------------------------------------------------------------------------- Co-ES
+def es_cohort_bounds(n_local, K):
+    """game bounds of K rollout cohorts (None = one cohort): games are individual-major, two per individual; cohort k =
+    individuals [k n / K, (k + 1) n / K)"""
+    K = max(1, min(int(K), n_local))
+    return [2 * (k * n_local // K) for k in range(K)] + [2 * n_local] if K > 1 else None
+
+
 class DQNESEngine(_SlabMixin):
     def __init__(self, pop, C, n_actions, T_train, T_eval, device="cuda", env_seed=SYNTH_SEED, philox_seed=0,
                  shard=(0, 1), gather=None, first_ordinal=1, antithetic=False, centered_rank=False, chunks=8):
@@ -559,9 +566,7 @@ class DQNESEngine(_SlabMixin):
         # two cohorts by default: one-frame tasks make this rollout fc1-bound (6.4 MB of weights per frame), and one
         # cohort's conv launch (matrix pipe) then runs under the other's fc1 stream (HBM): cfg 5 shard 9.5 vs 9.1
         # generations/s.  (Co-GA's 10-frame tasks are conv-bound: one cohort is faster there, 16.4 vs 15.6.)
-        K = max(1, min(int(os.environ.get("COEVO_DQN_COHORTS", "2")), self.n_local))
-        # games are individual-major (two per individual): cohort k = individuals [k n / K, (k + 1) n / K)
-        bounds = [2 * (k * self.n_local // K) for k in range(K)] + [self.n_main] if K > 1 else None
+        bounds = es_cohort_bounds(self.n_local, int(os.environ.get("COEVO_DQN_COHORTS", "2")))
         self.ro = SynthRollout(games, net_off, ordinal0, C, n_actions, self.slab, env_seed, self.per_gen, device,
                                bounds=bounds)
         self.ro.set_limits(np.full(self.n_main, self.T_train, dtype=np.int32))

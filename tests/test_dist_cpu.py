@@ -86,3 +86,25 @@ def test_es_engine_rejects_unaligned_shards():
         ESEngine(pop=12, shard=(0, 3), device="cpu")     # 8 chunks over 3 ranks
     with pytest.raises(ValueError, match="even"):
         ESEngine(pop=9, antithetic=True, device="cpu")
+
+
+def test_backend_choice():
+    """gloo only for a KNOWN local world larger than the device count (several ranks rehearsing on one GPU); a launcher
+    that exports no LOCAL_WORLD_SIZE (srun, mpirun over several nodes) gets RCCL; explicit requests win"""
+    from coevonet_amd.dist import choose_backend
+    assert choose_backend(None, {"LOCAL_WORLD_SIZE": "2"}, True, 1) == ("gloo", True)
+    assert choose_backend(None, {"LOCAL_WORLD_SIZE": "8"}, True, 8) == ("nccl", False)
+    assert choose_backend(None, {}, True, 8) == ("nccl", False)              # 16 ranks over 2 x 8 GPUs under srun
+    assert choose_backend(None, {"COEVO_DIST_BACKEND": "gloo"}, True, 8) == ("gloo", False)
+    assert choose_backend("nccl", {"LOCAL_WORLD_SIZE": "2", "COEVO_DIST_BACKEND": "gloo"}, True, 1)[0] == "nccl"
+
+
+def test_es_cohort_bounds_cover_every_game():
+    """DQNESEngine's cohort cut (individual-major games, two per individual) for any cohort count"""
+    from coevonet_amd.dqn_population import es_cohort_bounds
+    assert es_cohort_bounds(250, 1) is None and es_cohort_bounds(1, 2) is None
+    assert es_cohort_bounds(250, 2) == [0, 250, 500]
+    for n_local, K in [(250, 3), (5, 4), (7, 7), (3, 9)]:
+        b = es_cohort_bounds(n_local, K)
+        assert b[0] == 0 and b[-1] == 2 * n_local and len(b) == min(K, n_local) + 1
+        assert all(b1 > b0 and b1 % 2 == 0 for b0, b1 in zip(b, b[1:]))
