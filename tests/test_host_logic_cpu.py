@@ -243,3 +243,21 @@ def test_job_struct_layouts_match_the_header():
     assert (C.sizeof(L.PerturbJob), C.sizeof(L.FinalizeJob), C.sizeof(L.ResetSeg)) == (72, 40, 16)
     assert L.PerturbJob.child_first.offset == 48 and L.FinalizeJob.n_blocks.offset == 24
     assert L.ResetSeg.first_ordinal.offset == 8
+
+
+def test_bench_reads_tracked_pmc_traffic():
+    """bench.py's roofline.traffic comes from the tracked PMC summary (profiles/r03_pmc_hbm_traffic.json): the lookup keys it
+    uses must exist there, with HBM bytes per launch close to the algorithmic bytes of the kernels it names"""
+    import importlib
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    head, src = bench.pmc_traffic("headline", "fc_cycle16_kernel<5>")
+    assert head and 1.0 <= head / 171709450.0 < 1.25 and "r03_pmc_hbm_traffic.json" in src
+    for wl, kern, lo, hi in (("cfg3_es", "fc_cycle_kernel", 8.0e8, 9.0e8), ("cfg4_dqn_ga", "dqn_fc1_kernel", 4.0e8, 5.0e8),
+                             ("cfg4_dqn_ga", "dqn_conv_kernel", 5.5e7, 7.0e7), ("cfg5_dqn_es", "dqn_fc1_kernel", 8.0e8, 8.5e8),
+                             ("cfg4_dqn_ga_c6", "dqn_conv_kernel", 7.0e7, 9.0e7)):
+        b, _ = bench.pmc_traffic(wl, kern)
+        assert b and lo <= b <= hi, (wl, kern, b)
+    assert bench.pmc_traffic("no_such_workload", "x") == (None, None)
