@@ -19,6 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="cfg4")
 ap.add_argument("--C", type=int, default=4)
 ap.add_argument("--reps", type=int, default=40)
+ap.add_argument("--interleave", action="store_true", help="cfg4: HoF nets spread among the population nets in the task table")
 ap.add_argument("--task-rows", type=int, default=L.DQN_MAX_ROWS, help="rows per task of a net that acts in many games")
 a = ap.parse_args()
 dev = "cuda"
@@ -31,9 +32,15 @@ def _cut(rows):
 
 if a.shape == "cfg4":      # pop 50 x 10 HoF games, 10 HoF nets x 50 games (+ 10 evaluation games for the newest)
     n_act = 6
-    layout = [(i, 10) for i in range(50)]
-    for j in range(10):
-        layout += [(50 + j, r) for r in (_cut(60) if j == 0 else _cut(50))]
+    if a.interleave:   # five pop nets, one HoF net, ...: every contiguous eighth of the table (= one XCD's share in the
+        layout = []    # fc1 launch) then holds about the same number of distinct nets
+        for j in range(10):
+            layout += [(5 * j + i, 10) for i in range(5)]
+            layout += [(50 + j, r) for r in (_cut(60) if j == 0 else _cut(50))]
+    else:
+        layout = [(i, 10) for i in range(50)]
+        for j in range(10):
+            layout += [(50 + j, r) for r in (_cut(60) if j == 0 else _cut(50))]
     n_nets = 60
 elif a.shape == "eval":    # the evaluation games of a Co-ES generation: one base net x 10 games
     n_act = 18

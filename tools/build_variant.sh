@@ -1,6 +1,7 @@
 #!/bin/bash
 # tools/build_variant.sh NAME SOURCE.hip FLAGS...: variants/libcoevo_NAME.so = the current objects with SOURCE rebuilt under FLAGS
-# (A/B experiments: COEVO_LIB=variants/libcoevo_NAME.so python tools/...)
+# (A/B experiments: COEVO_ALLOW_VARIANT=1 COEVO_LIB=variants/libcoevo_NAME.so python tools/... - coevonet_amd.lib.load() refuses a
+# library whose coevo_build_flags() is not empty unless COEVO_ALLOW_VARIANT=1; the flags given here are what it reports)
 set -e
 cd "$(dirname "$0")/.."
 name=$1; src=$2; shift 2
