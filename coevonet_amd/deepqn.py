@@ -21,6 +21,16 @@ PARAM_ORDER = ["conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "conv
                "vbn3.weight", "vbn3.bias"]
 
 
+LAYER_ORDER = ["conv1", "conv2", "conv3", "fc1", "output", "vbn1", "vbn2", "vbn3"]
+
+
+class _Layer:
+    """a layer as the reference's accessors see it: .weight / .bias tensors (views of the owner's flat parameter vector)"""
+
+    def __init__(self, name, weight, bias):
+        self.name, self.weight, self.bias = name, weight, bias
+
+
 class DeepQN:
     def __init__(self, input_channels, n_actions, precision):
         if precision != "float32":
@@ -54,12 +64,40 @@ class DeepQN:
         for name in ("vbn1", "vbn2", "vbn3"):
             self._params[name + ".weight"].fill_(1.0)
             self._params[name + ".bias"].zero_()
+        # layer views in the reference's `self.layers` order (Atari/deepqn.py:14-37): objects with .weight / .bias tensors
+        # that alias the flat vector, what get_weights_ES / set_weights_ES walk
+        self.layers = []
+        for name in LAYER_ORDER:
+            layer = _Layer(name, self._params[name + ".weight"], self._params[name + ".bias"])
+            setattr(self, name, layer)
+            self.layers.append(layer)
+        # BatchNorm buffers: part of the reference's state_dict (training-mode BatchNorm at batch 1 never reads them, and
+        # the HIP forward does not maintain them): carried so that state_dicts exchange with strict=True
+        self._buffers = OrderedDict()
+        for name, c in (("vbn1", 32), ("vbn2", 64), ("vbn3", 64)):
+            self._buffers[name + ".running_mean"] = torch.zeros(c)
+            self._buffers[name + ".running_var"] = torch.ones(c)
+            self._buffers[name + ".num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
 
     def parameters(self):
         return iter(self._params.values())
 
+    def named_modules(self):
+        """('', self) then the layers in registration order, as torch.nn.Module.named_modules yields them"""
+        yield "", self
+        for layer in self.layers:
+            yield layer.name, layer
+
     def state_dict(self):
-        return OrderedDict((k, v.detach()) for k, v in self._params.items())
+        """keys and order of the reference's state_dict: per layer its parameters, BatchNorm layers followed by their buffers"""
+        sd = OrderedDict()
+        for layer in self.layers:
+            sd[layer.name + ".weight"] = self._params[layer.name + ".weight"].detach()
+            sd[layer.name + ".bias"] = self._params[layer.name + ".bias"].detach()
+            for suffix in ("running_mean", "running_var", "num_batches_tracked"):
+                if layer.name + "." + suffix in self._buffers:
+                    sd[layer.name + "." + suffix] = self._buffers[layer.name + "." + suffix]
+        return sd
 
     def load_state_dict(self, sd, strict=True):
         for k, v in self._params.items():
@@ -67,6 +105,58 @@ class DeepQN:
                 v.copy_(torch.as_tensor(sd[k], dtype=torch.float32))
             elif strict:
                 raise KeyError(f"Missing key in state_dict: {k}")
+        for k, v in self._buffers.items():
+            if k in sd:
+                v.copy_(torch.as_tensor(sd[k], dtype=v.dtype))
+
+    # ---- the weight accessors of Atari/deepqn.py:63-231 (same names, argument meaning and errors) -----------------------
+    def get_weights(self, layers=None):
+        """dict of cloned state_dict entries; `layers`: name prefixes (:63-87)"""
+        sd = self.state_dict()
+        if layers is None:
+            return {k: v.clone() for k, v in sd.items()}
+        return {k: v.clone() for k, v in sd.items() if any(k.startswith(layer) for layer in layers)}
+
+    def set_weights(self, new_weights, layers=None):
+        """(:90-123) with `layers` only the keys of new_weights are touched; every touched key must be present and of the
+        right shape"""
+        cur = self.state_dict()
+        keys = list(new_weights.keys()) if layers is not None else list(cur.keys())
+        for k in keys:
+            if k not in new_weights:
+                raise ValueError(f"Missing key in new_weights: {k}")
+            if tuple(new_weights[k].shape) != tuple(cur[k].shape):
+                raise ValueError(f"Shape mismatch for key '{k}': expected {cur[k].shape}, got {new_weights[k].shape}")
+        self.load_state_dict({k: new_weights[k] for k in keys}, strict=False)
+
+    def get_perturbable_layers(self):
+        """every layer that is not a BatchNorm2d, in registration order (:158-171)"""
+        return [layer for layer in self.layers if not layer.name.startswith("vbn")]
+
+    def get_weights_ES(self, layers=None):
+        """weights then biases of each layer, flattened and concatenated (:130-155); default: all eight layers = the
+        canonical flat order of include/coevo.h"""
+        layers = layers if layers else self.layers
+        return np.concatenate([t.detach().numpy().ravel() for layer in layers for t in (layer.weight, layer.bias)])
+
+    def get_perturbable_weights(self):
+        return self.get_weights_ES(self.get_perturbable_layers())
+
+    def set_weights_ES(self, flat_weights, args, layers=None):
+        """(:174-215) default: the perturbable layers"""
+        if getattr(args, "precision", "float32") == "float16":
+            raise ValueError("Unsupported precision: float16")
+        layers = self.get_perturbable_layers() if layers is None else layers
+        flat_weights = np.asarray(flat_weights)
+        i = 0
+        for layer in layers:
+            for t in (layer.weight, layer.bias):
+                n = t.numel()
+                t.data.copy_(torch.tensor(flat_weights[i:i + n].reshape(tuple(t.shape)), dtype=torch.float32))
+                i += n
+
+    def set_perturbable_weights(self, weights_to_set, args):
+        self.set_weights_ES(weights_to_set, args, self.get_perturbable_layers())
 
     def flat(self):
         return self._flat.numpy()

@@ -7,6 +7,7 @@ never copied) against this repo's AEC env.  Run in the build container only:
 What is recorded (data only - inputs and expected outputs):
   fc_forward.json   FCNetwork.forward / determine_action on seeded nets + observations
   deepqn_forward.json  DeepQN.forward on seeded nets + synthetic frames (logits only)
+  deepqn_weights.json  DeepQN's weight accessors (flat orders, perturbable subset, partial sets, state_dict keys)
   play_game.json    play_game() reward triples, action sequences, min top-2 logit margins
   ga_*.json         genetic_algorithm_train: per-game rewards, diversity, fitness, elite ids,
                     HoF / elite weight checksums, eval rewards, adaptive sigma trajectory
@@ -186,6 +187,40 @@ def mint_deepqn_forward():
                       "logits": logits, "mutate_std": 0.02,
                       "weights_sha256": hashlib.sha256(w.tobytes()).hexdigest()})
     dump("deepqn_forward.json", {"cases": cases})
+
+
+def mint_deepqn_weights():
+    """the weight accessors of Atari/deepqn.py:63-231 (what the ES branch and --save go through): flat orders, the
+    perturbable subset (no BatchNorm), partial sets, the state_dict key set"""
+    def h(a):
+        return hashlib.sha256(np.ascontiguousarray(a, dtype=np.float32).tobytes()).hexdigest()
+    cases = []
+    for seed, C, n in [(0, 4, 6), (1, 6, 18)]:
+        torch.manual_seed(seed)
+        net = DeepQN(C, n, "float32")
+        for p in net.parameters():
+            p.data += torch.normal(0, 0.02, size=p.size())
+        a = Bag(precision="float32")
+        case = {"torch_seed": seed, "C": C, "n_actions": n, "mutate_std": 0.02,
+                "state_dict_keys": list(net.state_dict().keys()),
+                "perturbable_layers": [nm for nm, m in net.named_modules() if m in net.get_perturbable_layers()],
+                "all_len": int(net.get_weights_ES().size), "all_sha256": h(net.get_weights_ES()),
+                "perturbable_len": int(net.get_perturbable_weights().size),
+                "perturbable_sha256": h(net.get_perturbable_weights()),
+                "fc1_vbn2_sha256": h(net.get_weights_ES([net.fc1, net.vbn2])),
+                "get_weights_fc1_vbn1_keys": list(net.get_weights(["fc1", "vbn1"]).keys())}
+        v = (net.get_perturbable_weights() * np.float32(0.5) + np.float32(0.01)).astype(np.float32)
+        net.set_perturbable_weights(v, a)
+        case["after_set_perturbable_sha256"] = h(net.get_weights_ES())
+        k = int(net.fc1.weight.numel() + net.fc1.bias.numel() + 2 * 64)
+        u = (np.arange(k, dtype=np.float32) % np.float32(97.0)) * np.float32(1e-3)
+        net.set_weights_ES(u, a, [net.fc1, net.vbn2])
+        case["after_set_fc1_vbn2_sha256"] = h(net.get_weights_ES())
+        new = {key: val * 2 for key, val in net.get_weights(["output"]).items()}
+        net.set_weights(new, layers=["output"])
+        case["after_set_weights_output_sha256"] = h(net.get_weights_ES())
+        cases.append(case)
+    dump("deepqn_weights.json", {"cases": cases})
 
 
 # ------------------------------------------------------------------ play_game ----
@@ -395,6 +430,8 @@ if __name__ == "__main__":
         mint_fc_forward()
     if not which or "dqn" in which:
         mint_deepqn_forward()
+    if not which or "dqnw" in which:
+        mint_deepqn_weights()
     if not which or "play" in which:
         mint_play_game()
     if not which or "ga" in which:

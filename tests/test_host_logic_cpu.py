@@ -261,3 +261,41 @@ def test_bench_reads_tracked_pmc_traffic():
         b, _ = bench.pmc_traffic(wl, kern)
         assert b and lo <= b <= hi, (wl, kern, b)
     assert bench.pmc_traffic("no_such_workload", "x") == (None, None)
+
+
+def test_deepqn_weight_accessors_match_reference_fixture():
+    """the DeepQN mirror's get_weights / set_weights / get_weights_ES / set_weights_ES / get_perturbable_* against values
+    minted from the reference's class (tests/golden/make_golden.py dqnw; Atari/deepqn.py:63-231).  No GPU call: only the
+    parameter-count query of the C library."""
+    import hashlib
+    from coevonet_amd import deepqn as dq
+    from tests.util import Bag, load_golden
+
+    def h(a):
+        return hashlib.sha256(np.ascontiguousarray(a, dtype=np.float32).tobytes()).hexdigest()
+    for case in load_golden("deepqn_weights.json")["cases"]:
+        torch.manual_seed(case["torch_seed"])
+        net = dq.DeepQN(case["C"], case["n_actions"], "float32")
+        for p in net.parameters():
+            p.data += torch.normal(0, case["mutate_std"], size=p.size())
+        a = Bag(precision="float32")
+        assert list(net.state_dict().keys()) == case["state_dict_keys"]
+        assert [nm for nm, m in net.named_modules() if m in net.get_perturbable_layers()] == case["perturbable_layers"]
+        assert net.get_weights_ES().size == case["all_len"] and h(net.get_weights_ES()) == case["all_sha256"]
+        assert np.array_equal(net.get_weights_ES(), net.flat())            # = the canonical flat order of the C ABI
+        assert net.get_perturbable_weights().size == case["perturbable_len"]
+        assert h(net.get_perturbable_weights()) == case["perturbable_sha256"]
+        assert h(net.get_weights_ES([net.fc1, net.vbn2])) == case["fc1_vbn2_sha256"]
+        assert list(net.get_weights(["fc1", "vbn1"]).keys()) == case["get_weights_fc1_vbn1_keys"]
+        v = (net.get_perturbable_weights() * np.float32(0.5) + np.float32(0.01)).astype(np.float32)
+        net.set_perturbable_weights(v, a)
+        assert h(net.get_weights_ES()) == case["after_set_perturbable_sha256"]
+        k = int(net.fc1.weight.numel() + net.fc1.bias.numel() + 2 * 64)
+        net.set_weights_ES((np.arange(k, dtype=np.float32) % np.float32(97.0)) * np.float32(1e-3), a, [net.fc1, net.vbn2])
+        assert h(net.get_weights_ES()) == case["after_set_fc1_vbn2_sha256"]
+        net.set_weights({key: val * 2 for key, val in net.get_weights(["output"]).items()}, layers=["output"])
+        assert h(net.get_weights_ES()) == case["after_set_weights_output_sha256"]
+        with pytest.raises(ValueError):
+            net.set_weights({"fc1.weight": torch.zeros(3)}, layers=["fc1"])
+        with pytest.raises(ValueError):
+            net.set_weights({}, layers=None)
