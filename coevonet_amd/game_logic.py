@@ -148,22 +148,34 @@ def _play_atari_device(env, player1, player2, args, eval):
     return float(r[0]), float(r[1])
 
 
+def play_MPE(env, player1, player2, adversary, args, eval):
+    """utils/game_logic_functions.py:123-212 - one episode on an ALREADY RESET env (play_game resets): the whole episode
+    on the device when env and policies are this package's, else the AEC loop with one device forward per agent-step"""
+    from .fcnetwork import FCNetwork
+    ours = isinstance(env, SimpleAdversaryAEC) and env.seed_value is not None and \
+        all(isinstance(m, FCNetwork) for m in (player1, player2, adversary))
+    if ours:
+        return _play_mpe_device(env, player1, player2, adversary, args, eval)
+    return _play_mpe_aec(env, player1, player2, adversary, args, eval)
+
+
+def play_atari(env, player1, player2, args, eval=False):
+    """utils/game_logic_functions.py:84-119 (its own signature has no eval flag - quirk Q10; the call site at :227 passes
+    one, so it is accepted here and selects the step limit as for MPE)"""
+    from .deepqn import DeepQN
+    if isinstance(env, SyntheticAtariAEC) and isinstance(player1, DeepQN) and isinstance(player2, DeepQN) \
+            and not getattr(args, "coevo_host_aec", False):
+        return _play_atari_device(env, player1, player2, args, eval)
+    return _play_atari_aec(env, player1, player2, args, eval)
+
+
 def play_game(env, player1, player2, adversary=None, args=None, eval=False):
     """utils/game_logic_functions.py:215-228"""
     env.reset()
     if args.game == "simple_adversary_v3":
         if adversary is None:
             raise ValueError("adversary not specified")
-        from .fcnetwork import FCNetwork
-        ours = isinstance(env, SimpleAdversaryAEC) and env.seed_value is not None and \
-            all(isinstance(m, FCNetwork) for m in (player1, player2, adversary))
-        if ours:
-            return _play_mpe_device(env, player1, player2, adversary, args, eval)
-        return _play_mpe_aec(env, player1, player2, adversary, args, eval)
+        return play_MPE(env, player1, player2, adversary, args, eval)
     if args.game in ATARI_GAMES:
-        from .deepqn import DeepQN
-        if isinstance(env, SyntheticAtariAEC) and isinstance(player1, DeepQN) and isinstance(player2, DeepQN) \
-                and not getattr(args, "coevo_host_aec", False):
-            return _play_atari_device(env, player1, player2, args, eval)
-        return _play_atari_aec(env, player1, player2, args, eval)
+        return play_atari(env, player1, player2, args, eval)
     raise ValueError(f"Unsupported game type: {args.game}")
