@@ -32,6 +32,43 @@ def load_agents(file_path):
     return torch.load(file_path, weights_only=False)
 
 
+_TEST_ARGS = {   # the attributes main.py --test names the checkpoints with (main.py:60-75), per algorithm and role
+    "GA": (("GA_hof_to_test_agent_0", "agent_0"), ("GA_hof_to_test_agent_1", "agent_1"),
+           ("GA_hof_to_test_adversary", "adversary_0")),
+    "ES": (("ES_model_to_test_agent_0", "agent_0"), ("ES_model_to_test_agent_1", "agent_1"),
+           ("ES_model_to_test_adversary_0", "adversary_0")),
+}
+
+
+def load_agent_for_testing(args, env=None):
+    """utils/utils_pth_and_plots.py:8-74: the three agents `main.py --test` plays (main.py:204-243).  GA checkpoints are
+    Hall-of-Fame lists (the newest member is taken), ES checkpoints single agents.  Same ValueErrors: a path that is not
+    given, then a path that does not exist, checked for all three roles before anything is loaded."""
+    if args.algorithm not in _TEST_ARGS:
+        return None
+    spec = _TEST_ARGS[args.algorithm]
+    for attr, role in spec:
+        if getattr(args, attr, None) is None:
+            raise ValueError(f"Error: Model file for {role} not specified. Please specify the agent to test")
+    for attr, _ in spec:
+        if not os.path.exists(getattr(args, attr)):
+            raise ValueError(f"Error: Model file {getattr(args, attr)} not found.")
+    loaded = [load_agents(getattr(args, attr)) for attr, _ in spec]
+    return tuple(x[-1] for x in loaded) if args.algorithm == "GA" else tuple(loaded)
+
+
+def create_output_dir(args):
+    """utils/utils_pth_and_plots.py:83-96: the run's directory name from its hyper-parameters"""
+    name = (f"{args.algorithm}_models/gens{args.generations}_pop{args.population}_hof{args.hof_size}_game{args.game}"
+            f"_tslimit{args.max_timesteps_per_episode}_fitness-sharing{args.fitness_sharing}_adaptive{args.adaptive}")
+    if args.adaptive:
+        name += f"max_mutation{args.max_mutation_power}_min_mutation{args.min_mutation_power}"
+    if args.algorithm == "ES":
+        name += f"_lr{args.learning_rate}"
+    os.makedirs(name, exist_ok=True)
+    return name
+
+
 STATE_DICT_SUFFIX = ".state_dict.pth"
 
 

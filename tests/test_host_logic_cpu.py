@@ -1,5 +1,6 @@
 """Host-side mirror of the reference interface (no GPU): parameter layout, RNG-order parity of construction and
 mutation with the reference's fixtures, plan building, sigma adaptation, loud failure without the HIP library."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -299,3 +300,32 @@ def test_deepqn_weight_accessors_match_reference_fixture():
             net.set_weights({"fc1.weight": torch.zeros(3)}, layers=["fc1"])
         with pytest.raises(ValueError):
             net.set_weights({}, layers=None)
+
+
+def test_load_agent_for_testing_contract(tmp_path, monkeypatch):
+    """main.py --test's loader (utils/utils_pth_and_plots.py:8-74): error order and what is returned"""
+    from coevonet_amd.io_utils import create_output_dir, load_agent_for_testing, save_model
+    args = Bag(algorithm="GA", GA_hof_to_test_agent_0=None, GA_hof_to_test_agent_1=None, GA_hof_to_test_adversary=None)
+    with pytest.raises(ValueError, match="agent_0 not specified"):
+        load_agent_for_testing(args)
+    files = {}
+    for k in ("a0", "a1", "adv"):
+        files[k] = str(tmp_path / f"{k}.pth")
+    args.GA_hof_to_test_agent_0, args.GA_hof_to_test_agent_1, args.GA_hof_to_test_adversary = files["a0"], files["a1"], files["adv"]
+    with pytest.raises(ValueError, match="a0.pth not found"):
+        load_agent_for_testing(args)
+    for k in files:
+        save_model([f"{k}-old", f"{k}-new"], files[k])          # a Hall of Fame: the newest member is tested
+    assert load_agent_for_testing(args) == ("a0-new", "a1-new", "adv-new")
+    es = Bag(algorithm="ES", ES_model_to_test_agent_0=files["a0"], ES_model_to_test_agent_1=files["a1"],
+             ES_model_to_test_adversary_0=None)
+    with pytest.raises(ValueError, match="adversary_0 not specified"):
+        load_agent_for_testing(es)
+    es.ES_model_to_test_adversary_0 = files["adv"]
+    assert load_agent_for_testing(es)[2] == ["adv-old", "adv-new"]
+    monkeypatch.chdir(tmp_path)
+    d = create_output_dir(Bag(algorithm="ES", generations=5, population=20, hof_size=3, max_timesteps_per_episode=400,
+                              fitness_sharing=True, adaptive=True, max_mutation_power=0.5, min_mutation_power=0.001,
+                              learning_rate=0.1))
+    assert d == ("ES_models/gens5_pop20_hof3_gamesimple_adversary_v3_tslimit400_fitness-sharingTrue_adaptiveTrue"
+                 "max_mutation0.5_min_mutation0.001_lr0.1") and os.path.isdir(d)
