@@ -38,6 +38,55 @@ from .mpe.simple_adversary import ENV_SEED
 from .rollout import DeviceRollout, HostEnvRollout, RolloutPlan, effective_steps
 
 
+# ---- the reference's per-call helpers under their own names (evolutionary_strategy.py:11-148): sequential, on the host
+# except for the games.  The trainer below does the same work batched on the device.
+def get_numpy_dtype(precision):
+    if precision == "float32":
+        return np.float32
+    raise ValueError(f"Unsupported precision: {precision}")   # (float16 is out of the parity scope)
+
+
+def evaluate_current_weights(agent_0, agent_1, adversary, env, args):
+    from .genetic_algorithm import evaluate_current_weights as ga_eval
+    return ga_eval(agent_0, agent_1, adversary, env, args)
+
+
+def mutate_weights(env, agent_0, agent_1, adversary, args, role, step, weights_logging_agent_0, weights_logging_agent_1,
+                   weights_logging_adversary):
+    """one ES individual of `role`: clone the role's base agent, perturb its Linear layers (Agent.mutate_ES), play ONE game
+    against the two other base nets -> (the role's slot of play_game's triple, noise, get_weights_ES() of the mutated net)
+    (evolutionary_strategy.py:63-116)"""
+    from .game_logic import play_game
+    base = {"agent_0": agent_0, "agent_1": agent_1, "adversary_0": adversary}
+    if role not in base:
+        return None
+    mutated = base[role].clone(env, args, role=role)
+    noise = mutated.mutate_ES(args, role=role, step=step, weights_logging_agent_0=weights_logging_agent_0,
+                              weights_logging_agent_1=weights_logging_agent_1,
+                              weights_logging_adversary=weights_logging_adversary).astype(get_numpy_dtype(args.precision))
+    trio = dict(base)
+    trio[role] = mutated
+    r = play_game(env=env, player1=trio["agent_0"].model, player2=trio["agent_1"].model,
+                  adversary=trio["adversary_0"].model, args=args)
+    return r[RET_SLOT[role]], noise, mutated.model.get_weights_ES()
+
+
+def compute_weight_update(noises, rewards, args, role, individual_weights=None, population_weights=None):
+    """(lr / (n sigma_role)) * noises^T fitness, fitness = rewards or rewards / (1 + diversity) -> (update, diversity)
+    (evolutionary_strategy.py:120-148: raw rewards, the reference's own normalisation is commented out there)"""
+    from .game_logic import diversity_penalty
+    dt = get_numpy_dtype(args.precision)
+    noises, rewards = np.array(noises, dtype=dt), np.array(rewards, dtype=dt)
+    diversity = None
+    fitness = rewards
+    if args.fitness_sharing:
+        diversity = diversity_penalty(individual_weights=individual_weights, population_weights=population_weights, args=args)
+        fitness = rewards / (1 + diversity)
+    sigma = getattr(args, SIGMA_ATTR[role])
+    update = (args.learning_rate / (len(noises) * sigma)) * np.dot(noises.T, fitness)
+    return update.astype(dt), diversity
+
+
 ES_CHUNKS = 8   # the canonical ES summation: this many chunk sums, added left to right (include/coevo.h, K5)
 
 

@@ -46,6 +46,32 @@ SIGMA_ATTR = {"agent_0": "mutation_power_agent_0", "agent_1": "mutation_power_ag
 N_EVAL = 10
 
 
+# ---- the reference's per-call helpers under their own names (genetic_algorithm.py:12-48): the sequential forms a caller of
+# the reference's module may use directly.  The trainers below do the same work batched on the device.
+def evaluate_current_weights(agent_0, agent_1, adversary, env, args):
+    """mean rewards of 10 evaluation games of one trio (genetic_algorithm.py:12-29, evolutionary_strategy.py:22-59)"""
+    from .game_logic import play_game
+    tot = [0.0, 0.0, 0.0]
+    for _ in range(N_EVAL):
+        r = play_game(env=env, player1=agent_0.model, player2=agent_1.model, adversary=adversary.model, args=args, eval=True)
+        for s in range(3):
+            tot[s] += r[s]
+    return tot[0] / 10, tot[1] / 10, tot[2] / 10
+
+
+def mutate_elites(env, elites, args, role):
+    """population - 1 children: child i = clone of elites[i % elites_number] with every parameter += N(0, sigma_role)
+    (genetic_algorithm.py:32-48; any role name other than agent_0 / agent_1 takes the adversary's sigma, as there)"""
+    sigma = {"agent_0": args.mutation_power_agent_0, "agent_1": args.mutation_power_agent_1}.get(
+        role, args.mutation_power_adversary)
+    children = []
+    for i in range(args.population - 1):
+        child = elites[i % args.elites_number].clone(env, args, role)
+        child.mutate(sigma)
+        children.append(child)
+    return children
+
+
 def adapt_mutation_power(args, gen, hist):
     """genetic_algorithm.py:323-345 (evolutionary_strategy.py:292-316 is identical), quirk Q5 included."""
     def worse(h):

@@ -118,3 +118,33 @@ def test_es_extension_mode_matches_oracle_port():
     np.random.seed(cfg["seed"])
     plain = rp.es_train(Bag(algorithm="ES", **oa), noise="philox", philox_seed=0)
     assert sha(plain[-1]["base"]["agent_0"]) != sha(want[-1]["base"]["agent_0"])
+
+
+def test_reference_step_functions_reproduce_generation0():
+    """the reference's per-call helpers under their own names (mutate_weights, evaluate_current_weights:
+    evolutionary_strategy.py:22-116) driven in the reference's loop order (:222-265) reproduce generation 0 of the fixture
+    the reference's own loop minted: every margin-safe game's reward in the role's slot"""
+    fx = load_golden("es_small.json")
+    cfg = fx["config"]
+    torch.manual_seed(cfg["seed"])
+    np.random.seed(cfg["seed"])
+    args = Bag(algorithm="ES", **cfg["args"])
+    env = initialize_env(args)
+    env.max_cycles = cfg.get("max_cycles", 25)
+    from coevonet_amd.game_logic import create_agent
+    from coevonet_amd.genetic_algorithm import RET_SLOT
+    a0, a1, adv = (create_agent(env, args, role=r) for r in ROLES)
+    logs = ([], [], [])
+    games = fx["generations"][0]["games"]
+    n_safe = 0
+    for j in range(args.population):
+        for ri, r in enumerate(ROLES):
+            rew, noise, w = es.mutate_weights(env, a0, a1, adv, args, r, j, *logs)
+            ref = games[3 * j + ri]
+            assert noise.dtype == np.float32 and w.ndim == 1 and len(noise) < len(w)   # (LayerNorm is not perturbed)
+            if ref["min_margin"] > SAFE_MARGIN:
+                assert rew == ref["rewards"][RET_SLOT[r]], (j, r)
+                n_safe += 1
+    assert n_safe >= 0.8 * 3 * args.population and len(logs[0]) == args.population
+    ev = es.evaluate_current_weights(a0, a1, adv, env, args)     # (the un-updated trio: ten more games of the reset stream)
+    assert len(ev) == 3 and all(np.isfinite(ev))
