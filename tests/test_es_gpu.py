@@ -141,7 +141,7 @@ def test_reference_step_functions_reproduce_generation0():
         for ri, r in enumerate(ROLES):
             rew, noise, w = es.mutate_weights(env, a0, a1, adv, args, r, j, *logs)
             ref = games[3 * j + ri]
-            assert noise.dtype == np.float32 and w.ndim == 1 and len(noise) < len(w)   # (LayerNorm is not perturbed)
+            assert noise.dtype == np.float32 and w.ndim == 1 and len(noise) == len(w)   # (both: the three Linear layers)
             if ref["min_margin"] > SAFE_MARGIN:
                 assert rew == ref["rewards"][RET_SLOT[r]], (j, r)
                 n_safe += 1
