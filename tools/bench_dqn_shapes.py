@@ -2,7 +2,7 @@
 """The DeepQN agent-step launches of the cfg 4 / cfg 5 shards (their exact task tables, random weights and frames) timed
 kernel by kernel with HIP events: conv stack, fc1, and the whole three-launch step.
 
-    [COEVO_LIB=variants/libcoevo_X.so] python tools/bench_dqn_shapes.py [--shape cfg4|cfg5|cfg5x2] [--C 4] [--reps 40]
+    [COEVO_LIB=variants/libcoevo_X.so] python tools/bench_dqn_shapes.py [--shape cfg4|cfg5|eval|pop:<nets>x<rows>] [--C 4] [--reps 40]
 """
 import argparse
 import os
@@ -42,6 +42,10 @@ if a.shape == "cfg4":      # pop 50 x 10 HoF games, 10 HoF nets x 50 games (+ 10
         for j in range(10):
             layout += [(50 + j, r) for r in (_cut(60) if j == 0 else _cut(50))]
     n_nets = 60
+elif a.shape.startswith("pop:"):   # pop:<nets>x<rows>: that many nets with that many frames each
+    n_act = 6
+    n_nets, r = (int(v) for v in a.shape[4:].split("x"))
+    layout = [(i, rr) for i in range(n_nets) for rr in _cut(r)]
 elif a.shape == "eval":    # the evaluation games of a Co-ES generation: one base net x 10 games
     n_act = 18
     layout = [(0, 10)]
