@@ -102,8 +102,8 @@ __device__ __forceinline__ float u8_over_255(unsigned b)
 // the matrix pipe at 46 %): within a chunk the tap of k-step j, lane group kk is
 //   conv1 (8 x 8 window, t = 4 q + kk):  ci = q0 / 16, ky = (q0 / 2) % 8 + j / 2, kx = kk + 4 (j % 2)
 //   conv2 (4 x 4):                        ci = q0 / 4 + j / 4, ky = j % 4, kx = kk
-// i.e. one per-lane chunk base + a compile-time offset per j (an instruction immediate); conv3's 3 x 3 window does not
-// decompose that way: its offsets come from a 16-bit table in LDS (1.1 KB).
+// i.e. one per-lane chunk base + a compile-time offset per j (an instruction immediate); conv3's 3 x 3 window repeats every
+// nine k-steps instead: nine per-lane addresses + an immediate (Conv16::run).
 template <int KS, int HIN, bool U8IN, int IN_PITCH, int CT>
 struct TapAddr {
     // offset of tap (chunk q0, step j, lane group kk) = chunk_base(q0, kk) + rel(j)
@@ -140,7 +140,7 @@ struct Conv16 {
     // starts inside the layer's input image (a kernel that stages only the rows its tile needs).
     template <int NU, bool XL>
     static __device__ __forceinline__ void run(const void *in_lds, const float *lut, int cin, int taps, const float *wt,
-                                               const float *bias, float *out, const unsigned short *tap3, int l, int np,
+                                               const float *bias, float *out, int l, int np,
                                                const int (&mt)[NU > 0 ? NU : 1], int xh, int in_shift)
     {
         const int c = l & 15, kk = l >> 4;
@@ -177,33 +177,43 @@ struct Conv16 {
         // QU = k-steps per chunk: their weight operands are requested together, one chunk AHEAD of the MFMAs that use them
         // (an L2 round trip per chunk would otherwise be exposed: conv2 / conv3 have only one or two units per wave to hide
         // it behind).  This lane's B operands: one float4 per k-step pair (layout: dqn_common.hip.h dqn_conv_slab_to_flat)
-        const float4 *wlane = reinterpret_cast<const float4 *>(wt) + np * 64 + l;
+        // (buffer loads: wave-uniform descriptor + the chunk's byte offset in an SGPR + the lane's constant 32-bit offset - as
+        // global loads every chunk cost a 64-bit vector add, and vector instructions are taken from the matrix pipe's time)
+        typedef unsigned u32x4_b __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(wt) + np * 256, 0, 0x7fffffff, 0x00020000);
         float bvA[QU][2], bvB[QU][2];
-        int cbA, cbB;            // chunk bases (conv1 / conv2) ...
-        int toA[QU], toB[QU];    // ... or the table offsets (conv3)
-        auto issue = [&](float (&bv)[QU][2], int &cb, int (&to)[QU], int q0) {
-            const float4 *wq = wlane + (size_t)(q0 >> 1) * (NP * 64);
+        int cbA = 0, cbB = 0;    // chunk bases (conv1 / conv2)
+        // conv3 (3 x 3 window): k-step q = 9 m + s, lane group kk holds tap t = 36 m + 4 s + kk, i.e. input channel
+        // 4 m + (4 s + kk) / 9 and window cell (4 s + kk) % 9: nine per-lane addresses per unit (s = 0 .. 8) + a compile-time
+        // 4 m channel pitches (an instruction immediate; the k loop is unrolled) - no vector instruction per gather.  (A
+        // 16-bit offset table in LDS cost a table read and a shift-add per gather: half a vector instruction per MFMA.)
+        int a9[KS == 3 ? NA : 1][9];
+        if constexpr (KS == 3) {
+#pragma unroll
+            for (int sft = 0; sft < 9; ++sft) {
+                const int t = 4 * sft + kk, cell = t % 9;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) a9[i][sft] = base[i] + (t / 9) * IN_PITCH + (cell / 3) * HIN + cell % 3;
+            }
+        }
+        auto issue = [&](float (&bv)[QU][2], int &cb, int q0) {
 #pragma unroll
             for (int jp = 0; jp < QU / 2; ++jp) {
-                const float4 v = wq[jp * NP * 64];
-                bv[2 * jp][0] = v.x;
-                bv[2 * jp][1] = v.y;
-                bv[2 * jp + 1][0] = v.z;
-                bv[2 * jp + 1][1] = v.w;
+                const u32x4_b v = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, 16 * l + jp * (NP * 1024), (q0 >> 1) * (NP * 1024), 0);
+                bv[2 * jp][0] = __uint_as_float(v[0]);
+                bv[2 * jp][1] = __uint_as_float(v[1]);
+                bv[2 * jp + 1][0] = __uint_as_float(v[2]);
+                bv[2 * jp + 1][1] = __uint_as_float(v[3]);
             }
-            if constexpr (KS == 3) {
-#pragma unroll
-                for (int j = 0; j < QU; ++j) to[j] = tap3[4 * (q0 + j) + kk];
-            } else {
-                cb = Tap::chunk_base(q0, kk, cin);
-            }
+            if constexpr (KS != 3) cb = Tap::chunk_base(q0, kk, cin);
         };
-        auto consume = [&](const float (&bv)[QU][2], int cb, const int (&to)[QU]) {
+        auto consume = [&](const float (&bv)[QU][2], int cb, int qc) {   // qc: the chunk's first k-step (conv3 only)
 #pragma unroll
             for (int j = 0; j < QU; ++j) {
-                auto gather = [&](int b0) {
+                auto gather = [&](int b0, int i) {
                     int off;
-                    if constexpr (KS == 3) off = b0 + to[j];
+                    if constexpr (KS == 3) off = a9[i][(qc + j) % 9] + ((qc + j) / 9) * (4 * IN_PITCH);
                     else off = b0 + cb + Tap::rel(j, cin);
                     if constexpr (U8IN) return DQ_LUT ? lut[static_cast<const unsigned char *>(in_lds)[off]]
                                               : u8_over_255(static_cast<const unsigned char *>(in_lds)[off]);
@@ -211,24 +221,37 @@ struct Conv16 {
                 };
 #pragma unroll
                 for (int i = 0; i < NU; ++i) {
-                    const float av = gather(base[i]);
+                    const float av = gather(base[i], i);
                     acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j][0], acc[i][0], 0, 0, 0);
                     acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[j][1], acc[i][1], 0, 0, 0);
                 }
                 if constexpr (XL) {
-                    const float av = gather(xbase);
+                    const float av = gather(xbase, NU);
                     accx = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xh ? bv[j][1] : bv[j][0], accx, 0, 0, 0);
                 }
             }
         };
-        const int nq = taps / 4;   // a multiple of QU for every layer (C * 16, 128, 144)
-        issue(bvA, cbA, toA, 0);
-        for (int q0 = 0; q0 < nq; q0 += 2 * QU) {
-            if (q0 + QU < nq) issue(bvB, cbB, toB, q0 + QU);
-            consume(bvA, cbA, toA);
-            if (q0 + QU >= nq) break;
-            if (q0 + 2 * QU < nq) issue(bvA, cbA, toA, q0 + 2 * QU);
-            consume(bvB, cbB, toB);
+        issue(bvA, cbA, 0);
+        if constexpr (KS == 3) {
+            constexpr int NQ = 144;   // 64 input channels x 9 cells / 4: fully unrolled (a9's index must be a constant)
+            static_assert(!XL && NQ % QU == 0, "conv3: whole units, whole chunks");
+#pragma unroll
+            for (int q0 = 0; q0 < NQ; q0 += 2 * QU) {
+                if (q0 + QU < NQ) issue(bvB, cbB, q0 + QU);
+                consume(bvA, cbA, q0);
+                if (q0 + QU >= NQ) break;
+                if (q0 + 2 * QU < NQ) issue(bvA, cbA, q0 + 2 * QU);
+                consume(bvB, cbB, q0 + QU);
+            }
+        } else {
+            const int nq = taps / 4;   // a multiple of QU (C * 16, 128)
+            for (int q0 = 0; q0 < nq; q0 += 2 * QU) {
+                if (q0 + QU < nq) issue(bvB, cbB, q0 + QU);
+                consume(bvA, cbA, 0);
+                if (q0 + QU >= nq) break;
+                if (q0 + 2 * QU < nq) issue(bvA, cbA, q0 + 2 * QU);
+                consume(bvB, cbB, 0);
+            }
         }
         if constexpr (OVER) __syncthreads();   // the output overwrites the input: every wave has gathered its last tap
 #pragma unroll
@@ -257,7 +280,7 @@ struct Conv16 {
 // inside is reached once by all of them)
 template <int KS, int STRIDE, int HIN, int HOUT, int COUT, bool U8IN, int IN_PITCH, int OUT_PITCH, int CT, int QU, bool OVER>
 __device__ __forceinline__ void conv16_mfma(const void *in_lds, const float *lut, int cin, int taps, const float *wt,
-                                            const float *bias, float *out, const unsigned short *tap3, int w, int l)
+                                            const float *bias, float *out, int w, int l)
 {
     using K = Conv16<KS, STRIDE, HIN, HOUT, COUT, U8IN, IN_PITCH, OUT_PITCH, CT, QU, OVER>;
     // every wave must enter run<> exactly once: the barrier of an OVER layer sits inside it
@@ -268,7 +291,7 @@ __device__ __forceinline__ void conv16_mfma(const void *in_lds, const float *lut
         int mt[NU > 0 ? NU : 1];
 #pragma unroll
         for (int i = 0; i < (NU > 0 ? NU : 1); ++i) mt[i] = (w + 8 * i) / K::NP;
-        K::template run<NU, decltype(xl)::value>(in_lds, lut, cin, taps, wt, bias, out, tap3, l, np, mt, w & 1, 0);
+        K::template run<NU, decltype(xl)::value>(in_lds, lut, cin, taps, wt, bias, out, l, np, mt, w & 1, 0);
     };
     using std::integral_constant;
     if constexpr (K::SPLIT) {
@@ -345,7 +368,6 @@ constexpr int DQ_P1 = 401, DQ_P2 = 81, DQ_P3 = 49;   // channel pitches of the a
 // staging, two others feed the matrix pipe - and six-channel frames fit the same footprint.
 template <int CMAX>
 struct DqnSmem {
-    unsigned short tap3[576];                      // conv3's tap offsets ci * 81 + ky * 9 + kx
     float lut[DQ_LUT ? 256 : 1];                   // x / 255.0f for x = 0 .. 255
     union {
         unsigned char frame[84 * 84 * CMAX + 16];  // the uint8 HWC frame (dead after conv1's last gather)
@@ -396,22 +418,21 @@ __global__ __launch_bounds__(512, DQ_WPE) void dqn_conv_kernel(const float *slab
     uint4 *dst = reinterpret_cast<uint4 *>(sm.frame);
     for (int i = t; i < nbytes / 16; i += 512) dst[i] = src[i];
     if (DQ_LUT && t < 256) sm.lut[t] = (float)t / 255.0f;
-    for (int i = t; i < 576; i += 512) sm.tap3[i] = (unsigned short)((i / 9) * DQ_P2 + ((i % 9) / 3) * 9 + (i % 3));
     __syncthreads();
     DQ_STAMP(1);
-    conv16_mfma<8, 4, 84, 20, 32, true, 0, DQ_P1, CT, DQ_QU1, true>(sm.frame, sm.lut, C, C * 64, net + L.w1, net + L.b1, sm.a1, nullptr, w, l);
+    conv16_mfma<8, 4, 84, 20, 32, true, 0, DQ_P1, CT, DQ_QU1, true>(sm.frame, sm.lut, C, C * 64, net + L.w1, net + L.b1, sm.a1, w, l);
     __syncthreads();
     DQ_STAMP(2);
     bn_relu_rows<400, DQ_P1, 32>(sm.a1, net + L.b1 + 32, net + L.b1 + 64, w, l);
     __syncthreads();
     DQ_STAMP(3);
-    conv16_mfma<4, 2, 20, 9, 64, false, DQ_P1, DQ_P2, 0, DQ_QU2, true>(sm.a1, nullptr, 32, 512, net + L.w2, net + L.b2, sm.a2, nullptr, w, l);
+    conv16_mfma<4, 2, 20, 9, 64, false, DQ_P1, DQ_P2, 0, DQ_QU2, true>(sm.a1, nullptr, 32, 512, net + L.w2, net + L.b2, sm.a2, w, l);
     __syncthreads();
     DQ_STAMP(4);
     bn_relu_rows<81, DQ_P2, 64>(sm.a2, net + L.b2 + 64, net + L.b2 + 128, w, l);
     __syncthreads();
     DQ_STAMP(5);
-    conv16_mfma<3, 1, 9, 7, 64, false, DQ_P2, DQ_P3, 0, DQ_QU3, false>(sm.a2, nullptr, 64, 576, net + L.w3, net + L.b3, sm.a3, sm.tap3, w, l);
+    conv16_mfma<3, 1, 9, 7, 64, false, DQ_P2, DQ_P3, 0, DQ_QU3, false>(sm.a2, nullptr, 64, 576, net + L.w3, net + L.b3, sm.a3, w, l);
     __syncthreads();
     DQ_STAMP(6);
     bn_relu_rows<49, DQ_P3, 64>(sm.a3, net + L.b3 + 64, net + L.b3 + 128, w, l);
@@ -456,7 +477,7 @@ __global__ __launch_bounds__(64) void dqn_small_conv1_kernel(const float *slab, 
     __syncthreads();
     using K = Conv16<8, 4, 84, 20, 32, true, 0, 400, CT, DQ_SMALL_QU, false>;
     const int mt[1] = {m};
-    K::template run<1, false>(rows, lut, C, C * 64, net + L.w1, net + L.b1, a1raw + (size_t)row * (32 * 400), nullptr, l, 0, mt, 0,
+    K::template run<1, false>(rows, lut, C, C * 64, net + L.w1, net + L.b1, a1raw + (size_t)row * (32 * 400), l, 0, mt, 0,
                               y0 * 84 * C);
 }
 
@@ -483,8 +504,8 @@ __global__ __launch_bounds__(512) void dqn_small_conv2_kernel(const float *slab,
     __syncthreads();
     using K = Conv16<4, 2, 20, 9, 64, false, DQ_P1, DQ_P2, 0, DQ_SMALL_QU, true>;
     const int mt[1] = {w};
-    if (w < K::NM) K::template run<1, false>(sm.a1, nullptr, 32, 512, net + L.w2, net + L.b2, sm.a2, nullptr, l, pr, mt, 0, 0);
-    else K::template run<0, false>(sm.a1, nullptr, 32, 512, net + L.w2, net + L.b2, sm.a2, nullptr, l, pr, mt, 0, 0);
+    if (w < K::NM) K::template run<1, false>(sm.a1, nullptr, 32, 512, net + L.w2, net + L.b2, sm.a2, l, pr, mt, 0, 0);
+    else K::template run<0, false>(sm.a1, nullptr, 32, 512, net + L.w2, net + L.b2, sm.a2, l, pr, mt, 0, 0);
     __syncthreads();
     bn_relu_rows<81, DQ_P2, 32>(sm.a2 + 32 * pr * DQ_P2, net + L.b2 + 64 + 32 * pr, net + L.b2 + 128 + 32 * pr, w, l);
     __syncthreads();
@@ -497,7 +518,6 @@ __global__ __launch_bounds__(512) void dqn_small_conv3_kernel(const float *slab,
 {
     __shared__ __attribute__((aligned(16))) float a2[64 * DQ_P2];
     __shared__ __attribute__((aligned(16))) float a3[64 * DQ_P3];
-    __shared__ unsigned short tap3[576];
     const int row = blockIdx.x, pr = blockIdx.y;
     const coevo_dqn_task task = tasks[task_of_row(tasks, n_tasks, row)];
     const int t = threadIdx.x, w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;
@@ -505,11 +525,10 @@ __global__ __launch_bounds__(512) void dqn_small_conv3_kernel(const float *slab,
     const DqnLayout L = dqn_layout(C, n_actions);
     const float *src = a2g + (size_t)row * (64 * DQ_P2);
     for (int i = t; i < 64 * DQ_P2; i += 512) a2[i] = src[i];
-    for (int i = t; i < 576; i += 512) tap3[i] = (unsigned short)((i / 9) * DQ_P2 + ((i % 9) / 3) * 9 + (i % 3));
     __syncthreads();
     using K = Conv16<3, 1, 9, 7, 64, false, DQ_P2, DQ_P3, 0, DQ_SMALL_QU, false>;
     const int mt[1] = {w};
-    if (w < K::NM) K::template run<1, false>(a2, nullptr, 64, 576, net + L.w3, net + L.b3, a3, tap3, l, pr, mt, 0, 0);
+    if (w < K::NM) K::template run<1, false>(a2, nullptr, 64, 576, net + L.w3, net + L.b3, a3, l, pr, mt, 0, 0);
     __syncthreads();
     bn_relu_rows<49, DQ_P3, 32>(a3 + 32 * pr * DQ_P3, net + L.b3 + 64 + 32 * pr, net + L.b3 + 128 + 32 * pr, w, l);
     __syncthreads();
