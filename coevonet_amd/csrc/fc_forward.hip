@@ -762,10 +762,10 @@ __global__ __launch_bounds__(256) void fc_policy_kernel(FcArgs a)
 {
     stamp_begin(a.stamps);
     if constexpr (COEVO_COMPACT && MODE == MODE_FUSED && R <= 8) {   // fused env step: the body built for few instructions
-        __shared__ FcSmemC<R> smc;
+        __shared__ __attribute__((aligned(16))) FcSmemC<R> smc;
         fc_policy_body_c<R, MODE>(a, smc, a.tasks, blockIdx.x, gridDim.x);
     } else {
-        __shared__ FcSmem<R, 1> sm;
+        __shared__ __attribute__((aligned(16))) FcSmem<R, 1> sm;
         fc_policy_body<R, MODE, 1>(a, sm, a.tasks, blockIdx.x, gridDim.x);
     }
     stamp_end(a.stamps);
@@ -1078,7 +1078,7 @@ __device__ __forceinline__ void fc_policy_mfma_body(const FcArgs &a, FcMfmaSmem 
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void fc_policy_mfma_kernel(FcArgs a)
 {
-    __shared__ FcMfmaSmem sm;
+    __shared__ __attribute__((aligned(16))) FcMfmaSmem sm;
     fc_policy_mfma_body<MODE>(a, sm, a.tasks[blockIdx.x]);
 }
 
@@ -1384,7 +1384,9 @@ __device__ __forceinline__ void fc_policy_mfma16_body(const FcArgs &a, FcMfma16S
 template <int R>
 __global__ __launch_bounds__(256, 4) void fc_cycle16_kernel(FcArgs a)
 {
-    __shared__ union Cycle16Smem {
+    // (16-byte alignment stated: hipcc otherwise assumes 4 and splits every ds_read_b128 of the k-quad image into two
+    // ds_read2_b32 with a vector add each - a third of a vector instruction per MFMA in the stream loop)
+    __shared__ __attribute__((aligned(16))) union Cycle16Smem {
         FcMfma16Smem heavy;
 #if COEVO_COMPACT
         FcSmemC<R> light;
@@ -1413,7 +1415,7 @@ __global__ __launch_bounds__(256, 4) void fc_cycle16_kernel(FcArgs a)
 template <int R, int P>
 __global__ __launch_bounds__(256, 2) void fc_cycle_kernel(FcArgs a)
 {
-    __shared__ union CycleSmem {
+    __shared__ __attribute__((aligned(16))) union CycleSmem {
         FcMfmaSmem heavy;
         FcSmem<R, P> light;
     } sm;
