@@ -7,8 +7,8 @@
 //   dqn_conv_kernel   one workgroup (8 waves) per frame, three per CU: the uint8 HWC frame is staged in LDS once (coalesced
 //                     16-byte loads), /255 as an exact two-term product (u8_over_255), the three convolutions run as
 //                     implicit GEMMs on v_mfma_f32_16x16x4_f32 (A = im2col gather out of LDS, B = weights in lane
-//                     order from L2: dqn_conv_slab_to_flat), BatchNorm statistics are reduced in the canonical tree order
-//                     by packed butterflies (a wave's channels together), activations stay in LDS between layers (one
+//                     order from L2: dqn_conv_slab_to_flat), BatchNorm statistics are reduced in the canonical order
+//                     (lane-strided sums, then one packed butterfly for a wave's channels), activations stay in LDS between layers (one
 //                     region, each layer's output written over its input); conv3's output goes to HBM as act[row][3136].
 //   dqn_fc1_kernel    the 6.4 MB fc1 matrix of each net is streamed exactly once per task (<= 16 rows): a grouped GEMV
 //                     like fc2 of the MPE net, [8][784][64][4] tiling, lane = output, rows in groups of four on
@@ -307,56 +307,49 @@ __device__ __forceinline__ void conv16_mfma(const void *in_lds, const float *lut
 
 // BatchNorm in training mode at batch 1 (per-sample, per-channel statistics over the NPOS positions) + ReLU, in place on
 // x[channel][position] in LDS.  mean = S / N, var = S2 / N (biased), rstd = 1 / sqrtf(var + 1e-5f),
-// y = fmaf(d * rstd, gamma, beta); S = the canonical Reduce (64-wide blocks, zero padded, tree inside, blocks left to right).
-// A wave owns COUT / 8 channels and reduces G of them (G * NB <= 16 values per lane) in ONE packed butterfly
-// (coevo_common.hip.h): lane j < G * NB then holds the tree sum of block j % NB of channel j / NB, the block sums are
-// chained left to right by row shifts, and the IEEE divides and the square root run once per group, lane-parallel, instead
-// of once per channel; each channel's mean / rstd comes back by v_readlane.  (f32 MFMA and VALU instructions never
-// co-execute here - SQ_VALU_MFMA_COEXEC_CYCLES = 0 - so every vector instruction of this pass is taken from the other
-// workgroup's matrix time: channel by channel it was 2/3 of the kernel's vector instructions.)
-template <int B, int NB>
-__device__ __forceinline__ float chain_blocks(float acc, float s)
-{
-    if constexpr (B < NB) return chain_blocks<B + 1, NB>(acc + dpp_move<0x100 + B>(s), s);   // row_shl:B: lane i <- lane i + B
-    else return acc;
-}
-
+// y = fmaf(d * rstd, gamma, beta).  S = the canonical sum of a channel image (oracle/coevo_oracle.c reduce_strided64): lane l
+// adds its positions l, l + 64, l + 128, ... left to right (pad = 0), then the canonical 64-lane tree over the lane sums.
+// A wave owns COUT / 8 channels: their lane sums are plain vector adds and ALL the trees of a pass are ONE packed butterfly
+// (coevo_common.hip.h: lane k then holds channel k's total); the IEEE divides and the square root run once per pass,
+// lane-parallel, and each channel's mean / rstd comes back by v_readlane.  (f32 MFMA and VALU instructions share one
+// issue resource - tools/mfma_rate_probe.hip - so every vector instruction of this pass is taken from the other
+// workgroups' matrix time.  The first form summed 64-wide blocks by a tree each and chained the block sums: 7 trees per
+// channel of conv1's image instead of one, 550 instead of ~250 vector instructions per wave for that pass.)
 template <int NPOS, int PITCH, int COUT>
 __device__ __forceinline__ void bn_relu_rows(float *x, const float *gamma, const float *beta, int w, int l)
 {
-    constexpr int NB = (NPOS + 63) / 64, CPW = COUT / 8, G = (16 / NB < CPW) ? 16 / NB : CPW, NG = CPW / G;
-    static_assert(CPW % G == 0 && G * NB <= 16, "groups of G channels fill one packed butterfly");
+    constexpr int NB = (NPOS + 63) / 64, CPW = COUT / 8;
+    static_assert(CPW >= 1 && CPW <= 16, "one packed butterfly per pass");
+    float v[CPW][NB], s1[CPW], s2[CPW];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        float v[G * NB], sq[G * NB];
+    for (int k = 0; k < CPW; ++k) {
 #pragma unroll
-        for (int k = 0; k < G; ++k)
+        for (int b = 0; b < NB; ++b) v[k][b] = (64 * b + l < NPOS) ? x[(w + 8 * k) * PITCH + 64 * b + l] : 0.0f;
+        s1[k] = v[k][0];
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
-                v[k * NB + b] = (64 * b + l < NPOS) ? x[(w + 8 * (g * G + k)) * PITCH + 64 * b + l] : 0.0f;
-        const float s1 = packed_totals<G * NB>(v, l);
-        const float meanv = chain_blocks<1, NB>(s1, s1) / (float)NPOS;   // lane k * NB: channel k's mean
+        for (int b = 1; b < NB; ++b) s1[k] = s1[k] + v[k][b];
+    }
+    const float meanv = packed_totals<CPW>(s1, l) / (float)NPOS;   // lane k: channel k's mean
 #pragma unroll
-        for (int k = 0; k < G; ++k) {
-            const float mean = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(meanv), k * NB));
+    for (int k = 0; k < CPW; ++k) {
+        const float mean = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(meanv), k));
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                v[k * NB + b] = v[k * NB + b] - mean;
-                sq[k * NB + b] = (64 * b + l < NPOS) ? v[k * NB + b] * v[k * NB + b] : 0.0f;
-            }
+        for (int b = 0; b < NB; ++b) {
+            v[k][b] = v[k][b] - mean;
+            const float sq = (64 * b + l < NPOS) ? v[k][b] * v[k][b] : 0.0f;
+            s2[k] = (b == 0) ? sq : s2[k] + sq;
         }
-        const float s2 = packed_totals<G * NB>(sq, l);
-        const float varv = chain_blocks<1, NB>(s2, s2) / (float)NPOS;
-        const float rstdv = 1.0f / __builtin_sqrtf(varv + LN_EPS);
+    }
+    const float varv = packed_totals<CPW>(s2, l) / (float)NPOS;
+    const float rstdv = 1.0f / __builtin_sqrtf(varv + LN_EPS);
 #pragma unroll
-        for (int k = 0; k < G; ++k) {
-            const int ch = w + 8 * (g * G + k);
-            const float rstd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rstdv), k * NB));
-            const float ga = gamma[ch], be = beta[ch];
+    for (int k = 0; k < CPW; ++k) {
+        const int ch = w + 8 * k;
+        const float rstd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rstdv), k));
+        const float ga = gamma[ch], be = beta[ch];
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
-                if (64 * b + l < NPOS) x[ch * PITCH + 64 * b + l] = relu_keep_nan(__builtin_fmaf(v[k * NB + b] * rstd, ga, be));
-        }
+        for (int b = 0; b < NB; ++b)
+            if (64 * b + l < NPOS) x[ch * PITCH + 64 * b + l] = relu_keep_nan(__builtin_fmaf(v[k][b] * rstd, ga, be));
     }
 }
 

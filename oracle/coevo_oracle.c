@@ -489,19 +489,20 @@ void oracle_es_update_from_pert(float *theta, int P, const float *pert, const fl
  * vbn1.w vbn1.b vbn2.w vbn2.b vbn3.w vbn3.b.
  * frame: uint8 [84][84][C] (HWC, what the env hands over; preprocess_observation's permute is an index change).
  * Canonical order: x = u8 / 255.0f; conv = bias, then fmaf over taps in (ci, ky, kx) order; BatchNorm in TRAINING
- * mode with batch 1 = per-sample, per-channel statistics over the spatial positions: positions in
- * blocks of 64 (the last one zero-padded), canonical tree inside, blocks left to right; mean = S / N, var = S2 / N
+ * mode with batch 1 = per-sample, per-channel statistics over the spatial positions: S = 64 strided sums
+ * (lane l adds positions l, l + 64, ... left to right, zero-padded) combined by the canonical 64-wide tree (the order the
+ * GPU's packed butterfly has - the reference's own order is torch's, pinned to tolerance by the logits fixture);
+ * mean = S / N, var = S2 / N
  * (biased), rstd = 1/sqrtf(var + 1e-5f), y = fmaf(d * rstd, gamma, beta), ReLU; fc = sequential-k chains. */
-static float reduce_canon_padded(const float *v, int n)
+static float reduce_strided64(const float *v, int n)
 {
-    float s = 0.0f;
-    for (int b = 0; b * 64 < n; ++b) {
-        float blk[64];
-        for (int i = 0; i < 64; ++i) blk[i] = (b * 64 + i < n) ? v[b * 64 + i] : 0.0f;
-        float t = block_tree64(blk, 64);
-        s = (b == 0) ? t : s + t;
+    float lane[64];
+    for (int l = 0; l < 64; ++l) {
+        float s = (l < n) ? v[l] : 0.0f;
+        for (int b = 1; b * 64 < n; ++b) s = s + ((b * 64 + l < n) ? v[b * 64 + l] : 0.0f);
+        lane[l] = s;
     }
-    return s;
+    return block_tree64(lane, 64);
 }
 
 static void conv_bn_relu(const float *in, int cin, int hin, const float *w, const float *b, const float *gamma,
@@ -521,9 +522,9 @@ static void conv_bn_relu(const float *in, int cin, int hin, const float *w, cons
                                        in[((size_t)ci * hin + oy * stride + ky) * hin + ox * stride + kx], acc);
                 o[oy * hout + ox] = acc;
             }
-        float mean = reduce_canon_padded(o, npos) / (float)npos;
+        float mean = reduce_strided64(o, npos) / (float)npos;
         for (int p = 0; p < npos; ++p) { o[p] = o[p] - mean; tmp[p] = o[p] * o[p]; }
-        float var = reduce_canon_padded(tmp, npos) / (float)npos;
+        float var = reduce_strided64(tmp, npos) / (float)npos;
         float rstd = 1.0f / sqrtf(var + LN_EPS);
         for (int p = 0; p < npos; ++p) {
             float y = fmaf(o[p] * rstd, gamma[co], beta[co]);
