@@ -24,10 +24,13 @@ def short(name):
 
 
 def stats(tag, wl, src, dst):
-    files = glob.glob(f"{src}/{wl}/**/*kernel_stats.csv", recursive=True)
+    # gpurun merges every call's output into the same scratch tree: take the newest run of this workload, and of it the
+    # process that launched the kernels (rocprofv3 also writes an empty set for helper processes)
+    files = sorted(glob.glob(f"{src}/{wl}/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)
+    files = [f for f in files if os.path.getmtime(f) > os.path.getmtime(files[-1]) - 120 and os.path.getsize(f) > 200] if files else []
     if not files:
         return None
-    rows = list(csv.DictReader(open(files[0])))
+    rows = list(csv.DictReader(open(max(files, key=os.path.getsize))))
     out = f"{dst}/{tag}_{wl}_kernel_stats.csv"
     with open(out, "w") as f:
         bench = open(f"{src}/{wl}.bench.json").read().strip() if os.path.exists(f"{src}/{wl}.bench.json") else ""
@@ -47,7 +50,8 @@ def stats(tag, wl, src, dst):
 
 
 def overlap(tag, src, dst, kernel="fc_cycle16_kernel"):
-    files = glob.glob(f"{src}/headline/**/*kernel_trace.csv", recursive=True)
+    files = sorted(glob.glob(f"{src}/headline/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
+    files = [max([f for f in files if os.path.getmtime(f) > os.path.getmtime(files[-1]) - 120], key=os.path.getsize)] if files else []
     if not files:
         return None
     iv = []
