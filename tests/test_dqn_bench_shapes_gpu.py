@@ -21,11 +21,14 @@ DEV = "cuda"
 ROLES = rp.DQN_ROLES
 
 
-def test_forward_one_net_in_several_tasks_ragged_grid():
+@pytest.mark.parametrize("C,n", [(4, 6), (6, 18), (3, 6), (5, 18)])
+def test_forward_one_net_in_several_tasks_ragged_grid(C, n):
     """one net acting in 37 rows = tasks of 16 + 16 + 5 rows interleaved with other nets' tasks, 41 rows in all (the conv
-    grid is rounded up to 48: tail workgroups), every fc1 row-group instantiation (1, 2 and 4 groups) in one launch"""
-    C, n = 4, 6
-    torch.manual_seed(77)
+    grid is rounded up to 48: tail workgroups), every fc1 row-group instantiation (1, 2 and 4 groups) in one launch.
+    More than 32 rows, so this is the one-workgroup-per-frame conv kernel (smaller launches take the three-launch path):
+    its four instantiations - 4 and 6 planes as compile-time constants (what the bench legs time; 6 = what the reference's
+    wrapper stack yields, utils/game_logic_functions.py:50-53), 3 and 5 planes at run time"""
+    torch.manual_seed(77 + C)
     nets = [rp.dqn_mutate_torch(*rp.dqn_init(C, n), 0.02) for _ in range(3)]
     stride = int(L.load().coevo_dqn_slab_stride(C, n))
     flat = torch.from_numpy(np.stack(nets)).to(DEV)
