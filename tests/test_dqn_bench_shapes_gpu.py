@@ -24,7 +24,7 @@ ROLES = rp.DQN_ROLES
 @pytest.mark.parametrize("C,n", [(4, 6), (6, 18), (3, 6), (5, 18)])
 def test_forward_one_net_in_several_tasks_ragged_grid(C, n):
     """one net acting in 37 rows = tasks of 16 + 16 + 5 rows interleaved with other nets' tasks, 41 rows in all (the conv
-    grid is rounded up to 48: tail workgroups), every fc1 row-group instantiation (1, 2 and 4 groups) in one launch.
+    grid is rounded up to 48: tail workgroups), the row -> task search over interleaved tasks.
     More than 32 rows, so this is the one-workgroup-per-frame conv kernel (smaller launches take the three-launch path):
     its four instantiations - 4 and 6 planes as compile-time constants (what the bench legs time; 6 = what the reference's
     wrapper stack yields, utils/game_logic_functions.py:50-53), 3 and 5 planes at run time"""
@@ -56,6 +56,43 @@ def test_forward_one_net_in_several_tasks_ragged_grid(C, n):
     for r in range(row):
         a, want = rp.dqn_forward(nets[net_of_row[r]], C, n, frames[r])
         assert np.array_equal(got_l[r].view(np.uint32), want.view(np.uint32)), r
+        assert got_a[r] == a, r
+
+
+def test_forward_wide_fc1_every_row_group_and_load_policy():
+    """more than 16 tasks, so fc1 is the streaming kernel (one wave per task and 64 outputs; 16 tasks or fewer take the
+    32-waves-per-task kernel): tasks of 1 .. 16 rows = one to four row groups, for nets with one task (non-temporal weight
+    loads) and for a net cut into 16 + 16 + 7 rows (plain loads: its neighbours stream the same matrix)"""
+    C, n = 4, 6
+    torch.manual_seed(99)
+    single = [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 15, 16]
+    nets = [rp.dqn_mutate_torch(*rp.dqn_init(C, n), 0.02) for _ in range(len(single) + 2)]
+    layout = [(i, r) for i, r in enumerate(single)]
+    layout += [(len(single), 16), (len(single), 16), (len(single), 7), (len(single) + 1, 16), (len(single) + 1, 2)]
+    assert len(layout) > 16
+    lib = L.load()
+    stride = int(lib.coevo_dqn_slab_stride(C, n))
+    slab = torch.zeros(len(nets), stride, dtype=torch.float32, device=DEV)
+    L.call("coevo_dqn_pack", L._p(torch.from_numpy(np.stack(nets)).to(DEV)), L._p(slab), len(nets), C, n)
+    tasks = np.zeros(len(layout), dtype=L.DQN_TASK_DTYPE)
+    net_of_row, row = [], 0
+    for i, (net, r) in enumerate(layout):
+        tasks[i] = (net * stride, row, r)
+        net_of_row += [net] * r
+        row += r
+    g = np.random.Generator(np.random.PCG64(11))
+    frames = g.integers(0, 256, size=(row, 84, 84, C), dtype=np.uint8)
+    actions = torch.full((row,), -1, dtype=torch.int32, device=DEV)
+    logits = torch.zeros(row, L.DQN_LOGIT_STRIDE, dtype=torch.float32, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ws = torch.zeros(int(lib.coevo_dqn_workspace_bytes(row)) // 4, dtype=torch.float32, device=DEV)
+    L.call("coevo_dqn_forward_argmax", L._p(slab), L._p(L.tasks_to_device(tasks, DEV)), len(layout), 16, row, C, n,
+           L._p(torch.from_numpy(frames).to(DEV)), L._p(actions), L._p(logits), L._p(status), L._p(ws))
+    L.raise_on_status(status)
+    got_l, got_a = logits[:, :n].cpu().numpy(), actions.cpu().numpy()
+    for r in range(row):
+        a, want = rp.dqn_forward(nets[net_of_row[r]], C, n, frames[r])
+        assert np.array_equal(got_l[r].view(np.uint32), want.view(np.uint32)), (r, net_of_row[r])
         assert got_a[r] == a, r
 
 
