@@ -88,6 +88,31 @@ def test_ga_device_philox_matches_oracle_port(cohorts):
         assert [sha(x) for x in eng.download(role, "hof", 0, hof)] == [sha(x) for x in want[-1]["hof"][role]]
 
 
+@pytest.mark.parametrize("hof", [7, 10, 17])
+def test_ga_larger_hof_sizes_match_oracle_port(hof):
+    """HoF sizes beyond the fixtures' 1 - 5: 7 (an individual's 7 games of a cycle = one streaming task of the 8-row
+    instantiation), 10 (more than 8 rows: the individuals' games become matrix-core tasks of <= 16 rows, as the HoF members'
+    are) and 17 (tasks of 16 + 1 rows; HoF promotion outside the fused tail graph).  genetic_algorithm.py:125-290."""
+    cfg = {"seed": 11 + hof, "args": dict(generations=2, population=6, hof_size=hof, elites_number=2, fitness_sharing=True,
+                                          max_timesteps_per_episode=30, max_evaluation_steps=40)}
+    args, env, res = _run(cfg, "device_philox", "device")
+    torch.manual_seed(cfg["seed"])
+    np.random.seed(cfg["seed"])
+    oargs = Bag(algorithm="GA", **cfg["args"])
+    want = rp.ga_train(oargs, noise="philox", philox_seed=0)
+    pop = oargs.population
+    for g, w in enumerate(want):
+        assert res.elite_ids[g] == w["elite_ids"]
+        got = res.game_rewards[g]
+        for i in range(3 * pop * hof):
+            assert list(got[i]) == w["games"][i]["rewards"], (g, i)
+        for ph in range(3):
+            np.testing.assert_allclose(res.fitness[g][ph], w["fitness"][ph], rtol=2e-6)
+        assert [res.rewards[r][g] for r in ga.ROLES] == w["eval_rewards"]
+    for role in ga.ROLES:
+        assert [sha(x) for x in res.engine.download(role, "hof", 0, hof)] == [sha(x) for x in want[-1]["hof"][role]]
+
+
 def test_play_game_facade_matches_fixture():
     """play_game(env, p1, p2, adversary, args) through this package's surface == the reference's returns"""
     for case in load_golden("play_game.json")["cases"]:
