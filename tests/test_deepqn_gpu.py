@@ -52,3 +52,24 @@ def test_dqn_matches_reference_logits_fixture():
             srt = np.sort(ref)[::-1]
             if srt[0] - srt[1] > 1e-3:
                 assert net.determine_action(x, None) == int(np.argmax(ref))
+
+
+def test_dqn_nan_propagates_and_no_action_is_an_error():
+    """a NaN weight in conv2 travels through BatchNorm, ReLU (NaN kept, as torch.relu does) and both Linear layers: every
+    logit is NaN (checked on the oracle), and the reference's determine_action would return -1 there (Atari/deepqn.py:55-62:
+    no `>` comparison holds) - this surface raises ValueError instead of acting on it.  A healthy net is unaffected"""
+    C, n = 4, 6
+    torch.manual_seed(5)
+    flat, shapes = rp.dqn_init(C, n)
+    good = rp.dqn_mutate_torch(flat, shapes, 0.02)
+    bad = good.copy()
+    bad[int(np.prod(shapes[0])) + 32 + 100] = np.nan          # one conv2 weight
+    g = np.random.Generator(np.random.PCG64(3))
+    frames = [g.integers(0, 256, size=(2, 84, 84, C), dtype=np.uint8) for _ in range(2)]
+    a, want = rp.dqn_forward(bad, C, n, frames[1][0])
+    assert a == -1 and np.isnan(want).all()
+    with pytest.raises(ValueError):
+        dq.batched_actions([good, bad], frames, C, n)
+    logits, actions = dq.batched_actions([good, good], frames, C, n)
+    a0, w0 = rp.dqn_forward(good, C, n, frames[1][1])
+    assert actions[3] == a0 and np.array_equal(logits[3].view(np.uint32), w0.view(np.uint32))
