@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="enqueue every launch eagerly instead of replaying the "
                     "captured hipGraph of a generation's rollout")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--stamp-every", type=int, default=0, help="ga: read the dominant kernel's launch stamps back every N-th "
+                    "generation inside the timed region (a host sync each time); 0 = the last timed generation only")
     ap.add_argument("--no-device-loop", action="store_true", help="drive every generation from the host (the code path "
                     "the sharded multi-GPU run uses), also on one GPU")
     ap.add_argument("--max-cycles", type=int, default=25, help="world steps before the env truncates a game; 25 is what "
@@ -428,7 +430,10 @@ def run_ga(a, ctx, dev):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if timed and not a.no_graph:
-        tr.stamp_every = 16  # reading launch durations back needs a host sync (2 % at every 8th): every 16th + the last
+        # the kernels stamp every launch, but reading the stamps back needs a host sync that drains the enqueued generations
+        # (2 % at every 8th generation): only the LAST timed generation's launches (2 cohorts x 25 cycles) are read, after the
+        # closing synchronize - `--stamp-every N` samples every N-th generation as well, at that price
+        tr.stamp_every = a.stamp_every if a.stamp_every > 0 else 1 << 30
     for i in range(a.steps):
         tr.step()
     torch.cuda.synchronize()
