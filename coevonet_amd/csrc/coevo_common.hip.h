@@ -187,7 +187,7 @@ __device__ __forceinline__ float row_blocks_total(const float (&v)[NB], int l)
 
 // ---- MPE observation element k of env slot `slot` from the fp64 struct-of-arrays game state -------------------
 // (PettingZoo simple_adversary.observation + SimpleEnv.observe's float32 cast; field indices in mpe_env.hip)
-__device__ inline float mpe_obs_element(const double *st, int n, int g, int slot, int k)
+__host__ __device__ inline float mpe_obs_element(const double *st, int n, int g, int slot, int k)
 {
     const int c = k & 1, e = k >> 1;
     int src;  // fp64 field the agent's own position is subtracted from
@@ -212,7 +212,7 @@ struct MpeGame {
     double gx, gy;                        // goal landmark
 };
 
-__device__ __forceinline__ void mpe_load_game(const double *st, int n, int g, MpeGame &s)
+__host__ __device__ __forceinline__ void mpe_load_game(const double *st, int n, int g, MpeGame &s)
 {
     const size_t N = (size_t)n;
     s.ax = st[0 * N + g]; s.ay = st[1 * N + g];
@@ -284,7 +284,7 @@ __device__ __forceinline__ void mpe_world_step(MpeGame &s, int act_a, int act_b,
 //   adversary: [lm0-p, lm1-p, agent_0-p, agent_1-p]           good: [goal-p, lm0-p, lm1-p, adversary-p, other good-p]
 // Three branches with fixed fields rather than selects on `slot`: hipcc turns a select chain over the position values
 // into a runtime-indexed load from a scratch copy.  Rows of one task almost always share a slot (wave-uniform branch).
-__device__ __forceinline__ void mpe_obs_good(const MpeGame &s, double mex, double mey, double ox, double oy, float o[10])
+__host__ __device__ __forceinline__ void mpe_obs_good(const MpeGame &s, double mex, double mey, double ox, double oy, float o[10])
 {
     o[0] = (float)(s.gx - mex);  o[1] = (float)(s.gy - mey);
     o[2] = (float)(s.l0x - mex); o[3] = (float)(s.l0y - mey);
@@ -293,7 +293,7 @@ __device__ __forceinline__ void mpe_obs_good(const MpeGame &s, double mex, doubl
     o[8] = (float)(ox - mex);    o[9] = (float)(oy - mey);
 }
 
-__device__ __forceinline__ void mpe_obs_from_game(const MpeGame &s, int slot, float o[10])
+__host__ __device__ __forceinline__ void mpe_obs_from_game(const MpeGame &s, int slot, float o[10])
 {
     if (slot == COEVO_SLOT_ADVERSARY) {
         o[0] = (float)(s.l0x - s.ax); o[1] = (float)(s.l0y - s.ay);

@@ -20,12 +20,12 @@ namespace coevo {
 
 typedef unsigned __int128 u128;
 
-__device__ inline u128 pcg_mult()
+__host__ __device__ inline u128 pcg_mult()
 {
     return (((u128)0x2360ED051FC65DA4ULL) << 64) | (u128)0x4385DF649FCCF645ULL;
 }
 
-__device__ inline uint64_t pcg_output(u128 s)
+__host__ __device__ inline uint64_t pcg_output(u128 s)
 {
     const uint64_t hi = (uint64_t)(s >> 64), lo = (uint64_t)s;
     const uint64_t x = hi ^ lo;
@@ -34,7 +34,7 @@ __device__ inline uint64_t pcg_output(u128 s)
 }
 
 // state after `delta` further steps of the 128-bit LCG (O(log delta))
-__device__ inline u128 pcg_advance(u128 state, u128 inc, uint64_t delta)
+__host__ __device__ inline u128 pcg_advance(u128 state, u128 inc, uint64_t delta)
 {
     u128 acc_mult = 1, acc_plus = 0, cur_mult = pcg_mult(), cur_plus = inc;
     while (delta > 0) {
@@ -52,7 +52,7 @@ __device__ inline u128 pcg_advance(u128 state, u128 inc, uint64_t delta)
 // numpy Generator semantics of one PettingZoo reset: choice(2) = one buffered 32-bit draw (the low half of a
 // 64-bit output for even ordinals, the kept high half for odd ones; Lemire range 2 => top bit), then ten
 // uniform(-1,1) doubles.  Two resets consume 21 raw 64-bit outputs.
-__device__ __forceinline__ void mpe_reset_game(double *st, int n, int g, coevo_pcg64 rng, uint64_t ordinal);
+__host__ __device__ __forceinline__ void mpe_reset_game(double *st, int n, int g, coevo_pcg64 rng, uint64_t ordinal);
 
 __global__ void mpe_reset_kernel(double *st, int n, int game_first, int count, coevo_pcg64 rng,
                                  int64_t first_ordinal, const int32_t *gen_dev, int64_t ordinals_per_gen)
@@ -74,7 +74,7 @@ __global__ void mpe_reset_multi_kernel(double *st, int n, ResetSegs segs, coevo_
     mpe_reset_game(st, n, sg.game_first + i, rng, sg.first_ordinal + (uint64_t)i);
 }
 
-__device__ __forceinline__ void mpe_reset_game(double *st, int n, int g, coevo_pcg64 rng, uint64_t ordinal)
+__host__ __device__ __forceinline__ void mpe_reset_game(double *st, int n, int g, coevo_pcg64 rng, uint64_t ordinal)
 {
     const u128 inc = ((u128)rng.pcg_inc_hi << 64) | rng.pcg_inc_lo;
     u128 s = ((u128)rng.pcg_state_hi << 64) | rng.pcg_state_lo;
@@ -108,15 +108,21 @@ __device__ __forceinline__ void mpe_reset_game(double *st, int n, int g, coevo_p
     st[23 * N + g] = 0.0;
 }
 
+// element i of the observation buffer [n_rows][COEVO_OBS_STRIDE] (the kernel's thread / the host loop's iteration)
+__host__ __device__ inline float mpe_observe_at(const double *st, int n, const int32_t *row_game, const int32_t *row_slot, int i)
+{
+    const int row = i / COEVO_OBS_STRIDE, k = i % COEVO_OBS_STRIDE;
+    const int slot = row_slot[row];
+    const int D = (slot == COEVO_SLOT_ADVERSARY) ? 8 : 10;
+    return (k < D) ? mpe_obs_element(st, n, row_game[row], slot, k) : 0.0f;
+}
+
 __global__ void mpe_observe_kernel(const double *st, int n, const int32_t *row_game, const int32_t *row_slot,
                                    int n_rows, float *obs)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows * COEVO_OBS_STRIDE) return;
-    const int row = i / COEVO_OBS_STRIDE, k = i % COEVO_OBS_STRIDE;
-    const int slot = row_slot[row];
-    const int D = (slot == COEVO_SLOT_ADVERSARY) ? 8 : 10;
-    obs[i] = (k < D) ? mpe_obs_element(st, n, row_game[row], slot, k) : 0.0f;
+    obs[i] = mpe_observe_at(st, n, row_game, row_slot, i);
 }
 
 // One world cycle (three agent-steps) of every game.  Agent-step index of slot s in cycle c is t = 3c + s; it
@@ -125,11 +131,9 @@ __global__ void mpe_observe_kernel(const double *st, int n, const int32_t *row_g
 //   adversary_0 acting at 3c   receives agent_0's cumulative reward  = good reward of world step c
 //   agent_0     acting at 3c+1 receives agent_1's cumulative reward  = good reward of world step c
 //   agent_1     acting at 3c+2 triggers world step c+1 and receives the adversary's reward of that step
-__global__ void mpe_step_kernel(double *st, int n, const int32_t *game_rows, const int32_t *actions, int cycle,
-                                const int32_t *game_limit, int pos_first)
+__host__ __device__ inline void mpe_step_game(double *st, int n, const int32_t *game_rows, const int32_t *actions,
+                                              int cycle, const int32_t *game_limit, int pos_first, int g)
 {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n) return;
     const size_t N = (size_t)n;
     const int limit = game_limit ? game_limit[g] : 0x7fffffff;
     const int t0 = 3 * cycle;
@@ -169,6 +173,13 @@ __global__ void mpe_step_kernel(double *st, int n, const int32_t *game_rows, con
     const double r_good = -m + d[0];
     st[21 * N + g] = st[21 * N + g] + r_adv;  // agent_1 acted
     st[18 * N + g] = r_good;
+}
+
+__global__ void mpe_step_kernel(double *st, int n, const int32_t *game_rows, const int32_t *actions, int cycle,
+                                const int32_t *game_limit, int pos_first)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) mpe_step_game(st, n, game_rows, actions, cycle, game_limit, pos_first, g);
 }
 
 // The last cycle's step in the fused scheme: its actions are applied only to close the books (credits of cycle
@@ -271,6 +282,44 @@ extern "C" int coevo_mpe_step(double *state, int n_games, const int32_t *game_ro
     hipLaunchKernelGGL(coevo::mpe_step_kernel, dim3((n_games + 127) / 128), dim3(128), 0, (hipStream_t)stream,
                        state, n_games, game_rows, actions, cycle, game_limit, pos_first);
     COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+// The same two functions on the host cores (env_mode "host": the env is stepped by the rank's own host process, the
+// observations go up and the actions come back over PCIe every cycle).  Plain host pointers; the bodies are the kernels'.
+extern "C" int coevo_mpe_host_reset(double *state, int n_games, coevo_pcg64 rng, const int64_t *ordinals)
+{
+    if (!state || !ordinals || n_games <= 0) return COEVO_ERR_ARG;
+    for (int g = 0; g < n_games; ++g)
+        if (ordinals[g] < 0) return COEVO_ERR_ARG;
+    for (int g = 0; g < n_games; ++g) coevo::mpe_reset_game(state, n_games, g, rng, (uint64_t)ordinals[g]);
+    return COEVO_OK;
+}
+
+extern "C" int coevo_mpe_host_observe(const double *state, int n_games, const int32_t *row_game, const int32_t *row_slot,
+                                      int n_rows, float *obs)
+{
+    if (!state || !row_game || !row_slot || !obs || n_games <= 0 || n_rows <= 0) return COEVO_ERR_ARG;
+    for (int r = 0; r < n_rows; ++r)
+        if (row_game[r] < 0 || row_game[r] >= n_games || row_slot[r] < 0 || row_slot[r] > 2) return COEVO_ERR_ARG;
+    for (int r = 0; r < n_rows; ++r) {   // a row at a time: the game's state once (the same casts of the same differences)
+        coevo::MpeGame s;
+        coevo::mpe_load_game(state, n_games, row_game[r], s);
+        float *o = obs + (size_t)r * COEVO_OBS_STRIDE;
+        coevo::mpe_obs_from_game(s, row_slot[r], o);
+        o[10] = 0.0f;
+        o[11] = 0.0f;
+    }
+    return COEVO_OK;
+}
+
+extern "C" int coevo_mpe_host_step(double *state, int n_games, const int32_t *game_rows, const int32_t *actions,
+                                   int n_rows, int cycle, const int32_t *game_limit, int pos_first)
+{
+    if (!state || !game_rows || !actions || n_games <= 0 || n_rows <= 0 || cycle < 0) return COEVO_ERR_ARG;
+    for (int i = 0; i < 3 * n_games; ++i)
+        if (game_rows[i] < 0 || game_rows[i] >= n_rows) return COEVO_ERR_ARG;
+    for (int g = 0; g < n_games; ++g) coevo::mpe_step_game(state, n_games, game_rows, actions, cycle, game_limit, pos_first, g);
     return COEVO_OK;
 }
 

@@ -362,10 +362,15 @@ class DeviceRollout:
 
 
 class HostEnvRollout:
-    """Same plan, env stepped on the host cores with NumPy (struct-of-arrays); per cycle the observations go up and
-    the actions come back over PCIe.  Results are bit-identical with DeviceRollout."""
+    """Same plan, env stepped on the host cores (struct-of-arrays); per cycle the observations go up and the actions come
+    back over PCIe.  Results are bit-identical with DeviceRollout.  impl = "native": coevo_mpe_host_observe /
+    coevo_mpe_host_step, the env kernels' own bodies compiled for the host (1.5 ms of NumPy per cycle at cfg 2 -> 0.1 ms);
+    impl = "numpy": coevonet_amd/mpe/simple_adversary.py's VecSimpleAdversary, the form the env fixtures are stated in."""
 
-    def __init__(self, plan: RolloutPlan, slab: torch.Tensor, env_seed=sa.ENV_SEED):
+    def __init__(self, plan: RolloutPlan, slab: torch.Tensor, env_seed=sa.ENV_SEED, impl=None):
+        self.impl = impl or os.environ.get("COEVO_HOST_ENV", "native")
+        if self.impl not in ("native", "numpy"):
+            raise ValueError(f"host env implementation {self.impl!r}: 'native' or 'numpy'")
         self.plan = plan
         self.slab = slab
         dev = plan.device
@@ -375,24 +380,49 @@ class HostEnvRollout:
         self.actions_host = torch.zeros(plan.n_rows, dtype=torch.int32).pin_memory()
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self.env_seed = env_seed
-        self.limits = np.zeros(plan.n_games, dtype=np.int64)
+        self.set_limits(np.zeros(plan.n_games, dtype=np.int64))
         self.rewards = None
         self._streams = {}
 
     def set_limits(self, limits_np):
         self.limits = np.asarray(limits_np, dtype=np.int64)
+        self._limits32 = np.ascontiguousarray(self.limits, dtype=np.int32)
 
     def reset_from_ordinals(self, ordinals):
         """ordinals[g] = reset ordinal of game g; draws every reset up to the largest one on the host."""
-        ordinals = np.asarray(ordinals, dtype=np.int64)
+        ordinals = np.ascontiguousarray(ordinals, dtype=np.int64)
+        n = self.plan.n_games
+        if self.impl == "native":   # the device state layout (csrc/mpe_env.hip) in host memory; reset = the reset kernel's body
+            self.state = np.zeros((L.MPE_STATE_DOUBLES, n), dtype=np.float64)   # (PCG64 jump-ahead to each game's ordinal)
+            L._check(L.load().coevo_mpe_host_reset(self.state.ctypes.data, n, L.PCG64State.from_seed(self.env_seed),
+                                                   ordinals.ctypes.data), "coevo_mpe_host_reset")
+            self._game_rows32 = np.ascontiguousarray(self.plan.game_rows_np, dtype=np.int32)
+            return
         stream = sa.ResetStream(self.env_seed, skip_initial=False)
         goal, apos, lpos = stream.take(int(ordinals.max()) + 1)
         self.env = sa.VecSimpleAdversary(goal[ordinals], apos[ordinals], lpos[ordinals])
-        n = self.plan.n_games
         self.acc = np.zeros((n, 3))
         self.rg_prev = np.zeros(n)
 
+    def _cycle_native(self, c):
+        p, lib = self.plan, L.load()
+        L._check(lib.coevo_mpe_host_observe(self.state.ctypes.data, p.n_games, p.row_game_np.ctypes.data,
+                                            p.row_slot_np.ctypes.data, p.n_rows, self.obs_host.data_ptr()),
+                 "coevo_mpe_host_observe")
+        self.obs.copy_(self.obs_host, non_blocking=True)
+        for tasks, tnp, mx in ((p.heavy, p.heavy_np, p.heavy_max), (p.light, p.light_np, p.light_max)):
+            if tasks is not None:
+                L.call("coevo_fc_forward_argmax", L._p(self.slab), L._p(tasks), len(tnp), mx, L._p(self.obs),
+                       L._p(self.actions), None, L._p(self.status))
+        self.actions_host.copy_(self.actions, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        L._check(lib.coevo_mpe_host_step(self.state.ctypes.data, p.n_games, self._game_rows32.ctypes.data,
+                                         self.actions_host.data_ptr(), p.n_rows, c, self._limits32.ctypes.data,
+                                         1 if sa.INTEGRATE_POS_FIRST else 0), "coevo_mpe_host_step")
+
     def cycle(self, c):
+        if self.impl == "native":
+            return self._cycle_native(c)
         p = self.plan
         adv, a0, a1 = self.env.observe()
         o = self.obs_host.numpy()
@@ -419,7 +449,10 @@ class HostEnvRollout:
     def run(self, n_cycles):
         for c in range(n_cycles):
             self.cycle(c)
-        self.rewards = np.stack([self.acc[:, 1], self.acc[:, 2], self.acc[:, 0]], axis=1)
+        if self.impl == "native":   # play_game's triple (agent_0, agent_1, adversary_0): state rows 20, 21, 19
+            self.rewards = np.ascontiguousarray(self.state[[20, 21, 19]].T)
+        else:
+            self.rewards = np.stack([self.acc[:, 1], self.acc[:, 2], self.acc[:, 0]], axis=1)
 
     def check_status(self):
         L.raise_on_status(self.status)

@@ -119,6 +119,16 @@ int coevo_mpe_observe(const double *state, int n_games, const int32_t *row_game,
  * adversary reward of world step c+1, each only while 3c+slot < limit.  pos_first = PettingZoo >= 1.24 order. */
 int coevo_mpe_step(double *state, int n_games, const int32_t *game_rows, const int32_t *actions, int cycle,
                    const int32_t *game_limit, int pos_first, void *stream);
+/* coevo_mpe_observe / coevo_mpe_step on the HOST cores (every pointer is host memory, the call returns when the work is
+ * done; same state layout, same arithmetic, the kernels' own bodies): the env of north_star's first configuration,
+ * "vectorised env stepping runs on the host cores" - what play_MPE drives through env.observe / env.step / env.last
+ * (utils/game_logic_functions.py:138,179-190), for all of a rank's games at once.  n_rows = length of `actions`. */
+int coevo_mpe_host_reset(double *state, int n_games, coevo_pcg64 rng, const int64_t *ordinals /* [n_games] reset ordinal of
+                         every game: play_game's env.reset(), utils/game_logic_functions.py:217, quirk Q6 */);
+int coevo_mpe_host_observe(const double *state, int n_games, const int32_t *row_game, const int32_t *row_slot,
+                           int n_rows, float *obs);
+int coevo_mpe_host_step(double *state, int n_games, const int32_t *game_rows, const int32_t *actions, int n_rows,
+                        int cycle, const int32_t *game_limit, int pos_first);
 /* play_game() return triples (agent_0, agent_1, adversary_0) -> rewards[n][3] fp64 */
 int coevo_mpe_rewards(const double *state, int n_games, double *rewards, void *stream);
 

@@ -367,3 +367,61 @@ def test_reference_helper_functions_host_side():
     np.testing.assert_allclose(upd2, (0.1 / (6 * 0.05)) * np.dot(noises.T, rewards.astype(np.float32) / (1 + div2)), rtol=1e-6)
     with pytest.raises(ValueError):
         es.get_numpy_dtype("float16")
+
+
+def test_native_host_env_equals_numpy_env():
+    """coevo_mpe_host_reset / _observe / _step (the env kernels' bodies compiled for the host cores) against the NumPy
+    env the fixtures are stated in: resets at random ordinals, then 25 world cycles of 257 games with random actions, a random row order and ragged
+    agent-step limits - observations of every live game and the final play_game triples, bit for bit
+    (utils/game_logic_functions.py:138,179-190; quirk Q1 credits)"""
+    from coevonet_amd import lib as L
+    from coevonet_amd.mpe import simple_adversary as sa
+    lib = L.load()
+    n = 257
+    rng = np.random.default_rng(1)
+    ordinals = rng.integers(0, 4000, size=n).astype(np.int64)   # env.reset() number of each game (odd and even: Q6)
+    goal, apos, lpos = sa.ResetStream(sa.ENV_SEED, skip_initial=False).take(int(ordinals.max()) + 1)
+    goal, apos, lpos = goal[ordinals], apos[ordinals], lpos[ordinals]
+    env = sa.VecSimpleAdversary(goal, apos, lpos)
+    want0 = np.zeros((L.MPE_STATE_DOUBLES, n))
+    want0[0:6] = apos.astype(np.float64).reshape(n, 6).T
+    want0[12:16] = lpos.astype(np.float64).reshape(n, 4).T
+    want0[16:18] = lpos.astype(np.float64)[np.arange(n), goal.astype(np.int64)].T
+    want0[22] = goal
+    st = np.full((L.MPE_STATE_DOUBLES, n), 7.0)
+    assert lib.coevo_mpe_host_reset(st.ctypes.data, n, L.PCG64State.from_seed(sa.ENV_SEED), ordinals.ctypes.data) == 0
+    assert np.array_equal(st.view(np.uint64), want0.view(np.uint64))   # PCG64 jump-ahead == numpy's Generator stream
+    game_rows = rng.permutation(3 * n).astype(np.int32).reshape(n, 3).copy()
+    row_game, row_slot = np.zeros(3 * n, np.int32), np.zeros(3 * n, np.int32)
+    for g in range(n):
+        for s in range(3):
+            row_game[game_rows[g, s]], row_slot[game_rows[g, s]] = g, s
+    limits = rng.integers(0, 80, size=n).astype(np.int32)
+    acc, rg_prev = np.zeros((n, 3)), np.zeros(n)
+    obs = np.zeros((3 * n, L.OBS_STRIDE), np.float32)
+    pos_first = 1 if sa.INTEGRATE_POS_FIRST else 0
+    for c in range(25):
+        want = np.zeros_like(obs)
+        for slot, arr in enumerate(env.observe()):
+            want[game_rows[:, slot], :arr.shape[1]] = arr
+        assert lib.coevo_mpe_host_observe(st.ctypes.data, n, row_game.ctypes.data, row_slot.ctypes.data, 3 * n,
+                                          obs.ctypes.data) == 0
+        live = 3 * c + 2 < limits   # a game past its last agent-step no longer moves here (the NumPy env moves on, unread)
+        rows = np.concatenate([game_rows[live, k] for k in range(3)])
+        assert np.array_equal(obs[rows].view(np.uint32), want[rows].view(np.uint32)), c
+        acts_rows = rng.integers(0, 5, size=3 * n).astype(np.int32)
+        t0 = 3 * c
+        m0, m1, m2 = t0 < limits, t0 + 1 < limits, t0 + 2 < limits
+        acc[m0, 0] += rg_prev[m0]
+        acc[m1, 1] += rg_prev[m1]
+        rg, ra = env.step(acts_rows[game_rows])
+        acc[m2, 2] += ra[m2]
+        rg_prev[m2] = rg[m2]
+        assert lib.coevo_mpe_host_step(st.ctypes.data, n, game_rows.ctypes.data, acts_rows.ctypes.data, 3 * n, c,
+                                       limits.ctypes.data, pos_first) == 0
+    want = np.stack([acc[:, 1], acc[:, 2], acc[:, 0]], axis=1)
+    assert np.array_equal(np.ascontiguousarray(st[[20, 21, 19]].T).view(np.uint64), want.view(np.uint64))
+    bad = game_rows.copy()
+    bad[0, 0] = 3 * n   # a row index outside the action buffer is refused, not read
+    assert lib.coevo_mpe_host_step(st.ctypes.data, n, bad.ctypes.data, acts_rows.ctypes.data, 3 * n, 0, limits.ctypes.data,
+                                   pos_first) == -1   # COEVO_ERR_ARG
