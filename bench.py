@@ -378,7 +378,7 @@ def extras(a, ctx, dev):
     # north_star's literal first configuration: the env vectorised on the host cores, observations up / actions down over
     # PCIe every cycle - the PCIe-and-Python-inclusive rate, never the headline
     host = copy.copy(b)
-    host.env, host.steps, host.warmup = "host", 3, 1
+    host.env, host.steps, host.warmup = "host", 20, 3
     leg("cfg2_host_env_mode", lambda: run_ga(host, ctx, dev))
     leg("cfg3_coes_reference_exact", lambda: run_es(b, ctx, dev, extension=False))
     leg("cfg3_coes_extension_antithetic_centered_rank", lambda: run_es(b, ctx, dev, extension=True))
