@@ -30,7 +30,7 @@ run cfg4_dqn_ga --workload dqn-ga --steps 2 --warmup 1
 run cfg5_dqn_es --workload dqn-es --steps 2 --warmup 1
 run cfg4_dqn_ga_c6 --workload dqn-ga --channels 6 --steps 2 --warmup 1
 run cfg5_dqn_es_c6 --workload dqn-es --channels 6 --steps 2 --warmup 1
-run cfg2_host_env --env host --steps 3 --warmup 1
+run cfg2_host_env --env host --steps 20 --warmup 3
 fi
 pmc() {  # workload name, bench args...: one pass per counter (never combined with a trace domain other than --kernel-trace)
     local name=$1; shift
