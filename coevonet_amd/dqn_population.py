@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from . import lib as L
-from .atari_synthetic import ATARI_GAMES, SYNTH_SEED
+from .atari_synthetic import SYNTH_SEED
 from .deepqn import DeepQN
 from .genetic_algorithm import N_EVAL, adapt_mutation_power
 

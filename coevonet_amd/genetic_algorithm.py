@@ -31,7 +31,6 @@ import numpy as np
 import torch
 
 from . import lib as L
-from .agent import MPEAgent
 from .fcnetwork import FCNetwork
 from .game_logic import create_agent
 from .mpe.simple_adversary import ENV_SEED
