@@ -482,7 +482,7 @@ template <int R, int MODE>
 __device__ __forceinline__ void fc_policy_body_c(const FcArgs &a, FcSmemC<R> &sm, const coevo_fc_task *tasks, int first,
                                                  int n_tasks)
 {
-    static_assert(MODE == MODE_FUSED && R * NACT <= 64 && R <= 8, "the lean merged cycle kernel");
+    static_assert((MODE == MODE_FUSED || MODE == MODE_OBS) && R * NACT <= 64 && R <= 8, "the lean merged cycle kernel");
     typedef float f32x4_acc __attribute__((ext_vector_type(4)));
     constexpr int NG = FcSmemC<R>::NG;
     COEVO_STAMP(0);
@@ -519,8 +519,13 @@ __device__ __forceinline__ void fc_policy_body_c(const FcArgs &a, FcSmemC<R> &sm
         for (int k = 0; k < COEVO_OBS_STRIDE; ++k) o[k] = 0.0f;
         if (l < nrows) {
             const int row = row0 + l;
-            mpe_fused_observe(a.state, a.state_next, a.act_prev, a.game_limit, a.n_games, a.row_game[row],
-                                     a.row_slot[row], a.cycle, a.pos_first, o);
+            if constexpr (MODE == MODE_FUSED) {
+                mpe_fused_observe(a.state, a.state_next, a.act_prev, a.game_limit, a.n_games, a.row_game[row],
+                                  a.row_slot[row], a.cycle, a.pos_first, o);
+            } else {   // observations given (env stepped elsewhere, e.g. on the host cores): columns >= D are not inputs
+#pragma unroll
+                for (int k = 0; k < 10; ++k) o[k] = (k < D) ? a.obs[(size_t)row * COEVO_OBS_STRIDE + k] : 0.0f;
+            }
 #pragma unroll
             for (int k = 0; k < 10; ++k)
                 if (!__builtin_isfinite(o[k])) st |= COEVO_ST_BAD_INPUT;
@@ -743,7 +748,8 @@ __device__ __forceinline__ void fc_policy_body_c(const FcArgs &a, FcSmemC<R> &sm
             }
             if (best < 0) { st |= COEVO_ST_NO_ACTION; best = 0; }
             const int row = row0 + l;
-            a.act_cur[3 * a.row_game[row] + a.row_slot[row]] = best;  // by (game, slot)
+            if constexpr (MODE == MODE_FUSED) a.act_cur[3 * a.row_game[row] + a.row_slot[row]] = best;  // by (game, slot)
+            else a.actions[row] = best;
             if (a.logits) {
 #pragma unroll
                 for (int o = 0; o < NACT; ++o) a.logits[(size_t)row * COEVO_LOGIT_STRIDE + o] = sm.logit[l][o];
@@ -1381,7 +1387,7 @@ __device__ __forceinline__ void fc_policy_mfma16_body(const FcArgs &a, FcMfma16S
 
 // The lean merged cycle launch: shared-opponent tasks of <= 16 rows (fc_policy_mfma16_body) + one per-individual net per
 // streaming workgroup, four workgroups per CU.
-template <int R>
+template <int R, int MODE = MODE_FUSED>
 __global__ __launch_bounds__(256, 4) void fc_cycle16_kernel(FcArgs a)
 {
     // (16-byte alignment stated: hipcc otherwise assumes 4 and splits every ds_read_b128 of the k-quad image into two
@@ -1397,12 +1403,12 @@ __global__ __launch_bounds__(256, 4) void fc_cycle16_kernel(FcArgs a)
     static_assert(sizeof(sm) <= 40960, "four workgroups per CU");
     stamp_begin(a.stamps);
     if ((int)blockIdx.x < a.n_heavy)  // workgroup-uniform
-        fc_policy_mfma16_body<MODE_FUSED>(a, sm.heavy, a.tasks[blockIdx.x]);
+        fc_policy_mfma16_body<MODE>(a, sm.heavy, a.tasks[blockIdx.x]);
     else
 #if COEVO_COMPACT
-        fc_policy_body_c<R, MODE_FUSED>(a, sm.light, a.light_tasks, (int)blockIdx.x - a.n_heavy, a.n_light);
+        fc_policy_body_c<R, MODE>(a, sm.light, a.light_tasks, (int)blockIdx.x - a.n_heavy, a.n_light);
 #else
-        fc_policy_body<R, MODE_FUSED, 1>(a, sm.light, a.light_tasks, (int)blockIdx.x - a.n_heavy, a.n_light);
+        fc_policy_body<R, MODE, 1>(a, sm.light, a.light_tasks, (int)blockIdx.x - a.n_heavy, a.n_light);
 #endif
     stamp_end(a.stamps);
 }
@@ -1570,6 +1576,34 @@ extern "C" int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_t
     else if (light_max_rows <= 5) COEVO_LAUNCH_CYCLE(5);
     else COEVO_LAUNCH_CYCLE(8);
 #undef COEVO_LAUNCH_CYCLE
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+// The merged launch with the observations GIVEN (the env stepped elsewhere - on the host cores, env_mode "host"): shared-opponent
+// tasks (<= 16 rows) and per-individual tasks (<= 8 rows) of one env-cycle in one launch of the lean kernel, instead of one
+// coevo_fc_forward_argmax per task class.  Needs every workgroup resident at four per CU; COEVO_ERR_ARG otherwise (the caller
+// then launches the classes one after the other).
+extern "C" int coevo_fc_forward_merged(const float *slab, const coevo_fc_task *heavy_tasks, int n_heavy, int heavy_max_rows,
+                                       const coevo_fc_task *light_tasks, int n_light, int light_max_rows, const float *obs,
+                                       int32_t *actions, float *logits, int32_t *status, void *stream)
+{
+    if (!slab || !heavy_tasks || !light_tasks || !obs || !actions || !status) return COEVO_ERR_ARG;
+    if (n_heavy <= 0 || n_light <= 0 || heavy_max_rows < 1 || heavy_max_rows > 16 || light_max_rows < 1 || light_max_rows > 8)
+        return COEVO_ERR_ARG;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return COEVO_ERR_HIP;
+    if (n_heavy + n_light > 4 * cus) return COEVO_ERR_ARG;
+    coevo::FcArgs a{slab, heavy_tasks, obs, nullptr, nullptr, nullptr, 0, actions, logits, status, nullptr, nullptr, nullptr,
+                    nullptr, nullptr, 0, 0, light_tasks, n_heavy, n_light};
+    const dim3 grid(n_heavy + n_light), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (light_max_rows <= 1) hipLaunchKernelGGL((coevo::fc_cycle16_kernel<1, coevo::MODE_OBS>), grid, block, 0, s, a);
+    else if (light_max_rows <= 2) hipLaunchKernelGGL((coevo::fc_cycle16_kernel<2, coevo::MODE_OBS>), grid, block, 0, s, a);
+    else if (light_max_rows <= 5) hipLaunchKernelGGL((coevo::fc_cycle16_kernel<5, coevo::MODE_OBS>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((coevo::fc_cycle16_kernel<8, coevo::MODE_OBS>), grid, block, 0, s, a);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

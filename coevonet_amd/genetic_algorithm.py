@@ -165,7 +165,8 @@ class GAEngine:
             games.append((net("hof", "adversary_0", h - 1), net("hof", "agent_0", h - 1), net("hof", "agent_1", h - 1)))
         # 16-row shared-opponent tasks select the lean merged cycle kernel (four workgroups per CU); COEVO_HEAVY_ROWS=32
         # keeps the 32-row tiles for A/B runs
-        heavy_rows = int(os.environ.get("COEVO_HEAVY_ROWS", "16")) if env == "device" else 32
+        # (host-stepped env: the same 16-row tasks, for the observation-fed merged launch coevo_fc_forward_merged)
+        heavy_rows = int(os.environ.get("COEVO_HEAVY_ROWS", "16"))
         # cohorts = contiguous ranges of this rank's individuals (so that offspring can be bred cohort by cohort and a
         # cohort's chain can start while the next cohort is still being bred); the evaluation games go with the last
         self.K = max(1, min(int(cohorts), self.n_local)) if env == "device" else 1

@@ -94,6 +94,8 @@ _SIGS = {
     "coevo_fc_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "coevo_fc_forward_argmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "coevo_fc_forward_merged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "coevo_mpe_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, PCG64State, C.c_uint64, C.c_void_p]),
     "coevo_mpe_reset_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, PCG64State, C.c_void_p]),
     "coevo_fc_perturb_dist_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]),

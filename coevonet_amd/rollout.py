@@ -383,6 +383,7 @@ class HostEnvRollout:
         self.set_limits(np.zeros(plan.n_games, dtype=np.int64))
         self.rewards = None
         self._streams = {}
+        self._merged = None
 
     def set_limits(self, limits_np):
         self.limits = np.asarray(limits_np, dtype=np.int64)
@@ -404,16 +405,29 @@ class HostEnvRollout:
         self.acc = np.zeros((n, 3))
         self.rg_prev = np.zeros(n)
 
+    def _forward(self):
+        """the policy step of every row: both task tables in one launch of the lean cycle kernel when they fit it
+        (<= 16-row shared-opponent tasks, everything resident), else one launch per table"""
+        p = self.plan
+        if self._merged is None:
+            self._merged = (p.heavy is not None and p.light is not None and p.heavy_max <= 16 and
+                            len(p.heavy_np) + len(p.light_np) <= 4 * torch.cuda.get_device_properties(self.obs.device).multi_processor_count)
+        if self._merged:
+            L.call("coevo_fc_forward_merged", L._p(self.slab), L._p(p.heavy), len(p.heavy_np), p.heavy_max, L._p(p.light),
+                   len(p.light_np), p.light_max, L._p(self.obs), L._p(self.actions), None, L._p(self.status))
+            return
+        for tasks, tnp, mx in ((p.heavy, p.heavy_np, p.heavy_max), (p.light, p.light_np, p.light_max)):
+            if tasks is not None:
+                L.call("coevo_fc_forward_argmax", L._p(self.slab), L._p(tasks), len(tnp), mx, L._p(self.obs),
+                       L._p(self.actions), None, L._p(self.status))
+
     def _cycle_native(self, c):
         p, lib = self.plan, L.load()
         L._check(lib.coevo_mpe_host_observe(self.state.ctypes.data, p.n_games, p.row_game_np.ctypes.data,
                                             p.row_slot_np.ctypes.data, p.n_rows, self.obs_host.data_ptr()),
                  "coevo_mpe_host_observe")
         self.obs.copy_(self.obs_host, non_blocking=True)
-        for tasks, tnp, mx in ((p.heavy, p.heavy_np, p.heavy_max), (p.light, p.light_np, p.light_max)):
-            if tasks is not None:
-                L.call("coevo_fc_forward_argmax", L._p(self.slab), L._p(tasks), len(tnp), mx, L._p(self.obs),
-                       L._p(self.actions), None, L._p(self.status))
+        self._forward()
         self.actions_host.copy_(self.actions, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         L._check(lib.coevo_mpe_host_step(self.state.ctypes.data, p.n_games, self._game_rows32.ctypes.data,
@@ -431,10 +445,7 @@ class HostEnvRollout:
             rows = p.game_rows_np[:, slot]
             o[rows, :arr.shape[1]] = arr
         self.obs.copy_(self.obs_host, non_blocking=True)
-        for tasks, tnp, mx in ((p.heavy, p.heavy_np, p.heavy_max), (p.light, p.light_np, p.light_max)):
-            if tasks is not None:
-                L.call("coevo_fc_forward_argmax", L._p(self.slab), L._p(tasks), len(tnp), mx, L._p(self.obs),
-                       L._p(self.actions), None, L._p(self.status))
+        self._forward()
         self.actions_host.copy_(self.actions, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         acts = self.actions_host.numpy()[p.game_rows_np]  # [n_games, 3]

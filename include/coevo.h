@@ -86,6 +86,13 @@ typedef struct {
  * max_rows_per_task: upper bound of n_rows over the tasks (selects the 8- or 32-row kernel). */
 int coevo_fc_forward_argmax(const float *slab, const coevo_fc_task *tasks, int n_tasks, int max_rows_per_task,
                             const float *obs, int32_t *actions, float *logits, int32_t *status, void *stream);
+/* The same forward (MPE/fcnetwork.py:37-90) for TWO task tables in ONE launch of the lean cycle kernel: `heavy` = nets that
+ * act in many games (tasks of <= 16 rows, matrix-core body), `light` = one task of <= 8 rows per individual (weight streaming
+ * body).  What a host-stepped env (env_mode "host") launches per env-cycle.  Every workgroup must be resident at four per CU:
+ * COEVO_ERR_ARG if n_heavy + n_light exceeds that (launch the two tables with coevo_fc_forward_argmax then). */
+int coevo_fc_forward_merged(const float *slab, const coevo_fc_task *heavy_tasks, int n_heavy, int heavy_max_rows,
+                            const coevo_fc_task *light_tasks, int n_light, int light_max_rows, const float *obs,
+                            int32_t *actions, float *logits, int32_t *status, void *stream);
 
 /* ---------------------------------------------------------------- device-side MPE simple_adversary ---------- */
 /* Replaces env.reset/observe/step/last of play_MPE (utils/game_logic_functions.py:123-212, :217) for E env

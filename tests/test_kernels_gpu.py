@@ -84,6 +84,49 @@ def test_fc_forward_bit_exact_vs_oracle(D, rows_per_task):
         r0 += n
 
 
+@pytest.mark.parametrize("D,heavy_rows,light_rows", [(10, [16, 9, 12], [5, 1, 8, 3, 2, 7]), (8, [13], [5, 5, 5]),
+                                                     (10, [16, 16, 3], [1, 1])])
+def test_fc_forward_merged_bit_exact_vs_oracle(D, heavy_rows, light_rows):
+    """coevo_fc_forward_merged: both task tables of a host-stepped env cycle in one launch of the lean cycle kernel
+    (shared-opponent tasks of <= 16 rows + one task of <= 8 rows per individual), observations given - logits, actions and
+    status against the oracle (MPE/fcnetwork.py:37-90)"""
+    n_h, n_l = len(heavy_rows), len(light_rows)
+    flat = make_nets(n_h + n_l, D, seed=7 + D + n_h)
+    slab = to_slab(flat, D)
+    rows = sum(heavy_rows) + sum(light_rows)
+    g = np.random.Generator(np.random.PCG64(9))
+    obs = np.zeros((rows, L.OBS_STRIDE), dtype=np.float32)
+    obs[:, :D] = g.uniform(-2, 2, size=(rows, D)).astype(np.float32)
+    obs[:, D:] = 123.0    # columns past the net's input width are not inputs (an 8-wide net in a 12-float row)
+    stride, r0, net_of_row = L.fc_slab_stride(D), 0, []
+    heavy, light = np.zeros(n_h, dtype=L.TASK_DTYPE), np.zeros(n_l, dtype=L.TASK_DTYPE)
+    for t, n in enumerate(heavy_rows):
+        heavy[t] = (t * stride, r0, n, D, 0)
+        net_of_row += [t] * n
+        r0 += n
+    for t, n in enumerate(light_rows):
+        light[t] = ((n_h + t) * stride, r0, n, D, 0)
+        net_of_row += [n_h + t] * n
+        r0 += n
+    d_heavy, d_light, d_obs = L.tasks_to_device(heavy), L.tasks_to_device(light), torch.from_numpy(obs).to(DEV)
+    actions = torch.full((rows,), -7, dtype=torch.int32, device=DEV)
+    logits = torch.zeros(rows, L.LOGIT_STRIDE, dtype=torch.float32, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    L.call("coevo_fc_forward_merged", L._p(slab), L._p(d_heavy), n_h, max(heavy_rows), L._p(d_light), n_l, max(light_rows),
+           L._p(d_obs), L._p(actions), L._p(logits), L._p(status))
+    assert status.item() == 0
+    got_a, got_l = actions.cpu().numpy(), logits.cpu().numpy()
+    for r in range(rows):
+        a, lg, st = rp.fc_forward(flat[net_of_row[r]], D, obs[r, :D])
+        assert st == 0
+        assert np.array_equal(got_l[r, :5].view(np.uint32), lg.view(np.uint32)), (r, got_l[r, :5], lg)
+        assert got_a[r] == a
+    # a table the lean kernel cannot hold (a 17-row task) is refused, not launched
+    with pytest.raises(L.CoevoError):
+        L.call("coevo_fc_forward_merged", L._p(slab), L._p(d_heavy), n_h, 17, L._p(d_light), n_l, max(light_rows),
+               L._p(d_obs), L._p(actions), L._p(logits), L._p(status))
+
+
 def test_fc_forward_golden_vectors():
     """HIP forward against logits the reference's own FCNetwork produced (fixture), tolerance = fp32
     summation-order noise of a 512-term dot product; action must agree where the margin is safe."""
