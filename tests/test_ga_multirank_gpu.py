@@ -16,14 +16,14 @@ CFG = dict(generations=3, population=8, hof_size=3, elites_number=2, fitness_sha
            max_evaluation_steps=75)
 
 
-def _train(dist_ctx):
+def _train(dist_ctx, env_mode="device"):
     from coevonet_amd import genetic_algorithm as ga
     from coevonet_amd.game_logic import initialize_env
     torch.manual_seed(5)
     np.random.seed(5)
     args = Bag(algorithm="GA", **CFG)
     env = initialize_env(args)
-    res = ga.genetic_algorithm_train(env, env.agents[0], args, None, rng="device_philox", env_mode="device",
+    res = ga.genetic_algorithm_train(env, env.agents[0], args, None, rng="device_philox", env_mode=env_mode,
                                      dist_ctx=dist_ctx)
     eng = res.engine
     return {"elite_ids": res.elite_ids, "fitness": res.fitness, "eval": [res.rewards[r] for r in ga.ROLES],
@@ -32,12 +32,12 @@ def _train(dist_ctx):
             "games": [g.tolist() for g in res.game_rewards], "shard": (eng.lo, eng.hi)}
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, env_mode="device"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", COEVO_DIST_BACKEND="gloo")
     from coevonet_amd.dist import DistContext
     ctx = DistContext(backend="gloo")
-    ret[rank] = _train(ctx)
+    ret[rank] = _train(ctx, env_mode)
     ctx.shutdown()
 
 
@@ -91,15 +91,18 @@ def test_es_two_ranks_equal_one_rank(extension):
             assert games == single["games"][g][3 * lo:3 * hi]
 
 
-def test_two_ranks_equal_one_rank():
+@pytest.mark.parametrize("env_mode", ["device", "host"])
+def test_two_ranks_equal_one_rank(env_mode):
+    """env_mode "host": every rank's host process steps the env copies of its own games (north_star: "env stepping on the
+    host cores ... population shards split across GPUs")"""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
-    single = _train(None)
+    mp.spawn(_worker, args=(2, port, ret, env_mode), nprocs=2, join=True)
+    single = _train(None, env_mode)
     pop, hof = CFG["population"], CFG["hof_size"]
     for rank in (0, 1):
         got = ret[rank]
