@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Co-GA population evaluation on MPE simple_adversary_v3, pop=200 per GPU, HoF=5, T=200
-(BASELINE.json configs[1]).  One "step" = one full generation: 3*pop*hof training games + the 10 evaluation games of
-the best trio, fitness sharing, ranking, HoF update and (pop-1) mutated offspring per role, all on the device.
+"""Headline benchmark: Co-GA population evaluation on MPE simple_adversary_v3, pop=200, HoF=5, T=200 (BASELINE.json
+configs[1] / `metric`: "pop=200 HoF=5 ... 1/2/4/8 GPU").  One "step" = one full generation: 3*pop*hof training games + the
+10 evaluation games of the best trio, fitness sharing, ranking, HoF update and (pop-1) mutated offspring per role, all on
+the device.  `--gpus N` shards THAT population over N ranks (strong scaling, the metric's own split; `--scaling weak`
+keeps 200 individuals per GPU instead).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -33,6 +35,42 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 class Bag:
     def __init__(self, **kw):
         self.__dict__.update(kw)
+
+
+def compact(o, digits=4):
+    """floats to `digits` significant digits, recursively: the driver keeps 8 KB of this line"""
+    if isinstance(o, float):
+        return float(f"{o:.{digits}g}")
+    if isinstance(o, dict):
+        return {k: compact(v, digits) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [compact(v, digits) for v in o]
+    return o
+
+
+def host_cores():
+    """cores this process may use: the affinity mask cut by the cgroup CPU quota (a GPU box hands a share of a larger host)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        if q != "max":
+            quota = max(1, int(float(q) / float(per) + 0.5))
+    except Exception:
+        pass
+    return {"nproc": os.cpu_count(), "affinity": n, "cgroup_quota": quota, "usable": min(n, quota) if quota else n}
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return None
 
 
 def make_args(pop, hof, elites, limit):
@@ -96,7 +134,8 @@ def cpu_baseline_all_cores(pop, hof, limit, workers=16, budget_s=10.0):
     dt = max(r[2] for r in res)
     games_per_gen = 3 * pop * hof + 10
     return {"value": (games / dt) / games_per_gen, "unit": "generations/s", "env_steps_per_sec": steps / dt,
-            "cores": workers, "kind": "port",
+            "cores": workers, "kind": "port", "host": host_cores(), "cpu_model": cpu_model(),
+            "torch_threads_per_process": torch.get_num_threads(),
             "sample": f"{games} games ({steps} agent-steps) over {workers} processes in {dt:.1f} s"}
 
 
@@ -105,7 +144,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pop-per-gpu", type=int, default=200)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default=None, help="ga / es under --gpus N: strong (default) = "
+                    "BASELINE's metric, ONE population (--pop, 200) sharded over the N ranks; weak = --pop-per-gpu "
+                    "individuals on every GPU.  (dqn-ga / dqn-es are the per-GPU shards of configs[3] / [4]: always weak)")
+    ap.add_argument("--pop", type=int, default=None, help="total population under --scaling strong (default 200; es: 1000)")
+    ap.add_argument("--pop-per-gpu", type=int, default=None, help="per-GPU population under --scaling weak (default 200); "
+                    "given alone it selects weak scaling")
+    ap.add_argument("--shard-of", type=int, default=0, metavar="N", help="ga on ONE GPU: run rank 0 of an N-rank strong-"
+                    "scaling split of the population (its games, its breeding, the elite rebuild; the all-gather replaced "
+                    "by tiling its own shard) - the per-GPU half of the scaling curve")
     ap.add_argument("--hof", type=int, default=5)
     ap.add_argument("--elites", type=int, default=2)
     ap.add_argument("--limit", type=int, default=200)
@@ -127,7 +174,7 @@ def main():
                          "configs[3] / configs[4] over the synthetic Atari-shaped env")
     ap.add_argument("--extension", action="store_true", help="es / dqn-es: antithetic pairs + centered ranks (BASELINE's "
                     "wording of configs[2]; NOT the reference's algorithm)")
-    ap.add_argument("--es-pop-per-gpu", type=int, default=1000)
+    ap.add_argument("--es-pop-per-gpu", type=int, default=None)
     ap.add_argument("--dqn-pop-per-gpu", type=int, default=None, help="default 50 (dqn-ga) / 250 (dqn-es)")
     ap.add_argument("--dqn-hof", type=int, default=10)
     ap.add_argument("--channels", type=int, default=4, help="frame channels: 4 = BASELINE's 84x84x4; the reference's "
@@ -137,6 +184,12 @@ def main():
     ap.add_argument("--cohorts", type=int, default=None, help="independent game cohorts per rollout (default: the "
                     "engine's DEFAULT_COHORTS)")
     a = ap.parse_args()
+    if a.scaling is None:
+        a.scaling = "weak" if (a.pop_per_gpu is not None or a.es_pop_per_gpu is not None) else "strong"
+    if a.scaling == "strong" and a.workload in ("ga", "es"):
+        total = a.pop or (200 if a.workload == "ga" else 1000)
+        if total % a.gpus:
+            raise SystemExit(f"--scaling strong: population {total} is not divisible by --gpus {a.gpus}")
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks as fresh child processes (one per GPU, torch.distributed.run)
@@ -154,7 +207,13 @@ def main():
     from coevonet_amd.dist import DistContext
 
     ctx = DistContext()
-    if ctx.world != a.gpus:
+    if a.shard_of:
+        if ctx.world != 1 or a.workload != "ga" or a.shard_of < 2:
+            raise SystemExit("--shard-of N (N >= 2) is a one-GPU rehearsal of the ga workload")
+        from coevonet_amd.dist import ShardRehearsal
+        ctx = ShardRehearsal(0, a.shard_of)
+        a.gpus = 1
+    elif ctx.world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={ctx.world}: launch with torch.distributed.run")
     dev_index = ctx.local_rank % max(torch.cuda.device_count(), 1)  # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(dev_index)
@@ -168,22 +227,36 @@ def main():
         out = run_es(a, ctx, dev)
     else:
         out = run_dqn(a, ctx, dev, a.workload[4:])
-    out.update({"n_gpus": ctx.world, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "weak",
+    scaling = a.scaling if a.workload in ("ga", "es") else "weak"
+    rehearsal = bool(getattr(ctx, "rehearsal", False))
+    real_world = 1 if rehearsal else ctx.world
+    out.update({"n_gpus": real_world, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": scaling,
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
-                "dist_backend": (torch.distributed.get_backend() if ctx.world > 1 else None),
-                "rccl_ranks": (torch.distributed.get_world_size() if ctx.world > 1 else 1)})
-    if ctx.world > 1:
+                "dist_backend": (torch.distributed.get_backend() if real_world > 1 else None),
+                "rccl_ranks": (torch.distributed.get_world_size() if real_world > 1 else 1)})
+    if rehearsal:
+        out["rehearsal"] = (f"rank 0 of {ctx.world} of a strong-scaling split on ONE GPU: its games, breeding and elite "
+                            "rebuild; the all-gather replaced by tiling its own shard (no collective)")
+    if real_world > 1:
         us = ctx.gather_times_us()
         # collectives of the timed region on this rank's stream (HIP events): separates exchange from compute in a scaling
         # record.  RCCL: the stream-ordered all-gather itself; gloo (ranks sharing a device): host-staged, not xGMI.
         out["allgather_us"] = {"per_generation": float(np.sum(us)) / max(a.steps, 1), "calls_per_generation":
                                len(us) / max(a.steps, 1), "max_call": float(np.max(us)) if us else 0.0,
                                "transport": "rccl" if torch.distributed.get_backend() == "nccl" else "gloo (host-staged)"}
+    if real_world > 1 and a.workload in ("ga", "es") and scaling == "strong" and not a.no_extra:
+        # the other reading of "N GPUs": per-GPU work fixed (every rank takes part; short run)
+        import copy
+        w = copy.copy(a)
+        w.scaling, w.steps, w.warmup, w.no_cpu_baseline, w.pop_per_gpu, w.es_pop_per_gpu = "weak", 5, 2, True, None, None
+        r = run_ga(w, ctx, dev) if a.workload == "ga" else run_es(w, ctx, dev)
+        out["weak_scaling"] = {"population": r["config"]["population"], "gens_per_sec": r["gens_per_sec"],
+                               "value": r["value"], "ms_per_step": r["ms_per_step"]}
     if ctx.rank == 0:
-        if a.workload == "ga" and ctx.world == 1 and not a.no_extra:
+        if a.workload == "ga" and ctx.world == 1 and not a.no_extra and not a.shard_of:
             out["extra"] = extras(a, ctx, dev)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(compact(out)), flush=True)
     ctx.shutdown()
 
 
@@ -211,9 +284,13 @@ def run_es(a, ctx, dev, pop_per_gpu=None, extension=None):
     ranks: BASELINE's wording, NOT in the reference - labelled in the output)."""
     from coevonet_amd.evolutionary_strategy import ESTrainer
     from coevonet_amd.game_logic import initialize_env
-    ppg = pop_per_gpu or a.es_pop_per_gpu
     ext = a.extension if extension is None else extension
-    pop = ppg * ctx.world
+    if pop_per_gpu is None and a.scaling == "strong":
+        pop = a.pop or 1000
+        ppg = pop // ctx.world
+    else:
+        ppg = pop_per_gpu or a.es_pop_per_gpu or 1000
+        pop = ppg * ctx.world
     args = make_args(pop, 1, 2, a.limit)
     args.algorithm, args.fitness_sharing = "ES", False
     args.coevo_antithetic = args.coevo_centered_rank = bool(ext)
@@ -229,7 +306,7 @@ def run_es(a, ctx, dev, pop_per_gpu=None, extension=None):
     # the dominant launch of a Co-ES generation: one env-cycle of one cohort, every individual's weight set streamed once
     es_traffic, es_src = pmc_traffic("cfg3_es", "fc_cycle_kernel")   # (both modes launch the same kernel on the same bytes)
     return {"metric": "env-steps/sec (agent-steps of the whole job; generations/sec in gens_per_sec), Co-ES "
-                      "simple_adversary_v3 pop=1000/GPU",
+                      f"simple_adversary_v3 pop={pop}",
             "value": gens * eng.steps_per_generation, "unit": "env-steps/s", "gens_per_sec": gens,
             "ms_per_step": 1e3 * dt / a.steps,
             "config": {"workload": f"Co-ES simple_adversary_v3 pop={pop} ({ppg}/GPU) sigma=0.05 lr=0.1 T={a.limit} "
@@ -353,19 +430,35 @@ def pmc_traffic(workload, kernel_substr):
 
 def extras(a, ctx, dev):
     """short, bounded runs of the other BASELINE configs on the same GPU, carried in the headline JSON so that the
-    driver's record holds them (each is also its own --workload / flag set)"""
+    driver's record holds them (each is also its own --workload / flag set; the prose - kernel, timing, workload - is in
+    that run's own line, here only numbers: the driver keeps 8 KB of this line)"""
     import copy
     import gc
+    from coevonet_amd.dist import ShardRehearsal
     ex = {}
-    keep = ("value", "unit", "gens_per_sec", "ms_per_step", "roofline")
+
+    def slim_rl(rl):
+        o = {k: rl[k] for k in ("bound", "frac", "avg_launch_ms", "traffic") if rl.get(k) is not None}
+        if "generation" in rl:
+            o["generation_frac"] = rl["generation"]["frac"]
+        if rl.get("rollout_aggregate"):
+            o["rollout_frac"] = rl["rollout_aggregate"]["frac"]
+            o["rollout_span_ms"] = rl["rollout_aggregate"]["rollout_span_ms"]
+        if "second_kernel" in rl:
+            o["second"] = {k: rl["second_kernel"][k] for k in ("bound", "frac", "avg_launch_ms", "traffic")
+                           if rl["second_kernel"].get(k) is not None}
+        return o
 
     def leg(name, fn):
         try:
             r = fn()
-            ex[name] = {k: r[k] for k in keep if k in r}
-            ex[name]["workload"] = r["config"]["workload"]
+            ex[name] = {"gens_per_sec": r["gens_per_sec"], "ms_per_step": r["ms_per_step"], "env_steps_per_sec": r["value"]}
+            if r.get("roofline"):
+                ex[name]["roofline"] = slim_rl(r["roofline"])
+            if r.get("host_env"):
+                ex[name]["host_env"] = r["host_env"]
         except Exception as e:
-            ex[name] = {"error": repr(e)}
+            ex[name] = {"error": repr(e)[:200]}
         gc.collect()
         torch.cuda.empty_cache()
 
@@ -374,23 +467,32 @@ def extras(a, ctx, dev):
     # SURVEY 8d "two variants, both reported": the env built with max_cycles >= 67 so that T = 200 binds
     t200 = copy.copy(b)
     t200.max_cycles = 67
-    leg("cfg2_T200_env_max_cycles_67", lambda: run_ga(t200, ctx, dev))
+    leg("cfg2_T200", lambda: run_ga(t200, ctx, dev))
     # north_star's literal first configuration: the env vectorised on the host cores, observations up / actions down over
-    # PCIe every cycle - the PCIe-and-Python-inclusive rate, never the headline
+    # PCIe every cycle - the PCIe-inclusive rate, never the headline
     host = copy.copy(b)
     host.env, host.steps, host.warmup = "host", 20, 3
-    leg("cfg2_host_env_mode", lambda: run_ga(host, ctx, dev))
-    leg("cfg3_coes_reference_exact", lambda: run_es(b, ctx, dev, extension=False))
-    leg("cfg3_coes_extension_antithetic_centered_rank", lambda: run_es(b, ctx, dev, extension=True))
+    leg("cfg2_host_env", lambda: run_ga(host, ctx, dev))
+    # the metric's own split (pop 200 over 2 / 4 / 8 GPUs): what ONE rank of it does on this GPU (dist.ShardRehearsal)
+    for n in (2, 4, 8):
+        sh = copy.copy(b)
+        sh.steps, sh.warmup = 20, 3
+        leg(f"cfg2_shard_1_of_{n}", lambda: run_ga(sh, ShardRehearsal(0, n), dev))
+    leg("cfg3_reference_exact", lambda: run_es(b, ctx, dev, extension=False))
+    leg("cfg3_extension", lambda: run_es(b, ctx, dev, extension=True))
     # (two timed generations under-reported cfg5 by 15 %: the first ones carry one-off host work)
-    leg("cfg4_coga_deepqn_per_gpu_shard", lambda: run_dqn(b, ctx, dev, "ga"))
-    leg("cfg5_coes_deepqn_per_gpu_shard", lambda: run_dqn(b, ctx, dev, "es"))
+    leg("cfg4_shard", lambda: run_dqn(b, ctx, dev, "ga"))
+    leg("cfg5_shard", lambda: run_dqn(b, ctx, dev, "es"))
     # six frame planes: what the reference's wrapper stack yields (frame_stack_v1(4) + agent_indicator_v0,
     # utils/game_logic_functions.py:50-53; Atari/atari_agent.py:20); BASELINE.json words the configs as 84x84x4
     c6 = copy.copy(b)
     c6.channels = 6
-    leg("cfg4_coga_deepqn_per_gpu_shard_6_planes", lambda: run_dqn(c6, ctx, dev, "ga"))
-    leg("cfg5_coes_deepqn_per_gpu_shard_6_planes", lambda: run_dqn(c6, ctx, dev, "es"))
+    leg("cfg4_shard_6_planes", lambda: run_dqn(c6, ctx, dev, "ga"))
+    leg("cfg5_shard_6_planes", lambda: run_dqn(c6, ctx, dev, "es"))
+    ex["legend"] = ("cfg2_T200: env max_cycles 67; cfg2_host_env: env on the host cores (PCIe-inclusive); cfg2_shard_1_of_N: "
+                    "rank 0 of pop 200 over N GPUs rehearsed on this GPU, no collective; cfg3: Co-ES pop 1000 (extension = "
+                    "antithetic + centered ranks, not in the reference); cfg4 / cfg5: per-GPU shards (pop 50, HoF 10 / pop 250) "
+                    "over DeepQN on SYNTHETIC 84x84x4 frames (6_planes: 84x84x6)")
     return ex
 
 
@@ -399,7 +501,12 @@ def run_ga(a, ctx, dev):
     from coevonet_amd.game_logic import initialize_env
     from coevonet_amd.genetic_algorithm import GATrainer
 
-    pop = a.pop_per_gpu * ctx.world  # weak scaling: per-GPU work fixed
+    if a.scaling == "strong":   # BASELINE's metric: ONE population, sharded by index over the ranks
+        pop = a.pop or 200
+        ppg = pop // ctx.world
+    else:                       # weak: per-GPU work fixed
+        ppg = a.pop_per_gpu or 200
+        pop = ppg * ctx.world
     args = make_args(pop, a.hof, a.elites, a.limit)
     args.generations = a.steps + a.warmup  # sizes the device-resident evaluation / sigma histories
     if a.cohorts is not None:
@@ -442,16 +549,27 @@ def run_ga(a, ctx, dev):
     light_ms = eng.ro.light_times_ms() if timed else []
     if timed:
         eng.ro.time_light = False
+    host_phase = None
+    if a.env == "host" and getattr(eng.ro, "ctx", None):
+        # two more generations with HIP events around every cohort-cycle's copies and launch + host clocks around the
+        # waits and the env (outside the timed region: the events cost a few microseconds per cycle)
+        eng.ro.phase_us = np.zeros(6)
+        ph = []
+        for _ in range(2):
+            tr.step()
+            ph.append(eng.ro.phase_us.copy())
+        eng.ro.phase_us = None
+        host_phase = np.mean(ph, axis=0)
     tr.finish()
 
     steps_per_gen = eng.steps_per_generation  # agent-steps of the whole job per generation
     gens_per_s = a.steps / dt
     out = {
         "metric": "env-steps/sec (agent-steps of the whole job; generations/sec in gens_per_sec), Co-GA "
-                  "simple_adversary_v3 pop=200/GPU HoF=5",
+                  f"simple_adversary_v3 pop={pop} HoF={a.hof}",
         "value": gens_per_s * steps_per_gen, "unit": "env-steps/s", "gens_per_sec": gens_per_s,
         "ms_per_step": 1e3 * dt / a.steps,
-        "config": {"workload": f"Co-GA simple_adversary_v3 pop={pop} ({a.pop_per_gpu}/GPU) HoF={a.hof} "
+        "config": {"workload": f"Co-GA simple_adversary_v3 pop={pop} ({ppg}/GPU) HoF={a.hof} "
                                f"elites={a.elites} T={a.limit} (env max_cycles={a.max_cycles} caps a game at "
                                f"{3 * a.max_cycles} agent-steps" + (", as in the reference" if a.max_cycles == 25 else
                                                                      ": the T=200 variant, SURVEY 8d cfg 2-T200") +
@@ -460,6 +578,29 @@ def run_ga(a, ctx, dev):
                    "agent_steps_per_generation": steps_per_gen, "env": a.env, "offspring": "device_philox",
                    "parallelism": f"population shard x{ctx.world}" if ctx.world > 1 else "single GPU"},
     }
+    if ctx.rank == 0 and host_phase is not None:
+        K = eng.plan.n_cohorts
+        nets = {}
+        for arr in (eng.plan.heavy_np, eng.plan.light_np):
+            for t in arr:
+                nets[int(t["net_off"])] = L.fc_param_count(int(t["D"])) * 4
+        cycle_bytes = sum(nets.values()) + eng.plan.n_rows * (4 * 10 + 4)
+        launch_ms = float(host_phase[4]) * 1e-3
+        ach = cycle_bytes / K / max(launch_ms, 1e-9) / 1e6
+        out["host_env"] = {"host_cores": eng.ro.threads, "cohorts": K, "zero_copy": bool(eng.ro.zero_copy),
+                           "per_cohort_cycle_us": {"host_wait_for_actions": float(host_phase[0]),
+                                                   "host_step_observe": float(host_phase[1]),
+                                                   "host_enqueue": float(host_phase[2]), "h2d_obs": float(host_phase[3]),
+                                                   "launch": float(host_phase[4]), "d2h_actions": float(host_phase[5])},
+                           "pcie_bytes_per_cycle": eng.plan.n_rows * (4 * L.OBS_STRIDE + 4)}
+        out["roofline"] = {"bound": "hbm", "kernel": "fc_cycle16_kernel<R, MODE_OBS> (observations given; one launch per "
+                           "cohort and env-cycle)", "timing": "HIP events on the cohort's stream (2 extra generations)",
+                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_launch": cycle_bytes / K, "avg_launch_ms": launch_ms,
+                           "concurrent_launches": K,
+                           "generation": {"algorithmic_bytes": cycle_bytes * eng.n_cycles,
+                                          "achieved": cycle_bytes * eng.n_cycles * gens_per_s / 1e9,
+                                          "frac": cycle_bytes * eng.n_cycles * gens_per_s / 1e9 / HBM_PEAK_GBS}}
     if ctx.rank == 0:
         if light_ms:
             d = light_ms
@@ -502,7 +643,7 @@ def run_ga(a, ctx, dev):
             else:
                 kernel_id = f"fc_policy_kernel<{R}, 2>"
             traffic, traffic_note = None, None
-            if a.pop_per_gpu == 200 and a.hof == 5 and a.max_cycles == 25:
+            if pop == 200 and ctx.world == 1 and a.hof == 5 and a.max_cycles == 25:
                 # HBM bytes per launch of this kernel from the PMC counters (FETCH_SIZE/WRITE_SIZE, separate rocprofv3
                 # passes of this same command, gfx950 correction applied) - collected offline, see the file
                 traffic, traffic_note = pmc_traffic("headline", kernel_id)
@@ -532,10 +673,10 @@ def run_ga(a, ctx, dev):
             out["roofline"]["generation"] = {"algorithmic_bytes": gen_bytes, "achieved": gen_bytes * gens_per_s / 1e9,
                                              "frac": gen_bytes * gens_per_s / 1e9 / HBM_PEAK_GBS}
         if not a.no_cpu_baseline and ctx.world == 1:
-            out["cpu_baseline"] = cpu_baseline(a.pop_per_gpu, a.hof, a.limit)
+            out["cpu_baseline"] = cpu_baseline(pop, a.hof, a.limit)
             try:
-                workers = min(16, os.cpu_count() or 1)
-                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(a.pop_per_gpu, a.hof, a.limit, workers=workers)
+                workers = host_cores()["usable"]   # one process per core this box gives us (count in `cores`)
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(pop, a.hof, a.limit, workers=min(workers, 128))
             except Exception as e:  # the single-core figure above is the contractual one
                 out["cpu_baseline_all_cores"] = {"error": repr(e)}
     del tr

@@ -323,6 +323,32 @@ extern "C" int coevo_mpe_host_step(double *state, int n_games, const int32_t *ga
     return COEVO_OK;
 }
 
+// One slice of a game list on the calling thread: world step `cycle` (cycle < 0: none) of games[lo..hi), then (observe != 0)
+// the observations of their three rows.  The unit of work a host core gets from coevo_mpe_host_rollout; no argument scan
+// (the caller validated the tables once), so that T threads on T slices cost what one thread costs on the whole list / T.
+extern "C" int coevo_mpe_host_step_games(double *state, int n_games, const int32_t *game_rows, const int32_t *actions,
+                                         int cycle, const int32_t *game_limit, int pos_first, const int32_t *games, int lo,
+                                         int hi, int observe, float *obs)
+{
+    if (!state || !game_rows || !games || n_games <= 0 || lo < 0 || hi < lo || (cycle >= 0 && !actions) || (observe && !obs))
+        return COEVO_ERR_ARG;
+    for (int i = lo; i < hi; ++i) {
+        const int g = games[i];
+        if (cycle >= 0) coevo::mpe_step_game(state, n_games, game_rows, actions, cycle, game_limit, pos_first, g);
+        if (observe) {
+            coevo::MpeGame s;
+            coevo::mpe_load_game(state, n_games, g, s);
+            for (int slot = 0; slot < 3; ++slot) {
+                float *o = obs + (size_t)game_rows[3 * g + slot] * COEVO_OBS_STRIDE;
+                coevo::mpe_obs_from_game(s, slot, o);
+                o[10] = 0.0f;
+                o[11] = 0.0f;
+            }
+        }
+    }
+    return COEVO_OK;
+}
+
 extern "C" int coevo_mpe_final_step(const double *state, int n_games, const int32_t *actions_by_game, int cycle,
                                     const int32_t *game_limit, int pos_first, double *rewards, void *stream)
 {

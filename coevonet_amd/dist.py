@@ -40,7 +40,44 @@ def choose_backend(requested, env, cuda_available, device_count):
     the host - they get nccl."""
     lws = env.get("LOCAL_WORLD_SIZE")
     shared = lws is not None and cuda_available and int(lws) > device_count
-    return requested or env.get("COEVO_DIST_BACKEND") or ("gloo" if shared else "nccl"), shared
+    # (no GPU at all - a CPU-only or rehearsal host: RCCL cannot initialise there either)
+    return requested or env.get("COEVO_DIST_BACKEND") or ("gloo" if (shared or not cuda_available) else "nccl"), shared
+
+
+class ShardRehearsal:
+    """Rank `rank` of `world` WITHOUT the other ranks: the per-GPU half of a population-sharded run on one GPU (bench.py's
+    shard legs).  This rank plays, breeds and rebuilds exactly what rank `rank` of a real run would; the all-gather is
+    replaced by tiling this rank's own (reward, distance) shard over the other ranks' index ranges - the same pack / unpack
+    copies, no collective.  Results are NOT those of the real run (the other shards' fitness is made up); the work is."""
+
+    rehearsal = True
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.local_rank = int(rank), int(world), 0
+
+    def _tile(self, eng):
+        n = eng.hi - eng.lo
+        for r in range(self.world):
+            if r != self.rank:
+                eng.last_reward[:, r * n:(r + 1) * n] = eng.last_reward[:, eng.lo:eng.hi]
+                eng.dist_all[:, r * n:(r + 1) * n] = eng.dist_all[:, eng.lo:eng.hi]
+
+    gather_ga = gather_ga2 = _tile
+
+    def start_gather_timing(self):
+        pass
+
+    def gather_times_us(self):
+        return []
+
+    def barrier(self):
+        pass
+
+    def max_over_ranks(self, seconds, device):
+        return seconds
+
+    def shutdown(self):
+        pass
 
 
 class DistContext:

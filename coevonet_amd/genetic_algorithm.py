@@ -169,7 +169,10 @@ class GAEngine:
         heavy_rows = int(os.environ.get("COEVO_HEAVY_ROWS", "16"))
         # cohorts = contiguous ranges of this rank's individuals (so that offspring can be bred cohort by cohort and a
         # cohort's chain can start while the next cohort is still being bred); the evaluation games go with the last
-        self.K = max(1, min(int(cohorts), self.n_local)) if env == "device" else 1
+        # (env on the host cores: the cohorts ALTERNATE between the cores and the GPU - COEVO_HOST_COHORTS, default 2)
+        self.K = max(1, min(int(cohorts) if env == "device" else int(os.environ.get("COEVO_HOST_COHORTS", "2")),
+                            self.n_local))
+        row_order = "class" if env == "device" else "cohort"
         self._set_cohort_bounds()
         game_cohort = None
         if self.K > 1:
@@ -179,11 +182,12 @@ class GAEngine:
             game_cohort = np.concatenate([per_ind, per_ind, per_ind, np.full(N_EVAL, self.K - 1)]).astype(np.int32)
         try:
             self.plan = RolloutPlan(np.array(games), net_off, net_D, device=device, heavy_rows=heavy_rows,
-                                    n_cohorts=self.K, game_cohort=game_cohort)
+                                    n_cohorts=self.K, game_cohort=game_cohort, row_order=row_order)
         except ValueError:  # tiny populations: the shared opponents have so few rows that they tie all games together
             self.K = 1
             self._set_cohort_bounds()
-            self.plan = RolloutPlan(np.array(games), net_off, net_D, device=device, heavy_rows=heavy_rows)
+            self.plan = RolloutPlan(np.array(games), net_off, net_D, device=device, heavy_rows=heavy_rows,
+                                    row_order=row_order)
         if env == "device":
             self.ro = DeviceRollout(self.plan, self.slab, env_seed=env_seed, timing_pairs=timing_pairs)
         else:

@@ -70,6 +70,20 @@ class RolloutDesc(C.Structure):
                 ("merged", C.c_int32), ("concurrent_hint", C.c_int32)]
 
 
+class HostCohort(C.Structure):        # coevo_host_cohort
+    _fields_ = [("heavy", C.c_void_p), ("light", C.c_void_p), ("games", C.c_void_p), ("n_heavy", C.c_int32),
+                ("heavy_max_rows", C.c_int32), ("n_light", C.c_int32), ("light_max_rows", C.c_int32),
+                ("n_games", C.c_int32), ("row_first", C.c_int32), ("n_rows", C.c_int32), ("reserved", C.c_int32)]
+
+
+class HostRolloutDesc(C.Structure):   # coevo_host_rollout_desc
+    _fields_ = [("slab", C.c_void_p), ("state", C.c_void_p), ("game_rows", C.c_void_p), ("game_limit", C.c_void_p),
+                ("obs_host", C.c_void_p), ("obs_dev", C.c_void_p), ("actions_host", C.c_void_p),
+                ("actions_dev", C.c_void_p), ("status", C.c_void_p), ("cohorts", C.c_void_p), ("phase_us", C.c_void_p),
+                ("n_games", C.c_int32), ("n_rows", C.c_int32), ("n_cycles", C.c_int32), ("n_cohorts", C.c_int32),
+                ("pos_first", C.c_int32), ("zero_copy", C.c_int32)]
+
+
 class GaSelectRole(C.Structure):
     _fields_ = [("dist", C.c_void_p), ("rewards", C.c_void_p), ("diversity", C.c_void_p), ("fitness", C.c_void_p),
                 ("order", C.c_void_p), ("best_dist", C.c_void_p), ("game_first", C.c_int32), ("slot", C.c_int32)]
@@ -108,6 +122,14 @@ _SIGS = {
     "coevo_mpe_host_reset": (C.c_int, [C.c_void_p, C.c_int, PCG64State, C.c_void_p]),
     "coevo_mpe_host_observe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "coevo_mpe_host_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "coevo_mpe_host_step_games": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                            C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "coevo_host_rollout_create": (C.c_void_p, [C.c_int, C.c_int]),
+    "coevo_host_rollout_destroy": (None, [C.c_void_p]),
+    "coevo_host_rollout_threads": (C.c_int, [C.c_void_p]),
+    "coevo_host_rollout_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "coevo_mpe_host_rollout": (C.c_int, [C.c_void_p, C.POINTER(HostRolloutDesc), C.c_void_p]),
     "coevo_mpe_rewards": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "coevo_mpe_policy_cycle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -34,7 +34,7 @@ class RolloutPlan:
     net_off / net_D: per net id, float offset inside the slab and observation width."""
 
     def __init__(self, game_nets, net_off, net_D, device="cuda", heavy_rows=HEAVY_ROWS, n_cohorts=1,
-                 game_cohort=None, split_rows=None):
+                 game_cohort=None, split_rows=None, row_order="class"):
         game_nets = np.asarray(game_nets, dtype=np.int64)
         self.n_games = int(game_nets.shape[0])
         by_net = {}
@@ -79,17 +79,34 @@ class RolloutPlan:
         heavy = [self._xcd_order(h) for h in heavy]
         self.heavy_begin_np = np.cumsum([0] + [len(h) for h in heavy]).astype(np.int32)
         self.light_begin_np = np.cumsum([0] + [len(x) for x in light]).astype(np.int32)
-        heavy = [t for h in heavy for t in h]
-        light = [t for x in light for t in x]
-        # heavy tasks first in row space; inside each class keep first-game order (locality of the state reads)
+        # Row numbering.  "class" (device env): all shared-opponent tasks' rows first, then the per-individual tasks'; inside
+        # each class first-game order (locality of the state reads).  "cohort" (env on the host cores): cohort by cohort, so
+        # that a cohort's observations / actions are ONE contiguous range of the staging buffers (one copy each way).
+        # The task tables are [class][cohort] in both; a task names its first row itself.
+        assert row_order in ("class", "cohort")
         row_game, row_slot = [], []
-        tasks = {"heavy": [], "light": []}
-        for name, lst in (("heavy", heavy), ("light", light)):
-            for net, rows in lst:
-                tasks[name].append((int(net_off[net]), len(row_game), len(rows), int(net_D[net]), 0))
+        tasks = {"heavy": [[] for _ in range(self.n_cohorts)], "light": [[] for _ in range(self.n_cohorts)]}
+        cohort_rows = np.zeros(self.n_cohorts + 1, dtype=np.int64)
+
+        def number(name, k):
+            for net, rows in (heavy if name == "heavy" else light)[k]:
+                tasks[name][k].append((int(net_off[net]), len(row_game), len(rows), int(net_D[net]), 0))
                 for g, slot in rows:
                     row_game.append(g)
                     row_slot.append(slot)
+
+        if row_order == "class":
+            for name in ("heavy", "light"):
+                for k in range(self.n_cohorts):
+                    number(name, k)
+            self.cohort_row_begin_np = None
+        else:
+            for k in range(self.n_cohorts):
+                number("heavy", k)
+                number("light", k)
+                cohort_rows[k + 1] = len(row_game)
+            self.cohort_row_begin_np = cohort_rows
+        tasks = {name: [t for per in tasks[name] for t in per] for name in tasks}
         self.n_rows = len(row_game)
         assert self.n_rows == 3 * self.n_games
         game_rows = np.zeros((self.n_games, 3), dtype=np.int32)
@@ -363,11 +380,15 @@ class DeviceRollout:
 
 class HostEnvRollout:
     """Same plan, env stepped on the host cores (struct-of-arrays); per cycle the observations go up and the actions come
-    back over PCIe.  Results are bit-identical with DeviceRollout.  impl = "native": coevo_mpe_host_observe /
-    coevo_mpe_host_step, the env kernels' own bodies compiled for the host (1.5 ms of NumPy per cycle at cfg 2 -> 0.1 ms);
-    impl = "numpy": coevonet_amd/mpe/simple_adversary.py's VecSimpleAdversary, the form the env fixtures are stated in."""
+    back over PCIe.  Results are bit-identical with DeviceRollout.
 
-    def __init__(self, plan: RolloutPlan, slab: torch.Tensor, env_seed=sa.ENV_SEED, impl=None):
+    impl = "native" (default): ONE C-ABI call per rollout, coevo_mpe_host_rollout (csrc/host_rollout.hip) - the plan's
+    cohorts alternate: while one cohort's copies and policy launch are in flight on its own stream, the host cores
+    (COEVO_HOST_THREADS, default min(8, cores)) step the next cohort's games; per-cohort event polls are the only waits.
+    impl = "numpy": coevonet_amd/mpe/simple_adversary.py's VecSimpleAdversary, the form the env fixtures are stated in, one
+    blocking cycle at a time (1.5 ms of NumPy per cycle at cfg 2)."""
+
+    def __init__(self, plan: RolloutPlan, slab: torch.Tensor, env_seed=sa.ENV_SEED, impl=None, threads=None):
         self.impl = impl or os.environ.get("COEVO_HOST_ENV", "native")
         if self.impl not in ("native", "numpy"):
             raise ValueError(f"host env implementation {self.impl!r}: 'native' or 'numpy'")
@@ -382,8 +403,48 @@ class HostEnvRollout:
         self.env_seed = env_seed
         self.set_limits(np.zeros(plan.n_games, dtype=np.int64))
         self.rewards = None
-        self._streams = {}
         self._merged = None
+        self.ctx = None
+        self.phase_us = None          # set to a float64[6] array to collect the per-cohort-cycle breakdown
+        self.zero_copy = os.environ.get("COEVO_HOST_ZERO_COPY", "0") == "1"
+        if self.impl == "native":
+            p = plan
+            K = p.n_cohorts
+            if K > 1 and p.cohort_row_begin_np is None:
+                raise ValueError("a host-stepped rollout with several cohorts needs a plan built with row_order='cohort'")
+            if threads is None:
+                threads = int(os.environ.get("COEVO_HOST_THREADS", "0")) or min(8, os.cpu_count() or 1)
+            self.ctx = L.load().coevo_host_rollout_create(int(threads), K)
+            if not self.ctx:
+                raise L.CoevoError("coevo_host_rollout_create failed")
+            self.threads = int(L.load().coevo_host_rollout_threads(self.ctx))
+            self._game_rows32 = np.ascontiguousarray(p.game_rows_np, dtype=np.int32)
+            rows = p.cohort_row_begin_np if p.cohort_row_begin_np is not None else np.array([0, p.n_rows])
+            self._cohort_games = [np.ascontiguousarray(np.nonzero(p.game_cohort_np == k)[0], dtype=np.int32)
+                                  for k in range(K)]
+            tsz = L.TASK_DTYPE.itemsize
+            self._cohorts = (L.HostCohort * K)()
+            for k in range(K):
+                hb, he = int(p.heavy_begin_np[k]), int(p.heavy_begin_np[k + 1])
+                lb, le = int(p.light_begin_np[k]), int(p.light_begin_np[k + 1])
+                self._cohorts[k] = L.HostCohort(
+                    heavy=(p.heavy.data_ptr() + hb * tsz) if he > hb else None,
+                    light=(p.light.data_ptr() + lb * tsz) if le > lb else None,
+                    games=self._cohort_games[k].ctypes.data, n_heavy=he - hb,
+                    heavy_max_rows=int(max(p.heavy_np["n_rows"][hb:he], default=0)), n_light=le - lb,
+                    light_max_rows=int(max(p.light_np["n_rows"][lb:le], default=0)),
+                    n_games=len(self._cohort_games[k]), row_first=int(rows[k]), n_rows=int(rows[k + 1] - rows[k]))
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            L.load().coevo_host_rollout_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def set_limits(self, limits_np):
         self.limits = np.asarray(limits_np, dtype=np.int64)
@@ -397,7 +458,6 @@ class HostEnvRollout:
             self.state = np.zeros((L.MPE_STATE_DOUBLES, n), dtype=np.float64)   # (PCG64 jump-ahead to each game's ordinal)
             L._check(L.load().coevo_mpe_host_reset(self.state.ctypes.data, n, L.PCG64State.from_seed(self.env_seed),
                                                    ordinals.ctypes.data), "coevo_mpe_host_reset")
-            self._game_rows32 = np.ascontiguousarray(self.plan.game_rows_np, dtype=np.int32)
             return
         stream = sa.ResetStream(self.env_seed, skip_initial=False)
         goal, apos, lpos = stream.take(int(ordinals.max()) + 1)
@@ -406,37 +466,28 @@ class HostEnvRollout:
         self.rg_prev = np.zeros(n)
 
     def _forward(self):
-        """the policy step of every row: both task tables in one launch of the lean cycle kernel when they fit it
-        (<= 16-row shared-opponent tasks, everything resident), else one launch per table"""
+        """(numpy env) the policy step of every row: both task tables in one launch of the lean cycle kernel when they fit
+        it (<= 16-row shared-opponent tasks, <= 8-row per-individual tasks, everything resident), else one launch per table"""
         p = self.plan
         if self._merged is None:
-            self._merged = (p.heavy is not None and p.light is not None and p.heavy_max <= 16 and
+            self._merged = (p.heavy is not None and p.light is not None and p.heavy_max <= 16 and p.light_max <= 8 and
                             len(p.heavy_np) + len(p.light_np) <= 4 * torch.cuda.get_device_properties(self.obs.device).multi_processor_count)
         if self._merged:
-            L.call("coevo_fc_forward_merged", L._p(self.slab), L._p(p.heavy), len(p.heavy_np), p.heavy_max, L._p(p.light),
-                   len(p.light_np), p.light_max, L._p(self.obs), L._p(self.actions), None, L._p(self.status))
-            return
+            rc = L.load().coevo_fc_forward_merged(L._p(self.slab), L._p(p.heavy), len(p.heavy_np), p.heavy_max, L._p(p.light),
+                                                  len(p.light_np), p.light_max, L._p(self.obs), L._p(self.actions), None,
+                                                  L._p(self.status), L._stream())
+            if rc == 0:
+                return
+            if rc != -1:
+                L._check(rc, "coevo_fc_forward_merged")
+            self._merged = False   # COEVO_ERR_ARG: the library's own residency check disagrees - one launch per table
         for tasks, tnp, mx in ((p.heavy, p.heavy_np, p.heavy_max), (p.light, p.light_np, p.light_max)):
             if tasks is not None:
                 L.call("coevo_fc_forward_argmax", L._p(self.slab), L._p(tasks), len(tnp), mx, L._p(self.obs),
                        L._p(self.actions), None, L._p(self.status))
 
-    def _cycle_native(self, c):
-        p, lib = self.plan, L.load()
-        L._check(lib.coevo_mpe_host_observe(self.state.ctypes.data, p.n_games, p.row_game_np.ctypes.data,
-                                            p.row_slot_np.ctypes.data, p.n_rows, self.obs_host.data_ptr()),
-                 "coevo_mpe_host_observe")
-        self.obs.copy_(self.obs_host, non_blocking=True)
-        self._forward()
-        self.actions_host.copy_(self.actions, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        L._check(lib.coevo_mpe_host_step(self.state.ctypes.data, p.n_games, self._game_rows32.ctypes.data,
-                                         self.actions_host.data_ptr(), p.n_rows, c, self._limits32.ctypes.data,
-                                         1 if sa.INTEGRATE_POS_FIRST else 0), "coevo_mpe_host_step")
-
     def cycle(self, c):
-        if self.impl == "native":
-            return self._cycle_native(c)
+        """(numpy env) one blocking cycle"""
         p = self.plan
         adv, a0, a1 = self.env.observe()
         o = self.obs_host.numpy()
@@ -458,12 +509,26 @@ class HostEnvRollout:
         self.rg_prev[m2] = rg[m2]
 
     def run(self, n_cycles):
+        if self.impl == "native":
+            p = self.plan
+            d = L.HostRolloutDesc(
+                slab=L._p(self.slab), state=self.state.ctypes.data, game_rows=self._game_rows32.ctypes.data,
+                game_limit=self._limits32.ctypes.data, obs_host=self.obs_host.data_ptr(), obs_dev=L._p(self.obs),
+                actions_host=self.actions_host.data_ptr(), actions_dev=L._p(self.actions), status=L._p(self.status),
+                cohorts=C_cast(self._cohorts), phase_us=(self.phase_us.ctypes.data if self.phase_us is not None else None),
+                n_games=p.n_games, n_rows=p.n_rows, n_cycles=int(n_cycles), n_cohorts=p.n_cohorts,
+                pos_first=1 if sa.INTEGRATE_POS_FIRST else 0, zero_copy=1 if self.zero_copy else 0)
+            L._check(L.load().coevo_mpe_host_rollout(self.ctx, L.C.byref(d), L._stream()), "coevo_mpe_host_rollout")
+            # play_game's triple (agent_0, agent_1, adversary_0): state rows 20, 21, 19
+            self.rewards = np.ascontiguousarray(self.state[[20, 21, 19]].T)
+            return
         for c in range(n_cycles):
             self.cycle(c)
-        if self.impl == "native":   # play_game's triple (agent_0, agent_1, adversary_0): state rows 20, 21, 19
-            self.rewards = np.ascontiguousarray(self.state[[20, 21, 19]].T)
-        else:
-            self.rewards = np.stack([self.acc[:, 1], self.acc[:, 2], self.acc[:, 0]], axis=1)
+        self.rewards = np.stack([self.acc[:, 1], self.acc[:, 2], self.acc[:, 0]], axis=1)
 
     def check_status(self):
         L.raise_on_status(self.status)
+
+
+def C_cast(arr):
+    return _ct.cast(arr, _ct.c_void_p)

@@ -136,6 +136,53 @@ int coevo_mpe_host_observe(const double *state, int n_games, const int32_t *row_
                            int n_rows, float *obs);
 int coevo_mpe_host_step(double *state, int n_games, const int32_t *game_rows, const int32_t *actions, int n_rows,
                         int cycle, const int32_t *game_limit, int pos_first);
+/* world step `cycle` (cycle < 0: none) of games[lo..hi) on the calling thread, then (observe != 0) the observation rows of
+ * those games: the unit of work one host core gets per env-cycle.  No table scan - the caller has validated game_rows. */
+int coevo_mpe_host_step_games(double *state, int n_games, const int32_t *game_rows, const int32_t *actions, int cycle,
+                              const int32_t *game_limit, int pos_first, const int32_t *games, int lo, int hi, int observe,
+                              float *obs);
+
+/* A whole batch of games with the env on the host cores in ONE call (north_star: "vectorised env stepping runs on the host
+ * cores"): the per-game loop of play_MPE (utils/game_logic_functions.py:123-212) for all of a rank's games.  The games are cut
+ * into cohorts; per env-cycle and cohort the host cores (the context's n_threads, the caller's thread included) step the
+ * cohort's games and write their observations, the cohort's own stream carries obs up, one policy launch
+ * (MPE/fcnetwork.py:37-90 for every row) and the actions down; while that is in flight the cores work on the next cohort.
+ * Returns when the last cycle has been stepped; results are independent of n_threads and of the cohort partition. */
+typedef struct {
+    const coevo_fc_task *heavy;   /* DEVICE: this cohort's shared-opponent tasks (may be NULL / 0) */
+    const coevo_fc_task *light;   /* DEVICE: this cohort's per-individual tasks */
+    const int32_t *games;         /* HOST: ids of this cohort's games */
+    int32_t n_heavy, heavy_max_rows, n_light, light_max_rows;
+    int32_t n_games;
+    int32_t row_first, n_rows;    /* the cohort's rows: one contiguous range of obs / actions; n_rows = 3 * n_games */
+    int32_t reserved;
+} coevo_host_cohort;
+typedef struct {
+    const float *slab;            /* DEVICE weight slab */
+    double *state;                /* HOST [COEVO_MPE_STATE_DOUBLES][n_games], as coevo_mpe_host_reset leaves it */
+    const int32_t *game_rows;     /* HOST [n_games][3]: row of each slot */
+    const int32_t *game_limit;    /* HOST [n_games] agent-step limits, or NULL */
+    float *obs_host;              /* HOST, page-locked: [n_rows][COEVO_OBS_STRIDE] */
+    float *obs_dev;               /* DEVICE twin */
+    int32_t *actions_host;        /* HOST, page-locked: [n_rows] */
+    int32_t *actions_dev;         /* DEVICE twin */
+    int32_t *status;              /* DEVICE status word */
+    const coevo_host_cohort *cohorts;
+    double *phase_us;             /* NULL, or HOST [6]: mean microseconds per cohort-cycle of {host wait for the actions, host
+                                     env step + observe, host enqueue, obs host->device, policy launch, actions device->host} */
+    int32_t n_games, n_rows, n_cycles, n_cohorts, pos_first;
+    int32_t zero_copy;            /* != 0: the launch reads obs_host / writes actions_host directly (page-locked, mapped
+                                     memory: same PCIe bytes, no copy engine in the chain) */
+} coevo_host_rollout_desc;
+void *coevo_host_rollout_create(int n_threads, int n_cohorts);   /* worker threads + one stream per cohort */
+void coevo_host_rollout_destroy(void *ctx);
+int coevo_host_rollout_threads(void *ctx);                       /* host cores a rollout uses (caller's thread included) */
+int coevo_mpe_host_rollout(void *ctx, const coevo_host_rollout_desc *desc, void *stream);
+/* one cohort-cycle's host share alone, on the context's cores: world step `cycle` (< 0: none) of the n_list listed games,
+ * then (observe != 0) their observation rows.  Needs no GPU.  n_rows = length of `actions` / rows of `obs`. */
+int coevo_host_rollout_step(void *ctx, double *state, int n_games, const int32_t *game_rows, const int32_t *actions,
+                            int n_rows, int cycle, const int32_t *game_limit, int pos_first, const int32_t *games,
+                            int n_list, int observe, float *obs);
 /* play_game() return triples (agent_0, agent_1, adversary_0) -> rewards[n][3] fp64 */
 int coevo_mpe_rewards(const double *state, int n_games, double *rewards, void *stream);
 

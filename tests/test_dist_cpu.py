@@ -97,6 +97,8 @@ def test_backend_choice():
     assert choose_backend(None, {}, True, 8) == ("nccl", False)              # 16 ranks over 2 x 8 GPUs under srun
     assert choose_backend(None, {"COEVO_DIST_BACKEND": "gloo"}, True, 8) == ("gloo", False)
     assert choose_backend("nccl", {"LOCAL_WORLD_SIZE": "2", "COEVO_DIST_BACKEND": "gloo"}, True, 1)[0] == "nccl"
+    assert choose_backend(None, {}, False, 0) == ("gloo", False)             # a CPU-only host: RCCL cannot start there
+    assert choose_backend(None, {"LOCAL_WORLD_SIZE": "2"}, False, 0) == ("gloo", False)
 
 
 def test_es_cohort_bounds_cover_every_game():

@@ -177,3 +177,26 @@ def test_save_and_metrics_roundtrip(tmp_path):
     trio = [load_agents(os.path.join(tmp_path, GA_FILES[r][0]))[-1] for r in ("agent_0", "agent_1", "adversary_0")]
     out = play_game(env=env, player1=trio[0].model, player2=trio[1].model, adversary=trio[2].model, args=args, eval=True)
     assert len(out) == 3 and all(np.isfinite(out))
+
+
+@pytest.mark.parametrize("cohorts,threads,zero_copy", [(1, 1, 0), (2, 4, 0), (3, 2, 0), (2, 3, 1), (4, 8, 1)])
+def test_host_cores_rollout_equals_device_rollout(monkeypatch, cohorts, threads, zero_copy):
+    """coevo_mpe_host_rollout (env on the host cores: K alternating cohorts, T threads, staged copies or mapped page-locked
+    buffers) against the device env: every play_game triple, fitness bits, elite ids and evaluation means of three
+    generations are identical - the partition and the thread count change the schedule, never a number
+    (utils/game_logic_functions.py:123-212)."""
+    cfg = {"seed": 11, "args": dict(generations=3, population=13, hof_size=3, elites_number=2, fitness_sharing=True,
+                                    max_timesteps_per_episode=41, max_evaluation_steps=75)}
+    _, _, want = _run(cfg, "device_philox", "device")
+    monkeypatch.setenv("COEVO_HOST_COHORTS", str(cohorts))
+    monkeypatch.setenv("COEVO_HOST_THREADS", str(threads))
+    monkeypatch.setenv("COEVO_HOST_ZERO_COPY", str(zero_copy))
+    _, _, res = _run(cfg, "device_philox", "host")
+    ro = res.engine.ro
+    assert ro.impl == "native" and ro.threads == threads and ro.plan.n_cohorts == cohorts and ro.zero_copy == bool(zero_copy)
+    for g in range(3):
+        assert res.elite_ids[g] == want.elite_ids[g]
+        assert np.array_equal(np.asarray(res.game_rewards[g]).view(np.uint64), np.asarray(want.game_rewards[g]).view(np.uint64))
+        assert np.array_equal(np.asarray(res.fitness[g], np.float32).view(np.uint32),
+                              np.asarray(want.fitness[g], np.float32).view(np.uint32))
+        assert [res.rewards[r][g] for r in ga.ROLES] == [want.rewards[r][g] for r in ga.ROLES]

@@ -425,3 +425,54 @@ def test_native_host_env_equals_numpy_env():
     bad[0, 0] = 3 * n   # a row index outside the action buffer is refused, not read
     assert lib.coevo_mpe_host_step(st.ctypes.data, n, bad.ctypes.data, acts_rows.ctypes.data, 3 * n, 0, limits.ctypes.data,
                                    pos_first) == -1   # COEVO_ERR_ARG
+
+
+@pytest.mark.parametrize("threads", [2, 5, 8])
+def test_host_cores_pool_equals_one_thread(threads):
+    """coevo_host_rollout_step (what coevo_mpe_host_rollout runs per cohort and env-cycle on its T host cores): T threads over
+    slices of a cohort's game list == the single-thread coevo_mpe_host_step / _observe, bit for bit - 25 cycles, two cohorts
+    of an odd game count in alternation, ragged limits, shuffled rows (utils/game_logic_functions.py:138,179-190).  No GPU."""
+    from coevonet_amd import lib as L
+    from coevonet_amd.mpe import simple_adversary as sa
+    lib = L.load()
+    n = 1013
+    rng = np.random.default_rng(threads)
+    ordinals = rng.integers(0, 9000, size=n).astype(np.int64)
+    ref = np.zeros((L.MPE_STATE_DOUBLES, n))
+    assert lib.coevo_mpe_host_reset(ref.ctypes.data, n, L.PCG64State.from_seed(sa.ENV_SEED), ordinals.ctypes.data) == 0
+    st = ref.copy()
+    game_rows = rng.permutation(3 * n).astype(np.int32).reshape(n, 3).copy()
+    row_game, row_slot = np.zeros(3 * n, np.int32), np.zeros(3 * n, np.int32)
+    for g in range(n):
+        for s in range(3):
+            row_game[game_rows[g, s]], row_slot[game_rows[g, s]] = g, s
+    limits = rng.integers(0, 80, size=n).astype(np.int32)
+    cohorts = [np.ascontiguousarray(np.nonzero(np.arange(n) % 3 != 0)[0], dtype=np.int32),
+               np.ascontiguousarray(np.nonzero(np.arange(n) % 3 == 0)[0], dtype=np.int32)]
+    ctx = lib.coevo_host_rollout_create(threads, 2)
+    assert ctx and lib.coevo_host_rollout_threads(ctx) == threads
+    obs_ref = np.zeros((3 * n, L.OBS_STRIDE), np.float32)
+    obs = np.full((3 * n, L.OBS_STRIDE), 3.0, np.float32)
+    pos_first = 1 if sa.INTEGRATE_POS_FIRST else 0
+    acts = rng.integers(0, 5, size=3 * n).astype(np.int32)
+    try:
+        for c in range(26):
+            for games in cohorts:   # step cycle c-1 (none at c = 0), then observe: the rollout's order per cohort
+                assert lib.coevo_host_rollout_step(ctx, st.ctypes.data, n, game_rows.ctypes.data, acts.ctypes.data, 3 * n,
+                                                   c - 1, limits.ctypes.data, pos_first, games.ctypes.data, len(games),
+                                                   1 if c < 25 else 0, obs.ctypes.data) == 0
+            if c > 0:
+                assert lib.coevo_mpe_host_step(ref.ctypes.data, n, game_rows.ctypes.data, acts.ctypes.data, 3 * n, c - 1,
+                                               limits.ctypes.data, pos_first) == 0
+            assert np.array_equal(st.view(np.uint64), ref.view(np.uint64)), c
+            if c < 25:
+                assert lib.coevo_mpe_host_observe(ref.ctypes.data, n, row_game.ctypes.data, row_slot.ctypes.data, 3 * n,
+                                                  obs_ref.ctypes.data) == 0
+                assert np.array_equal(obs.view(np.uint32), obs_ref.view(np.uint32)), c
+            acts = rng.integers(0, 5, size=3 * n).astype(np.int32)
+        bad = cohorts[0].copy()
+        bad[3] = n   # a game id outside the state is refused before any thread runs
+        assert lib.coevo_host_rollout_step(ctx, st.ctypes.data, n, game_rows.ctypes.data, acts.ctypes.data, 3 * n, 0,
+                                           limits.ctypes.data, pos_first, bad.ctypes.data, len(bad), 0, None) == -1
+    finally:
+        lib.coevo_host_rollout_destroy(ctx)
