@@ -169,8 +169,10 @@ class GAEngine:
         heavy_rows = int(os.environ.get("COEVO_HEAVY_ROWS", "16"))
         # cohorts = contiguous ranges of this rank's individuals (so that offspring can be bred cohort by cohort and a
         # cohort's chain can start while the next cohort is still being bred); the evaluation games go with the last
-        # (env on the host cores: the cohorts ALTERNATE between the cores and the GPU - COEVO_HOST_COHORTS, default 2)
-        self.K = max(1, min(int(cohorts) if env == "device" else int(os.environ.get("COEVO_HOST_COHORTS", "2")),
+        # (env on the host cores: the cohorts alternate between the cores and the GPU - COEVO_HOST_COHORTS, default 4: the
+        # chain launch -> actions -> host step -> next launch of ONE cohort is ~90 us of latency however many cores step it;
+        # four chains in flight hide most of it, six or more share hardware queues and serialise - profiles/r04_experiments.md)
+        self.K = max(1, min(int(cohorts) if env == "device" else int(os.environ.get("COEVO_HOST_COHORTS", "4")),
                             self.n_local))
         row_order = "class" if env == "device" else "cohort"
         self._set_cohort_bounds()

@@ -383,8 +383,9 @@ class HostEnvRollout:
     back over PCIe.  Results are bit-identical with DeviceRollout.
 
     impl = "native" (default): ONE C-ABI call per rollout, coevo_mpe_host_rollout (csrc/host_rollout.hip) - the plan's
-    cohorts alternate: while one cohort's copies and policy launch are in flight on its own stream, the host cores
-    (COEVO_HOST_THREADS, default min(8, cores)) step the next cohort's games; per-cohort event polls are the only waits.
+    cohorts are dealt to the host cores (COEVO_HOST_THREADS, default 2); a core drives its cohorts from the first
+    observation to the last world step and alternates between them - while one cohort's policy launch is in flight on its
+    own stream the core steps another - and polls a per-cohort completion word; nothing waits for a whole stream.
     impl = "numpy": coevonet_amd/mpe/simple_adversary.py's VecSimpleAdversary, the form the env fixtures are stated in, one
     blocking cycle at a time (1.5 ms of NumPy per cycle at cfg 2)."""
 
@@ -406,14 +407,15 @@ class HostEnvRollout:
         self._merged = None
         self.ctx = None
         self.phase_us = None          # set to a float64[6] array to collect the per-cohort-cycle breakdown
-        self.zero_copy = os.environ.get("COEVO_HOST_ZERO_COPY", "0") == "1"
+        self.zero_copy = os.environ.get("COEVO_HOST_ZERO_COPY", "1") == "1"
         if self.impl == "native":
             p = plan
             K = p.n_cohorts
             if K > 1 and p.cohort_row_begin_np is None:
                 raise ValueError("a host-stepped rollout with several cohorts needs a plan built with row_order='cohort'")
             if threads is None:
-                threads = int(os.environ.get("COEVO_HOST_THREADS", "0")) or min(8, os.cpu_count() or 1)
+                threads = int(os.environ.get("COEVO_HOST_THREADS", "0")) or 2
+            threads = max(1, min(int(threads), K))   # a core drives whole cohorts: more cores than cohorts would idle
             self.ctx = L.load().coevo_host_rollout_create(int(threads), K)
             if not self.ctx:
                 raise L.CoevoError("coevo_host_rollout_create failed")
