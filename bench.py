@@ -449,7 +449,11 @@ def extras(a, ctx, dev):
                            if rl["second_kernel"].get(k) is not None}
         return o
 
+    only = [x for x in os.environ.get("COEVO_BENCH_LEGS", "").split(",") if x]   # (diagnostics: a subset of the legs)
+
     def leg(name, fn):
+        if only and name not in only:
+            return
         try:
             r = fn()
             ex[name] = {"gens_per_sec": r["gens_per_sec"], "ms_per_step": r["ms_per_step"], "env_steps_per_sec": r["value"]}
@@ -470,9 +474,16 @@ def extras(a, ctx, dev):
     leg("cfg2_T200", lambda: run_ga(t200, ctx, dev))
     # north_star's literal first configuration: the env vectorised on the host cores, observations up / actions down over
     # PCIe every cycle - the PCIe-inclusive rate, never the headline
-    host = copy.copy(b)
-    host.env, host.steps, host.warmup = "host", 20, 3
-    leg("cfg2_host_env", lambda: run_ga(host, ctx, dev))
+    # Its own process: after the device-resident loop has run in a process (lane streams + a replayed tail graph), every
+    # operation on the host rollout's cohort streams takes ~9 us longer and the leg reads 240 instead of 370 generations/s
+    # (profiles/r04_experiments.md); `python bench.py --env host` is how the mode is run anyway.
+    def host_leg():
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--env", "host", "--no-extra", "--no-cpu-baseline", "--steps", "20",
+               "--warmup", "3"]
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, check=True)
+        return json.loads(p.stdout.decode().strip().splitlines()[-1])
+    leg("cfg2_host_env", host_leg)
     # the metric's own split (pop 200 over 2 / 4 / 8 GPUs): what ONE rank of it does on this GPU (dist.ShardRehearsal)
     for n in (2, 4, 8):
         sh = copy.copy(b)
