@@ -46,6 +46,13 @@ namespace coevo {
 #ifndef DQ_FC1_ALLNT
 #define DQ_FC1_ALLNT 0   // 1: non-temporal weight loads for every task (A/B)
 #endif
+#ifndef DQ_FC1_HALF
+#define DQ_FC1_HALF 0    // 1 (A/B, measured and not shipped): launches of <= 1024 waves as 32-output waves, two per SIMD - 104 vs
+                         // 92 us at cfg 4: a wave's time is its 3136-step dependent 4x4x1 chain, whatever its width (r04_experiments.md)
+#endif
+#ifndef DQ_FC1_NB_HALF
+#define DQ_FC1_NB_HALF 4   // ... and their ring depth (<= 256 registers)
+#endif
 #ifndef DQ_FC1_NB_MANY
 #define DQ_FC1_NB_MANY 2   // ... of a launch with more waves than the chip has SIMDs (fewer registers: several waves per SIMD)
 #endif
@@ -534,15 +541,26 @@ constexpr int DQ_RMAX = 16;
 // MFMAs.  One launch serves tasks of every size: the kernel picks the instantiation by the task's own row count.
 // NB = chunks of the weight stream in the wave's register ring: NB - 1 of them (14 KiB each) are in flight while one feeds
 // the matrix pipe.
-template <int NG, int NB, bool SHARED_NET>
+// HALF: a wave owns 32 outputs instead of 64 (`ob` then counts 32-output blocks): lanes l and l + 32 hold the SAME output
+// column l % 32 and different row groups - the sixteen 4x4 blocks of an MFMA are 8 column quads x 2 row groups - so a 16-row
+// task issues two matrix instructions per k and wave instead of four, and has 16 waves instead of 8.  For launches with fewer
+// waves than the chip has SIMDs (a Co-GA shard: 90 tasks): a lone wave on a SIMD cannot hide its own LDS round trips and MFMA
+// chain (100 k matrix-pipe cycles for 64 outputs x 16 rows); two half-size waves per SIMD overlap each other's.  The two
+// lanes of a column request the same 16-byte piece (one 512-byte segment per wave-load): no extra bytes leave the L2.
+// NG counts the MFMA groups of the wave (HALF: 8 rows each, else 4).  Same sequential-k chain per (row, output): same bits.
+template <int NG, int NB, bool SHARED_NET, bool HALF = false>
 __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &L, const coevo_dqn_task &task,
                                              const float *act, float *hid, float (*xs)[DQ_RMAX][DQ_FC1_U * 4], int ob, int l)
 {
     constexpr int U = DQ_FC1_U;  // k-quads per chunk; 784 = 56 * 14
     constexpr int NCHUNK = 784 / U;
     static_assert(784 % U == 0 && NCHUNK % NB == 0 && NB >= 2, "whole rounds of the ring");
+    constexpr int RG = HALF ? 2 * NG : NG;          // row groups of four staged per chunk
+    static_assert(4 * RG <= DQ_RMAX, "rows of one task");
     const int nrows = task.n_rows;
-    const float bb = net[L.bf + 64 * ob + l];
+    const int col = HALF ? 32 * ob + (l & 31) : 64 * ob + l;   // the lane's output
+    const int hrow = HALF ? (l >> 5) : 0;                       // which of a group's two row quads this lane accumulates
+    const float bb = net[L.bf + col];
     // rows in groups of four on v_mfma_f32_4x4x1_16B_f32 (16 blocks x 4 columns = the wave's 64 outputs, one k per
     // instruction; bit-identical to the fmaf chain, tools/mfma4_chain_probe.hip): the lane's streamed 16-byte piece is
     // the B operand as is, the A operand x[4g + l%4][4q..4q+3] is one ds_read_b128 per group.  (As VALU FMAs fed by one
@@ -554,9 +572,9 @@ __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &
     for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[g][i] = bb;
-    const float4 *wp = reinterpret_cast<const float4 *>(net + L.wf) + (size_t)ob * 784 * 64 + l;
+    const float4 *wp = reinterpret_cast<const float4 *>(net + L.wf) + (size_t)(col >> 6) * 784 * 64 + (col & 63);
     const float *arow = act + (size_t)task.row_begin * DQ_FC1_IN;
-    constexpr int XI = (4 * NG * U + 63) / 64;
+    constexpr int XI = (4 * RG * U + 63) / 64;
     float4 wv[NB][U], xr[NB][XI];
     // a chunk's weight pieces (read once per launch: non-temporal, keeps the conv weights / activations in L2 - unless the
     // neighbouring task streams the same net: then plain loads, so that the siblings' requests meet in the XCD's L2.
@@ -575,7 +593,7 @@ __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &
 #pragma unroll
         for (int j = 0; j < XI; ++j) {
             const int i = l + 64 * j, r = i / U, q = i % U;
-            x[j] = (i < 4 * NG * U && r < nrows)
+            x[j] = (i < 4 * RG * U && r < nrows)
                        ? *reinterpret_cast<const float4 *>(arow + (size_t)r * DQ_FC1_IN + 4 * (kq + q))
                        : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -584,22 +602,34 @@ __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &
 #pragma unroll
         for (int j = 0; j < XI; ++j) {
             const int i = l + 64 * j;
-            if (i < 4 * NG * U) *reinterpret_cast<float4 *>(&x_lds[i / U][4 * (i % U)]) = xin[j];
+            if (i < 4 * RG * U) *reinterpret_cast<float4 *>(&x_lds[i / U][4 * (i % U)]) = xin[j];
         }
         __syncthreads();   // one wave per workgroup: orders the LDS round trip
+        // The broadcast reads of k-quad u + 1 are requested BEFORE the matrix instructions of k-quad u are issued (two
+        // register sets, the order pinned): left to itself the compiler re-used one set and waited out every read - a lone
+        // wave on its SIMD then spent ~150 of its ~290 cycles per k-quad on LDS latency, which is what bounded the launch
+        // (its time did not follow the bytes, the wave count, the ring depth or the MFMA count: profiles/r04_experiments.md).
+        float4 x[2][NG];
+        auto read_x = [&](float4 (&dst)[NG], int u) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                dst[g] = *reinterpret_cast<const float4 *>(&x_lds[4 * ((HALF ? 2 * g : g) + hrow) + (l & 3)][4 * u]);
+        };
+        read_x(x[0], 0);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            float4 x[NG];
+            if (u + 1 < U) read_x(x[(u + 1) & 1], u + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 (&xc)[NG] = x[u & 1];
 #pragma unroll
-            for (int g = 0; g < NG; ++g) x[g] = *reinterpret_cast<const float4 *>(&x_lds[4 * g + (l & 3)][4 * u]);
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(xc[g].x, w[u].x, acc[g], 0, 0, 0);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].x, w[u].x, acc[g], 0, 0, 0);
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(xc[g].y, w[u].y, acc[g], 0, 0, 0);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].y, w[u].y, acc[g], 0, 0, 0);
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(xc[g].z, w[u].z, acc[g], 0, 0, 0);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].z, w[u].z, acc[g], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[g].w, w[u].w, acc[g], 0, 0, 0);
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(xc[g].w, w[u].w, acc[g], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     // the ring: chunk c lives in buffer c % NB; before chunk c is consumed chunk c + NB - 1 is requested into the buffer
@@ -621,9 +651,10 @@ __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (4 * g + i < nrows)
-                hid[(size_t)(task.row_begin + 4 * g + i) * DQ_FC1_OUT + 64 * ob + l] = relu_keep_nan(acc[g][i]);
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * ((HALF ? 2 * g : g) + hrow) + i;
+            if (r < nrows) hid[(size_t)(task.row_begin + r) * DQ_FC1_OUT + col] = relu_keep_nan(acc[g][i]);
+        }
 }
 
 // fc1 + ReLU: grid (task, 8), ONE wavefront per workgroup: it owns outputs [64*ob, +64) and streams their 802 KB
@@ -634,8 +665,8 @@ __device__ __forceinline__ void dqn_fc1_body(const float *net, const DqnLayout &
 // of 7 KiB (~300 registers, nothing else would hide a lone wave's round trips); a launch with more waves than SIMDs (a
 // Co-ES cohort: 133 tasks = 1064 waves) keeps two (< 256 registers: every wave resident; with the deep ring its last 40
 // waves ran as a second round, 171 against 141 us).  Chunks of 7 instead of 14 pieces: 170 -> 141 us for that launch.
-template <int NB>
-__global__ __launch_bounds__(64, NB <= DQ_FC1_NB_MANY ? 2 : 1) void dqn_fc1_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int C,
+template <int NB, bool HALF = false>
+__global__ __launch_bounds__(64, (HALF || NB <= DQ_FC1_NB_MANY) ? 2 : 1) void dqn_fc1_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int C,
                                                       int n_actions, const float *act, float *hid)
 {
     __shared__ __attribute__((aligned(16))) float xs[2][DQ_RMAX][DQ_FC1_U * 4];
@@ -654,8 +685,17 @@ __global__ __launch_bounds__(64, NB <= DQ_FC1_NB_MANY ? 2 : 1) void dqn_fc1_kern
     const float *net = slab + task.net_off;
     const DqnLayout L = dqn_layout(C, n_actions);
     const int ob = blockIdx.y, l = threadIdx.x;
-    const int ng = (task.n_rows + 3) >> 2;   // workgroup-uniform, as is shared_net: one straight-line instantiation each
-    if (shared_net) {
+    // MFMA groups of this wave (workgroup-uniform, as is shared_net: one straight-line instantiation each)
+    const int ng = HALF ? (task.n_rows + 7) >> 3 : (task.n_rows + 3) >> 2;
+    if constexpr (HALF) {
+        if (shared_net) {
+            if (ng == 1) dqn_fc1_body<1, NB, true, true>(net, L, task, act, hid, xs, ob, l);
+            else dqn_fc1_body<2, NB, true, true>(net, L, task, act, hid, xs, ob, l);
+        } else {
+            if (ng == 1) dqn_fc1_body<1, NB, false, true>(net, L, task, act, hid, xs, ob, l);
+            else dqn_fc1_body<2, NB, false, true>(net, L, task, act, hid, xs, ob, l);
+        }
+    } else if (shared_net) {
         if (ng == 1) dqn_fc1_body<1, NB, true>(net, L, task, act, hid, xs, ob, l);
         else if (ng == 2) dqn_fc1_body<2, NB, true>(net, L, task, act, hid, xs, ob, l);
         else if (ng == 3) dqn_fc1_body<3, NB, true>(net, L, task, act, hid, xs, ob, l);
@@ -840,6 +880,9 @@ static int dqn_forward_launch(const float *slab, const coevo_dqn_task *tasks, in
     const dim3 fg(8 * ((n_tasks + 7) / 8), 8);
     if (n_tasks <= DQ_FC1_NARROW_MAX_TASKS)
         hipLaunchKernelGGL(dqn_fc1_narrow_kernel<DQ_FC1_NBN>, dim3(n_tasks, 32), dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions,
+                           act, hid);
+    else if (DQ_FC1_HALF && n_tasks * 8 <= 1024)
+        hipLaunchKernelGGL((dqn_fc1_kernel<DQ_FC1_NB_HALF, true>), dim3(fg.x, 16), dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions,
                            act, hid);
     else if (n_tasks * 8 <= 1024) hipLaunchKernelGGL(dqn_fc1_kernel<DQ_FC1_NB>, fg, dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, act, hid);
     else hipLaunchKernelGGL(dqn_fc1_kernel<DQ_FC1_NB_MANY>, fg, dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, act, hid);
