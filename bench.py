@@ -232,6 +232,7 @@ def main():
     real_world = 1 if rehearsal else ctx.world
     out.update({"n_gpus": real_world, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": scaling,
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "noise": f"philox4x32-{L.load().coevo_noise_rounds()}", "coevo_version": L.load().coevo_version(),
                 "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "dist_backend": (torch.distributed.get_backend() if real_world > 1 else None),
                 "rccl_ranks": (torch.distributed.get_world_size() if real_world > 1 else 1)})

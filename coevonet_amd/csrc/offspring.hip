@@ -640,4 +640,54 @@ extern "C" int coevo_net_gather(const float *src_slab, const int32_t *src_idx, f
     return COEVO_OK;
 }
 
+
+// ---- the noise contract, exposed: the round count and the generator itself (raw words and the Gaussians built from them),
+// so that a binding / a resumed run can check what it is loading and the tests can hold the generator against published
+// known-answer vectors (Random123's kat_vectors) and moment / correlation bounds, independently of the oracle.
+namespace coevo {
+__global__ void philox_raw_kernel(int rounds, const uint32_t *ctr_key, int n, uint32_t *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *c = ctr_key + 6 * (size_t)i;
+    u32x4 o;
+    if (rounds == 7) o = philox4x32<7>(c[0], c[1], c[2], c[3], c[4], c[5]);
+    else o = philox4x32<10>(c[0], c[1], c[2], c[3], c[4], c[5]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[4 * (size_t)i + k] = o.v[k];
+}
+
+__global__ void philox_normal_kernel(uint64_t seed, uint32_t stream_lo, uint32_t stream_hi, uint32_t q_first, int n_quads,
+                                     float *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_quads) return;
+    float z[4];
+    philox_normal4(seed, stream_lo, stream_hi, q_first + (uint32_t)i, z);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[4 * (size_t)i + k] = z[k];
+}
+}  // namespace coevo
+
+extern "C" int coevo_noise_rounds(void) { return coevo::COEVO_NOISE_ROUNDS; }
+
+extern "C" int coevo_philox4x32(int rounds, const uint32_t *ctr_key, int n, uint32_t *out, void *stream)
+{
+    if (!ctr_key || !out || n <= 0 || (rounds != 7 && rounds != 10)) return COEVO_ERR_ARG;
+    hipLaunchKernelGGL(coevo::philox_raw_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, rounds, ctr_key, n,
+                       out);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+extern "C" int coevo_philox_normals(uint64_t seed, uint32_t stream_lo, uint32_t stream_hi, uint32_t q_first, int n_quads,
+                                    float *out, void *stream)
+{
+    if (!out || n_quads <= 0) return COEVO_ERR_ARG;
+    hipLaunchKernelGGL(coevo::philox_normal_kernel, dim3((n_quads + 255) / 256), dim3(256), 0, (hipStream_t)stream, seed,
+                       stream_lo, stream_hi, q_first, n_quads, out);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
 COEVO_DEFINE_TU_FLAGS(offspring)

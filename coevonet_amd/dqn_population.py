@@ -127,8 +127,20 @@ class SynthRollout:
                 self._lane_ctx = None
 
     def __del__(self):
+        # No device-wide synchronize from a finaliser: the collector may run it while ANOTHER engine is capturing a hipGraph
+        # (bench.py builds many engines in one process), and a device sync invalidates the capture.  Owners call close()
+        # (DQNGATrainer.close / DQNESTrainer.close); a rollout dropped without it only gives its contexts back when nothing
+        # is capturing, after waiting for its OWN streams.
         try:
-            self.close()
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                return
+            for ln in getattr(self, "lanes", [])[1:]:
+                if ln.get("stream") is not None:
+                    ln["stream"].synchronize()
+            self._destroy_timing()
+            if getattr(self, "_lane_ctx", None):
+                L.load().coevo_rollout_ctx_destroy(self._lane_ctx)
+                self._lane_ctx = None
         except Exception:
             pass
 
@@ -171,7 +183,8 @@ class SynthRollout:
                          "coevo_dqn_out_synth_step")
             if t < T:
                 tc, which = None, 0
-                if timed and self.timing_ctx and t % self.timing_every == 0:
+                # (HIP events cannot be recorded inside a capture: timing is for eager enqueues only)
+                if timed and self.timing_ctx and t % self.timing_every == 0 and not torch.cuda.is_current_stream_capturing():
                     which = (t // self.timing_every) & 1
                     tc = self.timing_ctx[which]
                 L._check(lib.coevo_dqn_forward_hidden_timed(L._p(self.slab), L._p(ln["tasks"][p]), ln["n_tasks"][p],
@@ -590,7 +603,10 @@ class DQNESEngine(_SlabMixin):
         self.partials = torch.zeros(self.world * self.part_block, **f32)
         self.game_idx = torch.stack([torch.arange(self.n_local, device=device) * 2 + ri for ri in range(2)])
         self.steps_per_generation = 2 * pop * self.T_train + N_EVAL * self.T_eval
-        self.eval_graph = os.environ.get("COEVO_DQN_EVAL_GRAPH", "1") != "0"
+        # the evaluation rollout as a replayed hipGraph; with several ranks (an RCCL process group alive beside the capture)
+        # that combination has never run on hardware, so it is opt-in there until a multi-GPU box has passed
+        # tests/test_dist_gpu.py with COEVO_DQN_EVAL_GRAPH=1
+        self.eval_graph = os.environ.get("COEVO_DQN_EVAL_GRAPH", "1" if shard[1] == 1 else "0") != "0"
         self._eval_graph = None
 
     def generation(self, gen, sigmas, lr, fitness_sharing):

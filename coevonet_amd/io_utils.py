@@ -82,7 +82,10 @@ def save_state_dicts(agents, file_path, role=None):
     with tensors only.  `agents`: an Agent or a list of Agents.  Returns the path written."""
     single = not isinstance(agents, (list, tuple))
     lst = [agents] if single else list(agents)
+    from . import lib as L
     payload = {"format": "coevonet_amd.state_dict.v1", "role": role or "", "single": single,
+               # what a resumed device_philox run must match: other rounds are other offspring for the same seed
+               "coevo_version": int(L.load().coevo_version()), "noise": f"philox4x32-{int(L.load().coevo_noise_rounds())}",
                "agents": [{k: v.detach().clone() for k, v in a.model.state_dict().items()} for a in lst]}
     path = state_dict_path(file_path)
     torch.save(payload, path)

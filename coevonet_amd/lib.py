@@ -184,6 +184,9 @@ _SIGS = {
                                                 C.c_int, C.c_int, C.c_void_p]),
     "coevo_mpe_final_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                        C.c_void_p]),
+    "coevo_noise_rounds": (C.c_int, []),
+    "coevo_philox4x32": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "coevo_philox_normals": (C.c_int, [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]),
     "coevo_fc_perturb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]),
     "coevo_fc_perturb_flags": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,

@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define COEVO_VERSION 100
+#define COEVO_VERSION 101   /* 101: offspring noise = Philox4x32-7 (100: -10; other numbers for the same seed), host-cores
+                             * rollout entry points, coevo_noise_rounds */
 
 #define COEVO_OK 0
 #define COEVO_ERR_ARG (-1)   /* bad size / null pointer / unsupported shape */
@@ -272,6 +273,15 @@ int coevo_mpe_final_step(const double *state, int n_games, const int32_t *action
                          const int32_t *game_limit, int pos_first, double *rewards, void *stream);
 
 /* ---------------------------------------------------------------- K3/K4/K8: offspring on device ------------- */
+/* The noise contract: rounds of the Philox4x32 generator behind every device-built offspring (7).  A checkpoint / a binding
+ * that resumes a `device_philox` run must see the number it was started with - other rounds are other numbers. */
+int coevo_noise_rounds(void);
+/* the generator itself, for known-answer tests: n x (counter[4], key[2]) -> n x 4 words after `rounds` (7 or 10) rounds */
+int coevo_philox4x32(int rounds, const uint32_t *ctr_key, int n, uint32_t *out, void *stream);
+/* ... and the standard normals the offspring kernels add (agent.py:27-28's torch.normal / :52's np.random.normal in the
+ * `device_philox` mode): out[4 i + k] = normal k of counter q_first + i of stream (stream_lo, stream_hi) under `seed` */
+int coevo_philox_normals(uint64_t seed, uint32_t stream_lo, uint32_t stream_hi, uint32_t q_first, int n_quads, float *out,
+                         void *stream);
 /* child = parent + sigma * eps(seed, stream, p), p = canonical flat index; Philox4x32-7 (the Crush-resistant minimum) + Box-Muller with
  * fmaf-only polynomials (bit-reproducible against the oracle).  Replaces clone()+Agent.mutate (agent.py:25-29,
  * genetic_algorithm.py:32-48) and Agent.mutate_ES (agent.py:51-53).

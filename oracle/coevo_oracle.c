@@ -356,6 +356,13 @@ static void philox4x32(int rounds, uint32_t c0, uint32_t c1, uint32_t c2, uint32
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+/* the generator as such (known-answer tests hold it against Random123's published vectors) */
+void oracle_philox4x32(int rounds, const uint32_t ctr_key[6], uint32_t out[4])
+{
+    philox4x32(rounds, ctr_key[0], ctr_key[1], ctr_key[2], ctr_key[3], ctr_key[4], ctr_key[5], out);
+}
+int oracle_noise_rounds(void) { return COEVO_NOISE_ROUNDS; }
+
 static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                           uint32_t out[4])
 {

@@ -63,6 +63,8 @@ def lib():
         L.oracle_diversity.restype = C.c_double
         L.oracle_diversity.argtypes = [fp, fp, C.c_int, C.c_size_t, ip, ip, C.c_int, fp]
         L.oracle_philox_normal4.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, fp]
+        L.oracle_philox4x32.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.oracle_noise_rounds.restype = C.c_int
         L.oracle_perturb_philox.argtypes = [fp, fp, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32,
                                             ip, ip, C.c_int, C.c_int]
         L.oracle_es_update_from_pert.argtypes = [fp, C.c_int, fp, fp, C.c_int, C.c_float, ip, ip, C.c_int, C.c_int]

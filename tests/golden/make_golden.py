@@ -164,15 +164,17 @@ def mint_fc_forward():
 
 
 def mint_deepqn_forward():
+    """DeepQN.forward (Atari/deepqn.py:39-48) of six mutated nets covering C = 3, 4, 5, 6 frame planes and n = 6 / 18 actions on
+    eight frames each: five random, all-0, all-255, constant planes (tests/util.py:dqn_golden_frames)"""
+    from tests.util import DQN_FRAME_KINDS, dqn_golden_frames
     cases = []
-    for seed, C, n in [(0, 4, 6), (1, 6, 18)]:
+    for seed, C, n in [(0, 4, 6), (1, 6, 18), (2, 3, 6), (3, 5, 18), (4, 4, 18), (5, 6, 6)]:
         torch.manual_seed(seed)
         net = DeepQN(C, n, "float32")
         # make the BatchNorm affine non-trivial, as a GA mutation would
         for p in net.parameters():
             p.data += torch.normal(0, 0.02, size=p.size())
-        g = np.random.Generator(np.random.PCG64(200 + seed))
-        frames = g.integers(0, 256, size=(2, 84, 84, C), dtype=np.uint8)
+        frames = dqn_golden_frames(C, 200 + seed)
         logits = []
         for r in range(frames.shape[0]):
             x = torch.from_numpy(frames[r]).to(torch.float32).permute(2, 0, 1).unsqueeze(0)
@@ -183,7 +185,7 @@ def mint_deepqn_forward():
                             if not k.endswith("num_batches_tracked")
                             and "running" not in k]).astype(np.float32)
         cases.append({"torch_seed": seed, "C": C, "n_actions": n, "frame_pcg_seed": 200 + seed,
-                      "frame_sha256": hashlib.sha256(frames.tobytes()).hexdigest(),
+                      "frame_kinds": DQN_FRAME_KINDS, "frame_sha256": hashlib.sha256(frames.tobytes()).hexdigest(),
                       "logits": logits, "mutate_std": 0.02,
                       "weights_sha256": hashlib.sha256(w.tobytes()).hexdigest()})
     dump("deepqn_forward.json", {"cases": cases})

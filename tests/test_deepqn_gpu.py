@@ -33,7 +33,10 @@ def test_dqn_forward_bit_exact_vs_oracle(C, n_actions, rows):
 
 
 def test_dqn_matches_reference_logits_fixture():
-    """the product's DeepQN mirror: same parameters as the reference's (sha256) and logits within fp32 summation noise"""
+    """the product's DeepQN mirror on the widened pin (six nets: C = 3, 4, 5, 6 planes, 6 / 18 actions; eight frames each incl.
+    all-0 / all-255 / constant planes): same parameters as the reference's (sha256), logits within fp32 summation noise of the
+    reference's, and - the equality that guards the build-defined BatchNorm order - HIP == oracle bit for bit on these frames"""
+    from tests.util import DQN_FRAME_KINDS, dqn_golden_frames
     for case in load_golden("deepqn_forward.json")["cases"]:
         torch.manual_seed(case["torch_seed"])
         C, n = case["C"], case["n_actions"]
@@ -41,10 +44,10 @@ def test_dqn_matches_reference_logits_fixture():
         for p in net.parameters():
             p.data += torch.normal(0, case["mutate_std"], size=p.size())
         assert sha(net.flat()) == case["weights_sha256"]
-        g = np.random.Generator(np.random.PCG64(case["frame_pcg_seed"]))
-        frames = g.integers(0, 256, size=(2, 84, 84, C), dtype=np.uint8)
+        frames = dqn_golden_frames(C, case["frame_pcg_seed"])
         assert hashlib.sha256(frames.tobytes()).hexdigest() == case["frame_sha256"]
-        for r in range(2):
+        logits, actions = dq.batched_actions([net.flat()], [frames], C, n)   # all eight frames of the net in one launch
+        for r in range(len(DQN_FRAME_KINDS)):
             x = torch.from_numpy(frames[r]).to(torch.float32).permute(2, 0, 1).unsqueeze(0)  # preprocess_observation
             out = net.forward(x).numpy()[0]
             ref = np.array(case["logits"][r], dtype=np.float32)
@@ -52,6 +55,9 @@ def test_dqn_matches_reference_logits_fixture():
             srt = np.sort(ref)[::-1]
             if srt[0] - srt[1] > 1e-3:
                 assert net.determine_action(x, None) == int(np.argmax(ref))
+            a, want = rp.dqn_forward(net.flat(), C, n, frames[r])
+            assert np.array_equal(logits[r][:n].view(np.uint32), want.view(np.uint32)), (C, n, DQN_FRAME_KINDS[r])
+            assert np.array_equal(out.view(np.uint32), want.view(np.uint32)) and actions[r] == a
 
 
 def test_dqn_nan_propagates_and_no_action_is_an_error():

@@ -599,3 +599,38 @@ def test_multi_job_launches_equal_per_role_launches():
     L.call("coevo_mpe_reset_multi", L._p(b), n_games, C.cast(arr, C.c_void_p), len(segs), rng)
     torch.cuda.synchronize()
     assert torch.equal(a, b) and float(a[:, :33].abs().sum()) > 0.0
+
+
+def test_philox_kernel_known_answers_and_normals():
+    """the device generator against Random123's published vectors (7 and 10 rounds), its Gaussians against the oracle's bit
+    for bit over three streams, and the moments of 4 M device normals (agent.py:27-28 / :52 in the device_philox mode)"""
+    from tests.test_oracle_golden import PHILOX_KAT
+    import ctypes as C
+    lib = L.load()
+    assert lib.coevo_noise_rounds() == 7
+    for rounds in (7, 10):
+        kat = [k for k in PHILOX_KAT if k[0] == rounds]
+        ck = torch.from_numpy(np.array([k[1] for k in kat], dtype=np.uint32).view(np.int32)).cuda()
+        out = torch.zeros(len(kat), 4, dtype=torch.int32, device="cuda")
+        L.call("coevo_philox4x32", rounds, L._p(ck), len(kat), L._p(out))
+        got = out.cpu().numpy().view(np.uint32)
+        assert got.tolist() == [k[2] for k in kat], rounds
+    olib = rp.lib()
+    for seed, lo, hi, q0 in ((0, 0, 0, 0), (7, 199, 41, 1000), ((1 << 40) + 3, 2 ** 31, 3, 2 ** 32 - 600)):
+        z = torch.zeros(512, 4, dtype=torch.float32, device="cuda")
+        L.call("coevo_philox_normals", seed, lo, hi, q0, 512, L._p(z))
+        got = z.cpu().numpy()
+        want = np.empty((512, 4), np.float32)
+        buf = (C.c_float * 4)()
+        for i in range(512):
+            olib.oracle_philox_normal4(seed, lo, hi, (q0 + i) & 0xffffffff, buf)
+            want[i] = buf[:]
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (seed, lo, hi)
+    n = 1 << 20
+    z = torch.zeros(n, 4, dtype=torch.float32, device="cuda")
+    L.call("coevo_philox_normals", 3, 17, 5, 0, n, L._p(z))
+    x = z.double().reshape(-1)
+    se = 5.0 / np.sqrt(x.numel())
+    assert abs(float(x.mean())) < se and abs(float(x.var()) - 1.0) < se * np.sqrt(2)
+    assert abs(float((x ** 4).mean()) - 3.0) < se * np.sqrt(96)
+    assert abs(float((x[:-1] * x[1:]).mean())) < se

@@ -168,24 +168,107 @@ def test_es_long_horizon_and_early_stopping(name):
     assert exact or name == "es_long.json"
 
 
-def test_deepqn_forward_vectors():
-    """oracle DeepQN.forward vs the logits the reference's DeepQN produced (train-mode BatchNorm at batch 1 =
-    per-sample spatial statistics).  Tolerance = fp32 summation-order noise of 3136-term dot products."""
+def test_deepqn_forward_vectors(capsys):
+    """oracle DeepQN.forward vs the logits the reference's DeepQN produced (train-mode BatchNorm at batch 1 = per-sample
+    spatial statistics) on six nets (C = 3, 4, 5, 6 planes; 6 / 18 actions) x eight frames: five random ones and
+    three structured ones (all-0, all-255, constant planes: every conv1 channel is ONE value, BatchNorm variance -> 0, the
+    normalised activation is (x - mean) * 316 with x - mean the rounding noise of the mean's summation order - the one place
+    where torch's order and the build's canonical order, DESIGN 2: lane-strided sums + one tree, could drift apart).
+    Tolerance for all of them = fp32 summation-order noise of 3136-term dot products: rtol 1e-4 / atol 2e-5.  The measured
+    worst errors are printed and recorded in DESIGN.md (this build: 2.3e-6 abs on random, 9.7e-7 abs on structured frames)."""
     import hashlib
+    from tests.util import DQN_FRAME_KINDS, dqn_golden_frames
+    worst = {"random": [0.0, 0.0], "structured": [0.0, 0.0]}
+    seen = set()
     for case in load_golden("deepqn_forward.json")["cases"]:
         torch.manual_seed(case["torch_seed"])
         C, n = case["C"], case["n_actions"]
+        seen.add((C, n))
         flat, shapes = rp.dqn_init(C, n)
         flat = rp.dqn_mutate_torch(flat, shapes, case["mutate_std"])
         assert len(flat) == rp.lib().oracle_dqn_param_count(C, n)
         assert sha(flat) == case["weights_sha256"]  # same parameters as the reference's DeepQN, byte for byte
-        g = np.random.Generator(np.random.PCG64(case["frame_pcg_seed"]))
-        frames = g.integers(0, 256, size=(2, 84, 84, C), dtype=np.uint8)
+        frames = dqn_golden_frames(C, case["frame_pcg_seed"])
+        assert case["frame_kinds"] == DQN_FRAME_KINDS
         assert hashlib.sha256(frames.tobytes()).hexdigest() == case["frame_sha256"]
-        for r in range(2):
+        for r, kind in enumerate(DQN_FRAME_KINDS):
             a, logits = rp.dqn_forward(flat, C, n, frames[r])
             ref = np.array(case["logits"][r], dtype=np.float32)
+            cls = "random" if kind == "random" else "structured"
+            err = np.abs(logits - ref)
+            worst[cls][0] = max(worst[cls][0], float(err.max()))
+            worst[cls][1] = max(worst[cls][1], float((err / np.maximum(np.abs(ref), 1e-3)).max()))
             np.testing.assert_allclose(logits, ref, rtol=1e-4, atol=2e-5)
             srt = np.sort(ref)[::-1]
             if srt[0] - srt[1] > 1e-3:
                 assert a == int(np.argmax(ref))
+    assert {c for c, _ in seen} == {3, 4, 5, 6} and {m for _, m in seen} == {6, 18}
+    with capsys.disabled():
+        print(f"\n[deepqn pin] oracle vs reference logits: random frames max abs {worst['random'][0]:.3g} / max rel "
+              f"{worst['random'][1]:.3g}; structured frames (BatchNorm variance -> 0) max abs {worst['structured'][0]:.3g} / "
+              f"max rel {worst['structured'][1]:.3g}")
+
+
+# Random123 kat_vectors (Salmon et al., SC'11 reference implementation): philox4x32 R  counter[4] key[2] -> expected[4]
+PHILOX_KAT = [
+    (7, [0x00000000] * 6, [0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48]),
+    (7, [0xffffffff] * 6, [0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662]),
+    (7, [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0],
+     [0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a]),
+    (10, [0x00000000] * 6, [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+    (10, [0xffffffff] * 6, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+    (10, [0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0],
+     [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+]
+
+
+def test_philox_known_answers_and_round_count():
+    """the offspring noise generator against PUBLISHED known-answer vectors (independent of this build): the oracle's
+    Philox4x32 at 7 rounds (the offspring noise) and at 10 (the synthetic env's frames); the library and the oracle state the
+    same round count, and the C ABI version says that the noise contract is the 7-round one (COEVO_VERSION 101)"""
+    import ctypes as C
+    from coevonet_amd import lib as L
+    lib = rp.lib()
+    for rounds, ck, want in PHILOX_KAT:
+        out = (C.c_uint32 * 4)()
+        lib.oracle_philox4x32(rounds, (C.c_uint32 * 6)(*ck), out)
+        assert list(out) == want, (rounds, [hex(v) for v in out])
+    assert lib.oracle_noise_rounds() == 7 == L.load().coevo_noise_rounds()
+    assert L.load().coevo_version() >= 101
+
+
+def test_philox_normals_moments_and_independence():
+    """Box-Muller over Philox4x32-7 as the offspring kernels consume it (oracle_philox_normal4 = philox_normal4 bit for bit,
+    tests/test_kernels_gpu.py): 4 x 60 000 normals of one stream - mean, variance, skewness, kurtosis within 5 standard
+    errors; no correlation between consecutive normals, between the four normals of a counter, between the same counter of
+    ADJACENT streams (stream_lo + 1: the next child; stream_hi + 1: the next role / generation) or adjacent seeds"""
+    import ctypes as C
+    lib = rp.lib()
+    nq = 60000
+
+    def stream(seed, lo, hi):
+        out = np.empty((nq, 4), np.float32)
+        z = (C.c_float * 4)()
+        for q in range(nq):
+            lib.oracle_philox_normal4(seed, lo, hi, q, z)
+            out[q] = z[:]
+        return out.astype(np.float64)
+
+    a = stream(0, 5, 8)
+    x = a.reshape(-1)
+    n = x.size
+    assert np.isfinite(x).all() and np.abs(x).max() < 6.0      # u1 in (0, 1]: no infinities; 24-bit uniforms cap |z| at 5.8
+    se = 5.0 / np.sqrt(n)
+    assert abs(x.mean()) < se and abs(x.var() - 1.0) < se * np.sqrt(2)
+    assert abs((x ** 3).mean()) < se * np.sqrt(15) and abs((x ** 4).mean() - 3.0) < se * np.sqrt(96)
+
+    def corr(u, v):
+        return float(np.mean((u - u.mean()) * (v - v.mean())) / (u.std() * v.std()))
+
+    assert abs(corr(x[:-1], x[1:])) < se and abs(corr(x[:-4], x[4:])) < se         # lag 1, and the same lane of the next counter
+    for i in range(4):
+        for j in range(i + 1, 4):
+            assert abs(corr(a[:, i], a[:, j])) < 5.0 / np.sqrt(nq)                 # within one counter's four outputs
+    for other in (stream(0, 6, 8), stream(0, 5, 9), stream(1, 5, 8)):              # next child / next role-generation / next seed
+        assert abs(corr(x, other.reshape(-1))) < se
+        assert abs(corr(x ** 2, other.reshape(-1) ** 2)) < se

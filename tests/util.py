@@ -34,3 +34,17 @@ class Bag:
 # top-2 logit margin below which an action of the reference's torch-CPU forward may legitimately differ
 # from the canonical-order forward (fp32 summation-order noise on |logit| ~ 1 is ~1e-6)
 SAFE_MARGIN = 1e-4
+
+
+# the frames of tests/golden/deepqn_forward.json: five random ones, then three structured ones on which every BatchNorm
+# channel of conv1 sees ONE value (variance -> 0: the normalised activation is rounding noise times 1/sqrt(1e-5))
+DQN_FRAME_KINDS = ["random"] * 5 + ["all_0", "all_255", "constant_planes"]
+
+
+def dqn_golden_frames(C, pcg_seed):
+    g = np.random.Generator(np.random.PCG64(pcg_seed))
+    frames = g.integers(0, 256, size=(len(DQN_FRAME_KINDS), 84, 84, C), dtype=np.uint8)
+    frames[5] = 0
+    frames[6] = 255
+    frames[7] = (37 * (np.arange(C) + 1) % 256).astype(np.uint8)[None, None, :]
+    return frames
