@@ -293,6 +293,7 @@ __device__ __forceinline__ void fc_policy_body(const FcArgs &a, FcSmem<R, P> &sm
             a0[p][r] = relu_keep_nan(y0);
             a1[p][r] = relu_keep_nan(y1);
         }
+    asm volatile("" : "+v"(st));   // this phase's status bits settled here (see fc_policy_mfma16_body)
     COEVO_STAMP(2);
     COEVO_STAMP(11);
 
@@ -401,6 +402,7 @@ __device__ __forceinline__ void fc_policy_body(const FcArgs &a, FcSmem<R, P> &sm
             if (r < nrows[p] && bad_post_relu(y)) st |= COEVO_ST_BAD_FC2;
             sm.h2[p][r][t] = relu_keep_nan(y);
         }
+    asm volatile("" : "+v"(st));   // this phase's status bits settled here (see fc_policy_mfma16_body)
     __syncthreads();
     COEVO_STAMP(4);
 
@@ -945,6 +947,7 @@ __device__ __forceinline__ void fc_policy_mfma_body(const FcArgs &a, FcMfmaSmem 
             }
         }
     }
+    asm volatile("" : "+v"(st));   // this phase's status bits settled here (see fc_policy_mfma16_body)
     __syncthreads();
     COEVO_STAMP(2);
 
@@ -1035,6 +1038,7 @@ __device__ __forceinline__ void fc_policy_mfma_body(const FcArgs &a, FcMfmaSmem 
             }
         }
     }
+    asm volatile("" : "+v"(st));   // this phase's status bits settled here (see fc_policy_mfma16_body)
     __syncthreads();
     COEVO_STAMP(4);
 
@@ -1120,23 +1124,25 @@ __device__ __forceinline__ void fc_policy_mfma16_body(const FcArgs &a, FcMfma16S
     const float *net = a.slab + task.net_off;
     int st = 0;
 
-    // ---- all small parameters and the whole fc1 B operand requested up front ---------------------------------
-    // (Requesting these where they are used instead - they are L2 hits - frees 60 registers across the env step, but
-    // the loads then queue behind the streaming workgroups' traffic: the fc1 + LayerNorm phase grew from 9 to 42 us.)
+    // ---- W1t, fc1.bias and the LayerNorm(512) affine - (D + 3) * 512 contiguous floats of the slab - by LDS-DMA into the
+    //      region that later holds fc2's A operands (26 KiB of its 32), as the per-individual body stages them: requested
+    //      first, so they do not queue behind the streaming workgroups' traffic, and NOT held in registers across the env
+    //      step, whose fp64 state is this body's register peak (as 53 live registers they cost 24 bytes of scratch at four
+    //      workgroups per CU).  Read into registers after the barrier below; the region is rewritten three barriers later.
     constexpr int KS = 3;  // k-steps of fc1 (D <= 12)
-    float w1[KS][8], p_b1[8], p_g1[8], p_be1[8], p_b2[4], p_g2[4], p_be2[4];
+    float *par = &sm.h1a[0][0];
     {
-        const float *b1p = net + fc_off_b1(D), *b2p = net + fc_off_b2(D);
+        const int n_pieces = (D + 3) * (H1 / 4);
 #pragma unroll
-        for (int q = 0; q < KS; ++q)
-#pragma unroll
-            for (int T = 0; T < 8; ++T)  // a padded k contributes fma(0, -0, acc) = acc for every acc, -0 included
-                w1[q][T] = (4 * q + lg < D) ? net[(size_t)(4 * q + lg) * H1 + 128 * w + 16 * T + lc] : -0.0f;
-#pragma unroll
-        for (int T = 0; T < 8; ++T) {
-            const int j = 128 * w + 16 * T + lc;
-            p_b1[T] = b1p[j]; p_g1[T] = b1p[H1 + j]; p_be1[T] = b1p[2 * H1 + j];
-        }
+        for (int j = 0; j < 7; ++j)
+            if (64 * w + 256 * j < n_pieces)   // wave-uniform
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(net + 4 * (t + 256 * j)),
+                                                 (__attribute__((address_space(3))) void *)(par + 4 * (64 * w + 256 * j)),
+                                                 16, 0, 0);
+    }
+    float p_b2[4], p_g2[4], p_be2[4];
+    {
+        const float *b2p = net + fc_off_b2(D);
 #pragma unroll
         for (int T = 0; T < 4; ++T) p_b2[T] = b2p[64 * w + 16 * T + lc];
     }
@@ -1189,22 +1195,37 @@ __device__ __forceinline__ void fc_policy_mfma16_body(const FcArgs &a, FcMfma16S
             p_g2[T] = b2p[H2 + j]; p_be2[T] = b2p[2 * H2 + j];
         }
     }
-    __syncthreads();
+    __syncthreads();   // (waits for the LDS-DMA too: the fence counts it on vmcnt)
     COEVO_STAMP(1);
+    // (registers: the bias first, then one k-step's eight B operands at a time, the LayerNorm affine only after the matrix
+    // instructions - all 48 parameter values at once next to the 32 accumulators were this body's new register peak)
+    const float *b1s = par + (size_t)D * H1;
 
     // ---- fc1: 8 column tiles per wave, ceil(D/4) k-steps --------------------------------------------------
     f32x4_acc c1[8];
 #pragma unroll
-    for (int T = 0; T < 8; ++T)
+    for (int T = 0; T < 8; ++T) {
+        const float b = b1s[128 * w + 16 * T + lc];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) c1[T][i] = p_b1[T];
+        for (int i = 0; i < 4; ++i) c1[T][i] = b;
+    }
 #pragma unroll
     for (int q = 0; q < KS; ++q) {
         if (4 * q < D) {  // wave-uniform
             const float av = sm.xst[4 * q + lg][lc];
+            float w1[8];
 #pragma unroll
-            for (int T = 0; T < 8; ++T) c1[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w1[q][T], c1[T], 0, 0, 0);
+            for (int T = 0; T < 8; ++T)  // a padded k contributes fma(0, -0, acc) = acc for every acc, -0 included
+                w1[T] = (4 * q + lg < D) ? par[(size_t)(4 * q + lg) * H1 + 128 * w + 16 * T + lc] : -0.0f;
+#pragma unroll
+            for (int T = 0; T < 8; ++T) c1[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, w1[T], c1[T], 0, 0, 0);
         }
+    }
+    float p_g1[8], p_be1[8];
+#pragma unroll
+    for (int T = 0; T < 8; ++T) {
+        const int j = 128 * w + 16 * T + lc;
+        p_g1[T] = b1s[H1 + j]; p_be1[T] = b1s[2 * H1 + j];
     }
     // ---- LayerNorm(512): canonical blocks 2w (tiles 0..3) and 2w+1 (tiles 4..7); inside a block feature 16T' + lc:
     //      four tree levels inside the 16-lane row, then (T0 + T1) + (T2 + T3) ---------------------------------
@@ -1254,6 +1275,9 @@ __device__ __forceinline__ void fc_policy_mfma16_body(const FcArgs &a, FcMfma16S
             sm.h1a[k][row ^ ((k >> 2) & 3)] = relu_keep_nan(y);
         }
     }
+    // (the status bits of this phase settled HERE: left alone, the compiler keeps the 32 activations alive to test them at
+    // the very end of the body and spills across the fc2 stream to make room)
+    asm volatile("" : "+v"(st));
     __syncthreads();
     COEVO_STAMP(2);
 
@@ -1339,6 +1363,7 @@ __device__ __forceinline__ void fc_policy_mfma16_body(const FcArgs &a, FcMfma16S
             sm.h2[row][64 * w + 16 * T + lc] = relu_keep_nan(y);
         }
     }
+    asm volatile("" : "+v"(st));
     __syncthreads();
     COEVO_STAMP(4);
 
