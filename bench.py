@@ -179,6 +179,9 @@ def main():
     ap.add_argument("--dqn-hof", type=int, default=10)
     ap.add_argument("--channels", type=int, default=4, help="frame channels: 4 = BASELINE's 84x84x4; the reference's "
                     "wrapper stack would yield 6")
+    ap.add_argument("--frames", default="device", choices=["device", "host"], help="dqn-ga / dqn-es: host = the env in host "
+                    "memory (frames rendered by the host cores, copied up every agent-step, actions copied down): the "
+                    "PCIe-inclusive form; device = frames synthesised in HBM (the measured form of cfg 4 / cfg 5)")
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other configs carried in "
                     "the headline JSON's `extra` block")
     ap.add_argument("--cohorts", type=int, default=None, help="independent game cohorts per rollout (default: the "
@@ -346,12 +349,22 @@ def run_dqn(a, ctx, dev, algo, pop_per_gpu=None, T=None):
     args.fitness_sharing = ga          # the GA always computes its diversity (Q3); ES without, as cfg 3
     args.generations = a.steps + a.warmup
     args.coevo_graph = False           # eager enqueue: HIP events bracket sampled launches of the dominant kernel
+    args.coevo_frames = a.frames
     env = initialize_env(args)
     tr = (DQNGATrainer if ga else DQNESTrainer)(env, args, collect=False, dist_ctx=ctx)
     eng = tr.eng
-    eng.ro.start_timing(pairs=2048, every=7)
+    host_frames = a.frames == "host"
+    if not host_frames:
+        eng.ro.start_timing(pairs=2048, every=7)
     dt = _timed_steps(tr.step, a, ctx, dev, before_timed=lambda: (torch.cuda.synchronize(), eng.ro.reset_timing()))
     conv_ms, fc1_ms = eng.ro.times_ms(0), eng.ro.times_ms(1)
+    frame_phase = None
+    if host_frames:   # one more generation with HIP events around every cohort-step's copies and forward
+        eng.ro.phase_us = np.zeros(5)
+        tr.step()
+        torch.cuda.synchronize()
+        frame_phase = eng.ro.phase_us.copy()
+        eng.ro.phase_us = None
     if ga:
         tr.finish()
     gens = a.steps / dt
@@ -369,6 +382,19 @@ def run_dqn(a, ctx, dev, algo, pop_per_gpu=None, T=None):
                       "population": pop, "agent_steps_per_generation": eng.steps_per_generation,
                       "games_per_launch": n_frames, "cohorts": len(eng.ro.lanes), "offspring": "device_philox",
                       "parallelism": f"population shard x{ctx.world}" if ctx.world > 1 else "single GPU"}}
+    if frame_phase is not None:
+        K = len(eng.ro.lanes)
+        per_cohort = eng.ro.n_games / K * 84 * 84 * a.channels
+        out["host_frames"] = {"host_cores": eng.ro.threads, "cohorts": K, "frame_bytes_per_agent_step": eng.ro.n_games * 84 * 84 * a.channels,
+                              "per_cohort_step_us": {"host_wait_for_actions": float(frame_phase[0]),
+                                                     "host_book_and_render": float(frame_phase[1]),
+                                                     "h2d_frames": float(frame_phase[2]), "forward": float(frame_phase[3]),
+                                                     "d2h_actions": float(frame_phase[4])},
+                              "pcie_h2d_GBps": per_cohort / max(float(frame_phase[2]), 1e-9) / 1e3,
+                              "agent_step_ms": 1e3 * dt / a.steps / max(T, 1),
+                              "copy_hidden_under_other_cohort": bool(K > 1 and frame_phase[2] <= frame_phase[1] + frame_phase[0]),
+                              "note": "SYNTHETIC env in host memory; the frames of a step depend on the previous step's "
+                                      "actions, so a cohort's copy can only hide under ANOTHER cohort's host / GPU work"}
     if conv_ms and fc1_ms:
         c_avg, f_avg = float(np.mean(conv_ms)), float(np.mean(fc1_ms))
         tf = n_frames * 2 * mac / (c_avg * 1e-3) / 1e12
@@ -417,15 +443,16 @@ def L_load():
 
 def pmc_traffic(workload, kernel_substr):
     """HBM bytes per launch of a kernel from the tracked PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter
-    per pass, gfx950 correction applied: tools/pmc_traffic.py): (bytes, source) or (None, None)"""
-    path = os.path.join(REPO, "profiles", "r03_pmc_hbm_traffic.json")
-    if not os.path.exists(path):
-        return None, None
-    with open(path) as f:
-        j = json.load(f)
-    for name, e in j.get("workloads", {}).get(workload, {}).get("kernels", {}).items():
-        if kernel_substr in name and "hbm_bytes_per_launch" in e:
-            return e["hbm_bytes_per_launch"], f"profiles/r03_pmc_hbm_traffic.json [{workload}] {name}"
+    per pass, gfx950 correction applied: tools/pmc_traffic_all.py), newest round first: (bytes, source) or (None, None)"""
+    for tag in ("r04", "r03"):
+        path = os.path.join(REPO, "profiles", f"{tag}_pmc_hbm_traffic.json")
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            j = json.load(f)
+        for name, e in j.get("workloads", {}).get(workload, {}).get("kernels", {}).items():
+            if kernel_substr in name and "hbm_bytes_per_launch" in e:
+                return e["hbm_bytes_per_launch"], f"profiles/{tag}_pmc_hbm_traffic.json [{workload}] {name}"
     return None, None
 
 
@@ -462,6 +489,8 @@ def extras(a, ctx, dev):
                 ex[name]["roofline"] = slim_rl(r["roofline"])
             if r.get("host_env"):
                 ex[name]["host_env"] = r["host_env"]
+            if r.get("host_frames"):
+                ex[name]["host_frames"] = {k: v for k, v in r["host_frames"].items() if k != "note"}
         except Exception as e:
             ex[name] = {"error": repr(e)[:200]}
         gc.collect()
@@ -495,6 +524,10 @@ def extras(a, ctx, dev):
     # (two timed generations under-reported cfg5 by 15 %: the first ones carry one-off host work)
     leg("cfg4_shard", lambda: run_dqn(b, ctx, dev, "ga"))
     leg("cfg5_shard", lambda: run_dqn(b, ctx, dev, "es"))
+    # PCIe-inclusive: the (synthetic) env in host memory, frames up / actions down every agent-step
+    hf = copy.copy(b)
+    hf.frames, hf.steps, hf.warmup = "host", 2, 1
+    leg("cfg4_shard_host_frames", lambda: run_dqn(hf, ctx, dev, "ga"))
     # six frame planes: what the reference's wrapper stack yields (frame_stack_v1(4) + agent_indicator_v0,
     # utils/game_logic_functions.py:50-53; Atari/atari_agent.py:20); BASELINE.json words the configs as 84x84x4
     c6 = copy.copy(b)
@@ -504,7 +537,8 @@ def extras(a, ctx, dev):
     ex["legend"] = ("cfg2_T200: env max_cycles 67; cfg2_host_env: env on the host cores (PCIe-inclusive); cfg2_shard_1_of_N: "
                     "rank 0 of pop 200 over N GPUs rehearsed on this GPU, no collective; cfg3: Co-ES pop 1000 (extension = "
                     "antithetic + centered ranks, not in the reference); cfg4 / cfg5: per-GPU shards (pop 50, HoF 10 / pop 250) "
-                    "over DeepQN on SYNTHETIC 84x84x4 frames (6_planes: 84x84x6)")
+                    "over DeepQN on SYNTHETIC 84x84x4 frames (6_planes: 84x84x6; host_frames: the env in host memory, frames over PCIe "
+                    "every agent-step)")
     return ex
 
 

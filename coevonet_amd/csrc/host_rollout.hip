@@ -59,11 +59,11 @@ struct HostPool {
         const int me = sched_getcpu();
         for (int i = 1; i < T; ++i) {
             th.emplace_back([this, i] { worker(i); });
-            if (pin && me >= 0 && T <= 8) {
-                const int base = me & ~7;
+            if (pin && me >= 0 && T <= 16) {   // (up to 16 threads: two neighbouring complexes of the same socket)
+                const int span = T <= 8 ? 8 : 16, base = me & ~(span - 1);
                 cpu_set_t set;
                 CPU_ZERO(&set);
-                CPU_SET(base + ((me - base + i) & 7), &set);
+                CPU_SET(base + ((me - base + i) & (span - 1)), &set);
                 (void)pthread_setaffinity_np(th.back().native_handle(), sizeof(set), &set);
             }
         }
@@ -499,6 +499,233 @@ extern "C" int coevo_mpe_host_rollout(void *handle, const coevo_host_rollout_des
         }
         for (int i = 0; i < 6; ++i) d->phase_us[i] = tot[i] / (n > 0 ? n : 1);
     }
+    return COEVO_OK;
+}
+
+
+// =====================================================================================================================
+// coevo_dqn_host_frames_rollout - the DeepQN games with the env on the HOST: what the reference's play_atari drives through
+// env.observe / env.step / env.last (utils/game_logic_functions.py:84-120) with its ALE + SuperSuit env living in host memory
+// (:47-53), for all of a rank's games at once.  The env here is the synthetic Atari-shaped one (coevonet_amd/
+// atari_synthetic.py; device twin synth_step_kernel, csrc/dqn_engine.hip): per agent-step and cohort the host cores book the
+// previous action (hit / zero-sum reward, fp64) and render the next 84 x 84 x C uint8 frame of every live game into a
+// page-locked buffer (Philox4x32-10 keyed by game ordinal, step and previous action: the SAME bytes the device twin writes,
+// so rewards are bit-identical), the cohort's stream copies the frames up (28 224 bytes per game and step at C = 4), runs
+// conv stack + fc1 + output layer (coevo_dqn_forward_argmax) and copies the actions down.  Cohorts alternate: one cohort's
+// copy and launches run while the cores render the next cohort's frames.  This is the PCIe-inclusive form of the cfg 4 /
+// cfg 5 legs; the device-resident form (frames never leave HBM) is the measured headline of those configs.
+namespace {
+
+constexpr uint32_t PHILOX_M0 = 0xD2511F53u, PHILOX_M1 = 0xCD9E8D57u, PHILOX_W0 = 0x9E3779B9u, PHILOX_W1 = 0xBB67AE85u;
+
+inline void philox10_host(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)PHILOX_M0 * c0, p1 = (uint64_t)PHILOX_M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += PHILOX_W0; k1 += PHILOX_W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// 16 bytes per counter i = 0 .. n16-1 (synth_frame of atari_synthetic.py / the frame loop of synth_step_kernel), eight
+// counters at a time in struct-of-arrays form so that the host compiler turns the rounds into 8-wide vector code
+#define COEVO_FRAME_BODY(W)                                                                                            \
+    for (int i0 = 0; i0 < n16; i0 += W) {                                                                             \
+        uint32_t a[W], b[W], c[W], d[W];                                                                              \
+        for (int j = 0; j < W; ++j) { a[j] = (uint32_t)(i0 + j); b[j] = c1; c[j] = c2; d[j] = c3; }                   \
+        uint32_t ka = k0, kb = k1;                                                                                    \
+        for (int r = 0; r < 10; ++r) {                                                                                \
+            for (int j = 0; j < W; ++j) {                                                                             \
+                const uint64_t p0 = (uint64_t)PHILOX_M0 * a[j], p1 = (uint64_t)PHILOX_M1 * c[j];                      \
+                const uint32_t n0 = (uint32_t)(p1 >> 32) ^ b[j] ^ ka, n2 = (uint32_t)(p0 >> 32) ^ d[j] ^ kb;          \
+                a[j] = n0; b[j] = (uint32_t)p1; c[j] = n2; d[j] = (uint32_t)p0;                                       \
+            }                                                                                                         \
+            ka += PHILOX_W0; kb += PHILOX_W1;                                                                         \
+        }                                                                                                             \
+        const int lim = n16 - i0 < W ? n16 - i0 : W;                                                                  \
+        uint32_t *o = reinterpret_cast<uint32_t *>(dst) + 4 * (size_t)i0;                                             \
+        for (int j = 0; j < lim; ++j) { o[4 * j] = a[j]; o[4 * j + 1] = b[j]; o[4 * j + 2] = c[j]; o[4 * j + 3] = d[j]; } \
+    }
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target("avx2"))) void synth_frame_avx2(uint8_t *dst, int n16, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                      uint32_t k0, uint32_t k1)
+{
+    COEVO_FRAME_BODY(8)
+}
+__attribute__((target("avx512f,avx512vl,avx512dq"))) void synth_frame_avx512(
+    uint8_t *dst, int n16, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+    COEVO_FRAME_BODY(16)
+}
+#endif
+void synth_frame_base(uint8_t *dst, int n16, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+    COEVO_FRAME_BODY(8)
+}
+
+inline void synth_frame_host(uint8_t *dst, int nbytes, uint64_t seed, int64_t ordinal, int t, uint32_t last)
+{
+    const uint32_t c1 = (uint32_t)t | (last << 16), c2 = (uint32_t)ordinal,
+                   c3 = (uint32_t)((uint64_t)ordinal >> 32) ^ 0x66726d65u;
+#if !defined(__HIP_DEVICE_COMPILE__)
+    static const bool avx512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl") &&
+                               __builtin_cpu_supports("avx512dq");
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx512) {
+        synth_frame_avx512(dst, nbytes / 16, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
+        return;
+    }
+    if (avx2) {
+        synth_frame_avx2(dst, nbytes / 16, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
+        return;
+    }
+#endif
+    synth_frame_base(dst, nbytes / 16, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+inline uint32_t synth_target_host(uint64_t seed, int64_t ordinal, int t, int n_actions)
+{
+    uint32_t o[4];
+    philox10_host(0xFFFFFFFFu, (uint32_t)t, (uint32_t)ordinal, (uint32_t)((uint64_t)ordinal >> 32) ^ 0x74617267u,
+                  (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    return o[0] % (uint32_t)n_actions;
+}
+
+struct FrameJob {
+    const coevo_frames_rollout_desc *d;
+    const coevo_frame_cohort *c;
+    int t;
+};
+
+// the env's share of agent-step t for a slice of a cohort's games: book the action of step t-1, render frame t
+void frame_part(void *arg, int part, int parts)
+{
+    const FrameJob *j = static_cast<const FrameJob *>(arg);
+    const coevo_frames_rollout_desc *d = j->d;
+    const coevo_frame_cohort &c = *j->c;
+    const int t = j->t, p = t & 1, q = (t - 1) & 1;
+    const int nbytes = 84 * 84 * d->C;
+    const int lo = (int)((int64_t)c.n_games * part / parts), hi = (int)((int64_t)c.n_games * (part + 1) / parts);
+    for (int i = lo; i < hi; ++i) {
+        const int g = c.game_first + i;
+        const int64_t ordinal = d->game_ordinal0[g] + d->generation * d->ordinals_per_gen;
+        const int lim = ordinal < 0 ? 0 : d->limit[g];
+        int last = d->game_state[4 * g], prev_hit = d->game_state[4 * g + 1];
+        if (t == 0) {
+            last = 0xFF; prev_hit = 0;
+            d->acc[3 * (size_t)g] = 0.0; d->acc[3 * (size_t)g + 1] = 0.0; d->acc[3 * (size_t)g + 2] = 0.0;
+        } else if (t - 1 < lim) {
+            const int a = c.actions_host[c.rows[q][i]];
+            const int hit = ((uint32_t)a == synth_target_host(d->seed, ordinal, t - 1, d->n_actions)) ? 1 : 0;
+            const size_t slot = 3 * (size_t)g + ((t - 1) & 1);
+            d->acc[slot] = d->acc[slot] + (double)(prev_hit - hit);
+            prev_hit = hit;
+            last = a;
+        }
+        d->game_state[4 * g] = last;
+        d->game_state[4 * g + 1] = prev_hit;
+        if (t < d->T && t < lim)
+            synth_frame_host(c.frames_host + (size_t)c.rows[p][i] * nbytes, nbytes, d->seed, ordinal, t, (uint32_t)last);
+    }
+}
+
+}  // namespace
+
+extern "C" int coevo_dqn_host_frames_rollout(void *handle, const coevo_frames_rollout_desc *d, void *stream)
+{
+    auto *h = static_cast<HostRollout *>(handle);
+    if (!h || !d || !d->slab || !d->status || !d->game_state || !d->acc || !d->game_ordinal0 || !d->limit || !d->cohorts)
+        return COEVO_ERR_ARG;
+    if (d->n_games <= 0 || d->T < 0 || d->T > 65535 || d->C < 1 || d->C > 6 || d->n_actions < 1 || d->n_cohorts < 1 ||
+        d->n_cohorts > h->max_cohorts)
+        return COEVO_ERR_ARG;
+    const int K = d->n_cohorts;
+    const size_t nbytes = (size_t)84 * 84 * d->C;
+    int covered = 0;
+    for (int k = 0; k < K; ++k) {
+        const coevo_frame_cohort &c = d->cohorts[k];
+        if (c.n_games <= 0 || c.game_first != covered || !c.frames_host || !c.frames_dev || !c.actions_host || !c.actions_dev ||
+            !c.workspace)
+            return COEVO_ERR_ARG;
+        for (int p = 0; p < 2; ++p) {
+            if (!c.tasks[p] || !c.rows[p] || c.n_tasks[p] <= 0 || c.max_rows[p] < 1) return COEVO_ERR_ARG;
+            for (int i = 0; i < c.n_games; ++i)
+                if (c.rows[p][i] < 0 || c.rows[p][i] >= c.n_games) return COEVO_ERR_ARG;
+        }
+        covered += c.n_games;
+    }
+    if (covered != d->n_games) return COEVO_ERR_ARG;
+    {
+        const int rc_l = ensure_lanes(h);
+        if (rc_l) return rc_l;
+    }
+    const bool timed = d->phase_us != nullptr;
+    double acc_host = 0.0, acc_wait = 0.0, acc_gpu[3] = {0.0, 0.0, 0.0};
+    int acc_n = 0;
+    COEVO_HIP_CHECK(hipEventRecord(h->start, (hipStream_t)stream));
+    for (int k = 0; k < K; ++k) COEVO_HIP_CHECK(hipStreamWaitEvent(h->lanes[k].s, h->start, 0));
+    int rc = COEVO_OK;
+    for (int t = 0; t <= d->T && rc == COEVO_OK; ++t) {
+        for (int k = 0; k < K && rc == COEVO_OK; ++k) {
+            const coevo_frame_cohort &c = d->cohorts[k];
+            HostLane &ln = h->lanes[k];
+            const double t0 = timed ? now_us() : 0.0;
+            if (t > 0) {   // the actions of step t-1 are in actions_host
+                rc = wait_event(ln.done);
+                if (rc) break;
+                if (timed) {
+                    float ms;
+                    for (int i = 0; i < 3; ++i)
+                        if (hipEventElapsedTime(&ms, ln.t[i], ln.t[i + 1]) == hipSuccess) acc_gpu[i] += 1e3 * ms;
+                    ++acc_n;
+                }
+            }
+            const double t1 = timed ? now_us() : 0.0;
+            FrameJob job{d, &c, t};
+            h->pool.run(frame_part, &job);
+            if (timed) {
+                acc_wait += t1 - t0;
+                acc_host += now_us() - t1;
+            }
+            if (t == d->T) continue;
+            const int p = t & 1;
+            if (timed) COEVO_HIP_CHECK(hipEventRecord(ln.t[0], ln.s));
+            COEVO_HIP_CHECK(hipMemcpyAsync(c.frames_dev, c.frames_host, (size_t)c.n_games * nbytes, hipMemcpyHostToDevice, ln.s));
+            if (timed) COEVO_HIP_CHECK(hipEventRecord(ln.t[1], ln.s));
+            rc = coevo_dqn_forward_argmax(d->slab, c.tasks[p], c.n_tasks[p], c.max_rows[p], c.n_games, d->C, d->n_actions,
+                                          c.frames_dev, c.actions_dev, nullptr, d->status, c.workspace, ln.s);
+            if (rc) break;
+            if (timed) COEVO_HIP_CHECK(hipEventRecord(ln.t[2], ln.s));
+            COEVO_HIP_CHECK(hipMemcpyAsync(c.actions_host, c.actions_dev, (size_t)c.n_games * sizeof(int32_t),
+                                           hipMemcpyDeviceToHost, ln.s));
+            if (timed) COEVO_HIP_CHECK(hipEventRecord(ln.t[3], ln.s));
+            COEVO_HIP_CHECK(hipEventRecord(ln.done, ln.s));
+        }
+    }
+    if (rc != COEVO_OK) {
+        for (int k = 0; k < K; ++k) (void)hipStreamSynchronize(h->lanes[k].s);
+        return rc;
+    }
+    if (timed) {   // mean microseconds per cohort-step: host wait, host env (book + render), frames up, forward, actions down
+        const double n = acc_n > 0 ? (double)acc_n : 1.0;
+        d->phase_us[0] = acc_wait / n;
+        d->phase_us[1] = acc_host / n;
+        d->phase_us[2] = acc_gpu[0] / n;
+        d->phase_us[3] = acc_gpu[1] / n;
+        d->phase_us[4] = acc_gpu[2] / n;
+    }
+    return COEVO_OK;
+}
+
+// one frame on the calling thread: the bytes coevo_dqn_host_frames_rollout renders (tests: == atari_synthetic.synth_frame)
+extern "C" int coevo_synth_frame_host(uint8_t *dst, int C, uint64_t seed, int64_t ordinal, int t, int last_action)
+{
+    if (!dst || C < 1 || C > 6 || t < 0 || t > 65535) return COEVO_ERR_ARG;
+    synth_frame_host(dst, 84 * 84 * C, seed, ordinal, t, (uint32_t)last_action);
     return COEVO_OK;
 }
 

@@ -220,6 +220,97 @@ class SynthRollout:
         return len({int(t["net_off"]) for t in self.lanes[lane]["tasks_np"][parity]})
 
 
+class HostFrameRollout(SynthRollout):
+    """The same games with the synthetic env on the HOST (PCIe-inclusive: what an ALE env in host memory imposes,
+    utils/game_logic_functions.py:47-53,84-120): per agent-step and cohort the host cores book the previous action and render
+    the next frames into page-locked memory (the bytes coevo_synth_step writes on the device, so every reward is identical),
+    the cohort's stream copies them up (28 224 B per game and step at C = 4), runs conv stack + fc1 + output layer and copies
+    the actions down; the cohorts alternate.  One blocking C-ABI call per rollout (coevo_dqn_host_frames_rollout); the
+    bookkeeping (hits, fp64 returns) lives in host memory and is mirrored into the device tensors the engines read."""
+
+    def __init__(self, *a, threads=None, **k):
+        super().__init__(*a, **k)
+        n, K = self.n_games, len(self.lanes)
+        if threads is None:
+            threads = int(os.environ.get("COEVO_FRAME_THREADS", "0")) or min(16, os.cpu_count() or 1)
+        self.h_gstate = np.zeros((n, 4), dtype=np.int32)
+        self.h_acc = np.zeros((n, 3), dtype=np.float64)
+        self.h_ordinal0 = np.ascontiguousarray(self.ordinal0.cpu().numpy(), dtype=np.int64)
+        self.h_limit = np.zeros(n, dtype=np.int32)
+        self.frame_ctx = L.load().coevo_host_rollout_create(int(threads), K)
+        if not self.frame_ctx:
+            raise L.CoevoError("coevo_host_rollout_create failed")
+        self.threads = int(L.load().coevo_host_rollout_threads(self.frame_ctx))
+        self.phase_us = None          # a float64[5] array to collect the per-cohort-step breakdown
+        self._cohorts = (L.FrameCohort * K)()
+        self._keep = []
+        for k_, ln in enumerate(self.lanes):
+            m = ln["n"]
+            fh = torch.zeros(m * FRAME * self.C, dtype=torch.uint8).pin_memory()
+            ah = torch.zeros(m, dtype=torch.int32).pin_memory()
+            rows = [np.ascontiguousarray(ln["rows"][p].cpu().numpy(), dtype=np.int32) for p in range(2)]
+            self._keep.append((fh, ah, rows))
+            c = self._cohorts[k_]
+            for p in range(2):
+                c.tasks[p] = ln["tasks"][p].data_ptr()
+                c.rows[p] = rows[p].ctypes.data
+                c.n_tasks[p] = ln["n_tasks"][p]
+                c.max_rows[p] = ln["max_rows"][p]
+            c.frames_host, c.frames_dev = fh.data_ptr(), ln["frames"].data_ptr()
+            c.actions_host, c.actions_dev = ah.data_ptr(), ln["actions"][0].data_ptr()
+            c.workspace = ln["ws"].data_ptr()
+            c.game_first, c.n_games = ln["g0"], m
+
+    def set_limits(self, limits):
+        super().set_limits(limits)
+        self.h_limit[:] = np.asarray(limits, dtype=np.int32)
+
+    def enqueue(self, T, gen_dev):
+        """blocking: the whole rollout runs inside the C call; afterwards the device copies of the books are current"""
+        gen = int(gen_dev.item()) if gen_dev is not None else 0
+        d = L.FramesRolloutDesc(
+            slab=L._p(self.slab), status=L._p(self.status), game_state=self.h_gstate.ctypes.data, acc=self.h_acc.ctypes.data,
+            game_ordinal0=self.h_ordinal0.ctypes.data, limit=self.h_limit.ctypes.data,
+            cohorts=L.C.cast(self._cohorts, L.C.c_void_p),
+            phase_us=(self.phase_us.ctypes.data if self.phase_us is not None else None), generation=gen,
+            ordinals_per_gen=self.ordinals_per_gen, seed=self.env_seed, n_games=self.n_games, n_cohorts=len(self.lanes),
+            C=self.C, n_actions=self.n_actions, T=int(T), reserved=0)
+        L._check(L.load().coevo_dqn_host_frames_rollout(self.frame_ctx, L.C.byref(d), L._stream()),
+                 "coevo_dqn_host_frames_rollout")
+        self.acc.copy_(torch.from_numpy(self.h_acc))
+        self.gstate.copy_(torch.from_numpy(self.h_gstate))
+
+    def close(self):
+        super().close()
+        if getattr(self, "frame_ctx", None):
+            L.load().coevo_host_rollout_destroy(self.frame_ctx)
+            self.frame_ctx = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "frame_ctx", None):   # (joins the worker threads; no device call)
+                L.load().coevo_host_rollout_destroy(self.frame_ctx)
+                self.frame_ctx = None
+        except Exception:
+            pass
+        super().__del__()
+
+
+def frames_mode(args=None):
+    """"device" (frames synthesised in HBM: the measured form of cfg 4 / cfg 5) or "host" (args.coevo_frames /
+    COEVO_DQN_FRAMES): the env in host memory, frames over PCIe every agent-step"""
+    m = (getattr(args, "coevo_frames", None) if args is not None else None) or os.environ.get("COEVO_DQN_FRAMES", "device")
+    if m not in ("device", "host"):
+        raise ValueError(f"frames mode {m!r}: 'device' or 'host'")
+    return m
+
+
+def even_bounds(n, K):
+    K = max(1, min(int(K), n))
+    return [k * n // K for k in range(K + 1)]
+
+
+
 def dqn_init_flat(C, n_actions):
     """one randomly initialised DeepQN in canonical flat order (consumes the torch generator like DeepQN.__init__)"""
     return DeepQN(C, n_actions, "float32").flat().copy()
@@ -243,8 +334,9 @@ class _SlabMixin:
 class DQNGAEngine(_SlabMixin):
     def __init__(self, pop, hof, elites, C, n_actions, T_train, T_eval, device="cuda", env_seed=SYNTH_SEED,
                  philox_seed=0, shard=(0, 1), gather=None, first_ordinal=1, capacity=1024, sigmas=(0.05, 0.05),
-                 sig_min=0.001, sig_max=0.2, adaptive=True):
-        assert 1 <= elites <= pop and hof >= 1
+                 sig_min=0.001, sig_max=0.2, adaptive=True, frames="device"):
+        assert 1 <= elites <= pop and hof >= 1 and frames in ("device", "host")
+        self.frames = frames
         self.pop, self.hof, self.E, self.C, self.n_actions = pop, hof, elites, C, n_actions
         self.T_train, self.T_eval = int(T_train), int(T_eval)
         self.T = max(self.T_train, self.T_eval)
@@ -294,8 +386,10 @@ class DQNGAEngine(_SlabMixin):
         # stack and fc1 both live on the matrix pipe at these row counts, there is nothing complementary to overlap
         K = int(os.environ.get("COEVO_DQN_COHORTS", "1"))
         bounds = [0, self.n_main // 2, len(games)] if (K > 1 and self.n_main >= 2) else None
-        self.ro = SynthRollout(games, net_off, ordinal0, C, n_actions, self.slab, env_seed, self.per_gen, device,
-                               bounds=bounds)
+        if frames == "host":   # env in host memory: the cohorts alternate between the host cores and the GPU
+            bounds = even_bounds(len(games), int(os.environ.get("COEVO_FRAME_COHORTS", "3")))
+        self.ro = (HostFrameRollout if frames == "host" else SynthRollout)(
+            games, net_off, ordinal0, C, n_actions, self.slab, env_seed, self.per_gen, device, bounds=bounds)
         self.cohorts = len(self.ro.lanes)
         # ---- device-resident loop state ------------------------------------------------------------------------
         f32 = dict(dtype=torch.float32, device=device)
@@ -396,7 +490,7 @@ class DQNGAEngine(_SlabMixin):
             limits = np.full(self.ro.n_games, self.T_train, dtype=np.int32)
             limits[self.n_main:] = self.T_eval if gen == 1 else 0
             self.ro.set_limits(limits)
-        if self.world == 1 and use_graph and self.cohorts == 1:   # (cohort chains are enqueued eagerly on their streams)
+        if self.world == 1 and use_graph and self.cohorts == 1 and self.frames == "device":   # (cohort chains: eager)
             if self._graph is None:
                 torch.cuda.synchronize()
                 gr = torch.cuda.CUDAGraph()
@@ -467,7 +561,8 @@ class DQNGATrainer:
                                philox_seed=getattr(args, "coevo_seed", 0), shard=shard, gather=gather,
                                first_ordinal=self.first_ordinal, capacity=max(getattr(args, "generations", 0), 1) + 64,
                                sigmas=(args.mutation_power_agent_0, args.mutation_power_agent_1),
-                               sig_min=args.min_mutation_power, sig_max=args.max_mutation_power, adaptive=args.adaptive)
+                               sig_min=args.min_mutation_power, sig_max=args.max_mutation_power, adaptive=args.adaptive,
+                               frames=frames_mode(args))
         self.eng.load_initial(pop_flat, hof_flat)
         self.res = DQNResult()
         self.res.engine = self.eng
@@ -544,7 +639,10 @@ def es_cohort_bounds(n_local, K):
 
 class DQNESEngine(_SlabMixin):
     def __init__(self, pop, C, n_actions, T_train, T_eval, device="cuda", env_seed=SYNTH_SEED, philox_seed=0,
-                 shard=(0, 1), gather=None, first_ordinal=1, antithetic=False, centered_rank=False, chunks=8):
+                 shard=(0, 1), gather=None, first_ordinal=1, antithetic=False, centered_rank=False, chunks=8,
+                 frames="device"):
+        assert frames in ("device", "host")
+        self.frames = frames
         self.pop, self.C, self.n_actions, self.device = pop, C, n_actions, device
         self.T_train, self.T_eval = int(T_train), int(T_eval)
         self.philox_seed = int(philox_seed)
@@ -580,10 +678,13 @@ class DQNESEngine(_SlabMixin):
         # cohort's conv launch (matrix pipe) then runs under the other's fc1 stream (HBM): cfg 5 shard 9.5 vs 9.1
         # generations/s.  (Co-GA's 10-frame tasks are conv-bound: one cohort is faster there, 16.4 vs 15.6.)
         bounds = es_cohort_bounds(self.n_local, int(os.environ.get("COEVO_DQN_COHORTS", "2")))
-        self.ro = SynthRollout(games, net_off, ordinal0, C, n_actions, self.slab, env_seed, self.per_gen, device,
-                               bounds=bounds)
+        cls = HostFrameRollout if frames == "host" else SynthRollout
+        if frames == "host":
+            bounds = even_bounds(len(games), int(os.environ.get("COEVO_FRAME_COHORTS", "3")))
+            bounds = [b - (b & 1) for b in bounds[:-1]] + [bounds[-1]]   # an individual's two games stay in one cohort
+        self.ro = cls(games, net_off, ordinal0, C, n_actions, self.slab, env_seed, self.per_gen, device, bounds=bounds)
         self.ro.set_limits(np.full(self.n_main, self.T_train, dtype=np.int32))
-        self.eval_ro = SynthRollout([(0, 1)] * N_EVAL, net_off[:2], [first_ordinal + 2 * pop + j for j in range(N_EVAL)],
+        self.eval_ro = cls([(0, 1)] * N_EVAL, net_off[:2], [first_ordinal + 2 * pop + j for j in range(N_EVAL)],
                                     C, n_actions, self.slab, env_seed, self.per_gen, device)
         self.eval_ro.set_limits(np.full(N_EVAL, self.T_eval, dtype=np.int32))
         f32 = dict(dtype=torch.float32, device=device)
@@ -606,7 +707,8 @@ class DQNESEngine(_SlabMixin):
         # the evaluation rollout as a replayed hipGraph; with several ranks (an RCCL process group alive beside the capture)
         # that combination has never run on hardware, so it is opt-in there until a multi-GPU box has passed
         # tests/test_dist_gpu.py with COEVO_DQN_EVAL_GRAPH=1
-        self.eval_graph = os.environ.get("COEVO_DQN_EVAL_GRAPH", "1" if shard[1] == 1 else "0") != "0"
+        self.eval_graph = (os.environ.get("COEVO_DQN_EVAL_GRAPH", "1" if shard[1] == 1 else "0") != "0"
+                           and frames == "device")   # (a host-stepped rollout is a blocking call, not capturable)
         self._eval_graph = None
 
     def generation(self, gen, sigmas, lr, fitness_sharing):
@@ -685,7 +787,7 @@ class DQNESTrainer:
                                philox_seed=getattr(args, "coevo_seed", 0), shard=shard, gather=gather,
                                first_ordinal=self.first_ordinal, antithetic=getattr(args, "coevo_antithetic", False),
                                centered_rank=getattr(args, "coevo_centered_rank", False),
-                               chunks=getattr(args, "coevo_es_chunks", 8))
+                               chunks=getattr(args, "coevo_es_chunks", 8), frames=frames_mode(args))
         for r in ROLES2:
             self.eng.upload(r, "base", 0, base[r][None])
         self.res = DQNResult()

@@ -84,6 +84,21 @@ class HostRolloutDesc(C.Structure):   # coevo_host_rollout_desc
                 ("pos_first", C.c_int32), ("zero_copy", C.c_int32)]
 
 
+class FrameCohort(C.Structure):       # coevo_frame_cohort
+    _fields_ = [("tasks", C.c_void_p * 2), ("rows", C.c_void_p * 2), ("frames_host", C.c_void_p),
+                ("frames_dev", C.c_void_p), ("actions_host", C.c_void_p), ("actions_dev", C.c_void_p),
+                ("workspace", C.c_void_p), ("n_tasks", C.c_int32 * 2), ("max_rows", C.c_int32 * 2),
+                ("game_first", C.c_int32), ("n_games", C.c_int32)]
+
+
+class FramesRolloutDesc(C.Structure):   # coevo_frames_rollout_desc
+    _fields_ = [("slab", C.c_void_p), ("status", C.c_void_p), ("game_state", C.c_void_p), ("acc", C.c_void_p),
+                ("game_ordinal0", C.c_void_p), ("limit", C.c_void_p), ("cohorts", C.c_void_p), ("phase_us", C.c_void_p),
+                ("generation", C.c_int64), ("ordinals_per_gen", C.c_int64), ("seed", C.c_uint64),
+                ("n_games", C.c_int32), ("n_cohorts", C.c_int32), ("C", C.c_int32), ("n_actions", C.c_int32),
+                ("T", C.c_int32), ("reserved", C.c_int32)]
+
+
 class GaSelectRole(C.Structure):
     _fields_ = [("dist", C.c_void_p), ("rewards", C.c_void_p), ("diversity", C.c_void_p), ("fitness", C.c_void_p),
                 ("order", C.c_void_p), ("best_dist", C.c_void_p), ("game_first", C.c_int32), ("slot", C.c_int32)]
@@ -130,6 +145,8 @@ _SIGS = {
     "coevo_host_rollout_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                           C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "coevo_mpe_host_rollout": (C.c_int, [C.c_void_p, C.POINTER(HostRolloutDesc), C.c_void_p]),
+    "coevo_dqn_host_frames_rollout": (C.c_int, [C.c_void_p, C.POINTER(FramesRolloutDesc), C.c_void_p]),
+    "coevo_synth_frame_host": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_int, C.c_int]),
     "coevo_mpe_rewards": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "coevo_mpe_policy_cycle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -527,6 +527,41 @@ int coevo_dqn_out_synth_step(int32_t *game_state, double *acc, int n_games, cons
                              int n_actions, uint64_t seed, const float *slab, const coevo_dqn_task *tasks_prev,
                              int n_tasks_prev, int n_rows_total, const void *workspace, int32_t *status, void *stream);
 
+/* The DeepQN games with the env on the HOST (PCIe-inclusive form of cfg 4 / cfg 5): what play_atari drives through env.observe
+ * / env.step / env.last (utils/game_logic_functions.py:84-120) when the env lives in host memory (:47-53), for all of a rank's
+ * games.  Per agent-step and cohort the context's host cores book the previous action and render every live game's next frame
+ * (the synthetic env of coevo_synth_step, same bytes) into page-locked memory; the cohort's stream copies the frames up, runs
+ * coevo_dqn_forward_argmax and copies the actions down; cohorts alternate.  Returns when step T has been booked. */
+typedef struct {
+    const coevo_dqn_task *tasks[2];   /* DEVICE: task table per parity (who acts); rows = this cohort's games */
+    const int32_t *rows[2];           /* HOST [n_games]: row of game (game_first + i) in the parity's frame / action arrays */
+    uint8_t *frames_host;             /* HOST, page-locked: [n_games][84 * 84 * C] */
+    uint8_t *frames_dev;              /* DEVICE twin */
+    int32_t *actions_host;            /* HOST, page-locked: [n_games] */
+    int32_t *actions_dev;             /* DEVICE twin */
+    void *workspace;                  /* DEVICE: coevo_dqn_workspace_bytes(n_games) */
+    int32_t n_tasks[2], max_rows[2];
+    int32_t game_first, n_games;      /* this cohort's games: [game_first, game_first + n_games) of the arrays below */
+} coevo_frame_cohort;
+typedef struct {
+    const float *slab;                /* DEVICE */
+    int32_t *status;                  /* DEVICE */
+    int32_t *game_state;              /* HOST [n_games][4], as coevo_synth_step keeps it */
+    double *acc;                      /* HOST [n_games][3]: play_game's (first_0, second_0) returns + one unused slot */
+    const int64_t *game_ordinal0;     /* HOST [n_games] */
+    const int32_t *limit;             /* HOST [n_games] agent-step limits */
+    const coevo_frame_cohort *cohorts;
+    double *phase_us;                 /* NULL, or HOST [5]: mean microseconds per cohort-step of {host wait for the actions, host
+                                         env (book + render), frames host->device, conv stack + fc1 + output layer, actions
+                                         device->host} */
+    int64_t generation, ordinals_per_gen;   /* ordinal(g) = game_ordinal0[g] + generation * ordinals_per_gen; < 0: disabled */
+    uint64_t seed;
+    int32_t n_games, n_cohorts, C, n_actions, T, reserved;
+} coevo_frames_rollout_desc;
+int coevo_dqn_host_frames_rollout(void *ctx, const coevo_frames_rollout_desc *desc, void *stream);
+/* the frame of agent-step t of game `ordinal` after `last_action` (0xFF: none yet), on the calling thread */
+int coevo_synth_frame_host(uint8_t *dst, int C, uint64_t seed, int64_t ordinal, int t, int last_action);
+
 #ifdef __cplusplus
 }
 #endif

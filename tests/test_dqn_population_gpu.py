@@ -236,3 +236,38 @@ def test_dqn_two_ranks_equal_one_rank(algo):
             lo, hi = got["shard"]
             for g, games in enumerate(got["games"]):
                 assert games == res.game_rewards[g].tolist()[2 * lo:2 * hi]
+
+
+# ------------------------------------------------------------------------------------------------ env in host memory
+@pytest.mark.parametrize("cohorts,threads", [(1, 1), (2, 3), (3, 16)])
+def test_dqn_ga_host_frames_equal_device_frames(monkeypatch, cohorts, threads):
+    """coevo_dqn_host_frames_rollout (the env in host memory: frames rendered by the host cores, copied up every agent-step,
+    actions copied down - utils/game_logic_functions.py:47-53,84-120) against the device-resident rollout: every game's
+    reward pair, fitness, elite ids, evaluation means and the final HoF weights of three generations are identical, for any
+    number of alternating cohorts and host threads; and a rendered frame is the device twin's, byte for byte"""
+    from coevonet_amd import lib as L
+    from coevonet_amd.atari_synthetic import synth_frame
+    buf = np.zeros(84 * 84 * 4, np.uint8)
+    assert L.load().coevo_synth_frame_host(buf.ctypes.data, 4, 1870300, (1 << 33) + 5, 7, 3) == 0
+    assert np.array_equal(buf, synth_frame(1870300, (1 << 33) + 5, 7, 3, 4).reshape(-1))
+    want = _summary_ga(_run_ga(_ga_cfg())[2])
+    monkeypatch.setenv("COEVO_FRAME_COHORTS", str(cohorts))
+    monkeypatch.setenv("COEVO_FRAME_THREADS", str(threads))
+    args, env, res = _run_ga(_ga_cfg(coevo_frames="host"))
+    ro = res.engine.ro
+    assert type(ro).__name__ == "HostFrameRollout" and len(ro.lanes) == cohorts and ro.threads == threads
+    assert _summary_ga(res) == want
+
+
+def test_dqn_es_host_frames_equal_device_frames(monkeypatch):
+    """the same for Co-ES (main rollout in two cohorts, the ten evaluation games through the host env as well)"""
+    _, _, base_d, res_d = _run_es(_es_cfg())
+    monkeypatch.setenv("COEVO_FRAME_THREADS", "4")
+    monkeypatch.setenv("COEVO_FRAME_COHORTS", "2")
+    _, _, base_h, res_h = _run_es(_es_cfg(coevo_frames="host"))
+    assert type(res_h.engine.ro).__name__ == "HostFrameRollout" and type(res_h.engine.eval_ro).__name__ == "HostFrameRollout"
+    assert [g.tolist() for g in res_h.game_rewards] == [g.tolist() for g in res_d.game_rewards]
+    assert [res_h.rewards[r] for r in rp.DQN_ROLES] == [res_d.rewards[r] for r in rp.DQN_ROLES]
+    assert res_h.sigma_after == res_d.sigma_after
+    for ri in range(2):
+        assert sha(base_h[ri]) == sha(base_d[ri])

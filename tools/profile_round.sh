@@ -6,7 +6,7 @@
 # Separate passes: kernel trace + stats per workload; FETCH_SIZE and WRITE_SIZE (one counter per pass, never combined
 # with a trace domain other than --kernel-trace) for the headline.
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 PART=${2:-all}   # all | stats | pmc (a gpurun call is limited to 20 minutes: the two halves fit one call each)
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$TAG
@@ -31,6 +31,8 @@ run cfg5_dqn_es --workload dqn-es --steps 2 --warmup 1
 run cfg4_dqn_ga_c6 --workload dqn-ga --channels 6 --steps 2 --warmup 1
 run cfg5_dqn_es_c6 --workload dqn-es --channels 6 --steps 2 --warmup 1
 run cfg2_host_env --env host --steps 20 --warmup 3
+run cfg2_shard_1_of_4 --shard-of 4 --steps 20 --warmup 3
+run cfg4_host_frames --workload dqn-ga --frames host --steps 1 --warmup 1
 fi
 pmc() {  # workload name, bench args...: one pass per counter (never combined with a trace domain other than --kernel-trace)
     local name=$1; shift
