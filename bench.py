@@ -683,7 +683,7 @@ def run_ga(a, ctx, dev):
             per_launch = (len(eng.plan.heavy_np) + len(eng.plan.light_np)) / Kc
             lean = merged and eng.plan.heavy_max <= 16 and per_launch * Kc <= 4 * cus
             if lean:
-                kernel_id = f"fc_cycle16_kernel<{R}>"
+                kernel_id = f"fc_cycle16_kernel<{R}, 2>"   # <rows per streaming task, MODE_FUSED>
             elif merged:
                 kernel_id = f"fc_cycle_kernel<{R}, {2 if per_launch * Kc > 2 * cus else 1}>"
             else:
