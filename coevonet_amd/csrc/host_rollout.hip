@@ -366,6 +366,8 @@ void drive_part(void *arg, int part, int parts)
         for (int k = part; k < K; k += parts) {
             const coevo_host_cohort &c = d->cohorts[k];
             if (c.n_rows == 0) continue;
+            if (cyc == 0 && d->reset_ordinals)   // play_game's env.reset() of this cohort's games
+                (void)coevo_mpe_host_reset_games(d->state, d->n_games, d->reset_rng, d->reset_ordinals, c.games, 0, c.n_games);
             const double t0 = J.timed ? now_us() : 0.0;
             double t1 = t0;
             if (cyc > 0) {
@@ -443,6 +445,9 @@ extern "C" int coevo_mpe_host_rollout(void *handle, const coevo_host_rollout_des
             games += c.n_games;
         }
         if (games != d->n_games) return COEVO_ERR_ARG;
+        if (d->reset_ordinals)
+            for (int g = 0; g < d->n_games; ++g)
+                if (d->reset_ordinals[g] < 0) return COEVO_ERR_ARG;
     }
     DriveJob J;
     J.h = h;

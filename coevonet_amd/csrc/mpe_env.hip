@@ -287,12 +287,75 @@ extern "C" int coevo_mpe_step(double *state, int n_games, const int32_t *game_ro
 
 // The same two functions on the host cores (env_mode "host": the env is stepped by the rank's own host process, the
 // observations go up and the actions come back over PCIe every cycle).  Plain host pointers; the bodies are the kernels'.
+// Host side: the games of a list take their resets; a game whose ordinal follows its predecessor's continues the stream
+// where that one stopped (two resets consume 21 raw outputs: the shared choice word, then ten doubles each) instead of
+// jumping ahead from the seed again - the same stream positions, so the same bits as mpe_reset_game.
+namespace coevo {
+static void mpe_reset_list_host(double *st, int n, coevo_pcg64 rng, const int64_t *ordinals, const int32_t *games, int lo, int hi)
+{
+    const u128 inc = ((u128)rng.pcg_inc_hi << 64) | rng.pcg_inc_lo;
+    const u128 s0 = ((u128)rng.pcg_state_hi << 64) | rng.pcg_state_lo;
+    const size_t N = (size_t)n;
+    u128 s = 0;
+    uint64_t c = 0, prev = 0;
+    bool have = false;
+    for (int i = lo; i < hi; ++i) {
+        const int g = games ? games[i] : i;
+        const uint64_t ordinal = (uint64_t)ordinals[g];
+        if (have && ordinal == prev + 1) {
+            if (!(ordinal & 1)) {   // a new pair: its choice word is the next output
+                s = s * pcg_mult() + inc;
+                c = pcg_output(s);
+            }                       // (odd: the pair's word is `c`, the stream stands behind the even game's ten doubles)
+        } else {
+            s = pcg_advance(s0, inc, (ordinal >> 1) * 21);
+            s = s * pcg_mult() + inc;
+            c = pcg_output(s);
+            if (ordinal & 1) s = pcg_advance(s, inc, 10);
+        }
+        const uint32_t half = (ordinal & 1) ? (uint32_t)(c >> 32) : (uint32_t)c;
+        const int goal = (int)(((uint64_t)half * 2) >> 32);
+        double d[10];
+        for (int k = 0; k < 10; ++k) {
+            s = s * pcg_mult() + inc;
+            d[k] = -1.0 + 2.0 * ((double)(pcg_output(s) >> 11) * (1.0 / 9007199254740992.0));
+        }
+        for (int k = 0; k < 6; ++k) {
+            st[k * N + g] = d[k];
+            st[(6 + k) * N + g] = 0.0;
+        }
+        for (int k = 0; k < 4; ++k) st[(12 + k) * N + g] = d[6 + k];
+        st[16 * N + g] = d[6 + 2 * goal];
+        st[17 * N + g] = d[7 + 2 * goal];
+        st[18 * N + g] = 0.0;
+        st[19 * N + g] = 0.0;
+        st[20 * N + g] = 0.0;
+        st[21 * N + g] = 0.0;
+        st[22 * N + g] = (double)goal;
+        st[23 * N + g] = 0.0;
+        prev = ordinal;
+        have = true;
+    }
+}
+}  // namespace coevo
+
 extern "C" int coevo_mpe_host_reset(double *state, int n_games, coevo_pcg64 rng, const int64_t *ordinals)
 {
     if (!state || !ordinals || n_games <= 0) return COEVO_ERR_ARG;
     for (int g = 0; g < n_games; ++g)
         if (ordinals[g] < 0) return COEVO_ERR_ARG;
-    for (int g = 0; g < n_games; ++g) coevo::mpe_reset_game(state, n_games, g, rng, (uint64_t)ordinals[g]);
+    coevo::mpe_reset_list_host(state, n_games, rng, ordinals, nullptr, 0, n_games);
+    return COEVO_OK;
+}
+
+// ... of games[lo..hi) only (what a host core does for one of its cohorts at the start of coevo_mpe_host_rollout)
+extern "C" int coevo_mpe_host_reset_games(double *state, int n_games, coevo_pcg64 rng, const int64_t *ordinals,
+                                          const int32_t *games, int lo, int hi)
+{
+    if (!state || !ordinals || !games || n_games <= 0 || lo < 0 || hi < lo) return COEVO_ERR_ARG;
+    for (int i = lo; i < hi; ++i)
+        if (games[i] < 0 || games[i] >= n_games || ordinals[games[i]] < 0) return COEVO_ERR_ARG;
+    coevo::mpe_reset_list_host(state, n_games, rng, ordinals, games, lo, hi);
     return COEVO_OK;
 }
 

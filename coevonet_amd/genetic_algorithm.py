@@ -218,6 +218,8 @@ class GAEngine:
         """flat_np [n][P] (parameters() order) -> nets first.. of a region"""
         flat = torch.from_numpy(np.ascontiguousarray(flat_np, dtype=np.float32)).to(self.device)
         L.call("coevo_fc_pack", L._p(flat), self._ptr(role, region, first), flat.shape[0], ROLE_D[role])
+        if region in ("pop", "stale"):
+            self._dist_current = False   # (the stale-agent distances breed_device() left behind no longer describe the slab)
         return flat  # keep alive until the stream has consumed it
 
     def download(self, role, region, first, n):
@@ -298,14 +300,30 @@ class GAEngine:
 
     def select(self):
         """fitness sharing + fitness + ranking of all three roles on the device -> elite ids stay on the device"""
-        dev_rewards = self.ro.rewards if torch.is_tensor(self.ro.rewards) else \
-            torch.from_numpy(self.ro.rewards).to(self.device)
+        if torch.is_tensor(self.ro.rewards):
+            dev_rewards = self.ro.rewards
+        else:   # env on the host cores: the play_game triples come up once per generation (72 KB at cfg 2)
+            if getattr(self, "_rewards_dev", None) is None:
+                self._rewards_pin = torch.zeros(self.plan.n_games, 3, dtype=torch.float64).pin_memory()
+                self._rewards_dev = torch.zeros(self.plan.n_games, 3, dtype=torch.float64, device=self.device)
+            self._rewards_pin.numpy()[:] = self.ro.rewards
+            self._rewards_dev.copy_(self._rewards_pin, non_blocking=True)
+            dev_rewards = self._rewards_dev
         per_phase = self.n_local * self.hof
+        if self._fused_host_tail():
+            self._ensure_breed_buffers()
+            if not getattr(self, "_dist_current", False):   # (generation 0, or a population loaded from the host)
+                for r in ROLES:
+                    L.call("coevo_fc_distance", self._ptr(r, "stale"), self._ptr(r, "pop"), self.pop, ROLE_D[r],
+                           L._p(self.dist[r]))
+            self._select_roles(lambda ri: L._p(dev_rewards), lambda ri: ri * per_phase, self.hof)
+            return
         for ph, r in enumerate(ROLES):
             D = ROLE_D[r]
             # distances of the local shard to the stale agent (Q3), scores need every rank's distances
-            L.call("coevo_fc_distance", self._ptr(r, "stale"), self._ptr(r, "pop", self.lo), self.n_local, D,
-                   self.dist[r].data_ptr() + 4 * self.lo)
+            if not getattr(self, "_dist_current", False):
+                L.call("coevo_fc_distance", self._ptr(r, "stale"), self._ptr(r, "pop", self.lo), self.n_local, D,
+                       self.dist[r].data_ptr() + 4 * self.lo)
             # last HoF game of every local individual (Q2)
             idx = ph * per_phase + torch.arange(self.n_local, device=self.device) * self.hof + self.hof - 1
             self.last_reward[ph, self.lo:self.hi] = dev_rewards[idx]
@@ -325,6 +343,22 @@ class GAEngine:
         counter-based noise (coevo_fc_rebuild_elites) and materialises only the children of its own shard - breeding
         cost per GPU does not grow with the number of GPUs and no weight crosses xGMI."""
         sharded = self.world > 1
+        if self._fused_host_tail():
+            # (select() ran coevo_ga_select: best_dist holds the distance of each role's best individual)
+            for r in ROLES:
+                self.sigma[r].fill_(float(sigmas[r]))
+                self.sigma_prev[r].fill_(float(sigmas[r]))
+            self._promote_roles(elites_from_pop=True, best_to_pop0=True)
+            for ri, r in enumerate(ROLES):
+                # the children's stale-agent distances (Q3) are accumulated while they are written; individual 0 is the
+                # unchanged best, whose distance is the one it had
+                L.call("coevo_fc_perturb_dist", self._ptr(r, "elite"), L._p(self.parent_idx), self._ptr(r, "pop"), 1,
+                       self.pop - 1, ROLE_D[r], L._p(self.sigma[r]), self.philox_seed, 0, gen * 4 + ri, 0, None,
+                       self._ptr(r, "stale"), L._p(self.dist_partial[r]))
+                L.call("coevo_fc_distance_finalize", L._p(self.dist_partial[r]), self.pblocks[r], self.pop - 1,
+                       L._p(self.dist[r]), 1, L._p(self.best_dist[r]))
+            self._dist_current = True
+            return
         for ri, r in enumerate(ROLES):
             D = ROLE_D[r]
             if sharded and gen > 0:
@@ -357,6 +391,7 @@ class GAEngine:
         """mutate_elites as the reference runs it (genetic_algorithm.py:32-48): per role, per child a fresh net is
         constructed (burning the torch generator) and torch.normal noise is added to every parameter."""
         keep = []
+        self._dist_current = False
         for r in ROLES:
             D = ROLE_D[r]
             L.call("coevo_fc_gather", self._ptr(r, "pop"), L._p(self.order[r]), self._ptr(r, "elite"), 0, self.E, D)
@@ -394,16 +429,29 @@ class GAEngine:
         self._gen_graph = None
         # distances to the stale agent: computed once for the initial population, then accumulated by the perturb
         # kernel while it writes each new child (no second pass over the 336 MB population)
-        self.pblocks = {r: int(L.load().coevo_fc_perturb_blocks(ROLE_D[r])) for r in ROLES}
-        self.dist_partial = {r: torch.zeros(max(self.pop - 1, 1) * self.pblocks[r], dtype=torch.float64, device=dev)
-                             for r in ROLES}
-        self.best_dist = {r: torch.zeros(1, dtype=torch.float32, device=dev) for r in ROLES}
+        self._ensure_breed_buffers()
         for r in ROLES:
             L.call("coevo_fc_distance", self._ptr(r, "stale"), self._ptr(r, "pop"), self.pop, ROLE_D[r],
                    L._p(self.dist[r]))
         # argument blocks of the fused selection / promotion launches (one launch for the three roles)
         self.fused_tail = self.E <= 8 and self.hof <= 16 and self.pop <= 4096
         self.pipelined = os.environ.get("COEVO_PIPELINED", "1") != "0"   # breed / reset / roll out cohort by cohort
+
+    def _ensure_breed_buffers(self):
+        """partial sums of the children's stale-agent distances (fused into the perturb kernel) + the best's own distance"""
+        if getattr(self, "pblocks", None) is None:
+            dev = self.device
+            self.pblocks = {r: int(L.load().coevo_fc_perturb_blocks(ROLE_D[r])) for r in ROLES}
+            self.dist_partial = {r: torch.zeros(max(self.pop - 1, 1) * self.pblocks[r], dtype=torch.float64, device=dev)
+                                 for r in ROLES}
+            self.best_dist = {r: torch.zeros(1, dtype=torch.float32, device=dev) for r in ROLES}
+
+    def _fused_host_tail(self):
+        """the host-driven loop on one GPU with device-built offspring takes the device-resident loop's fused launches:
+        selection of the three roles in one (coevo_ga_select), promotion in one (coevo_ga_promote), children with their
+        distances fused in - 8 launches instead of ~40 per generation"""
+        return (self.world == 1 and self.rng_mode == "device_philox" and self.pop > 1 and self.E <= 8 and self.hof <= 16
+                and self.pop <= 4096)
 
     def _select_roles(self, rewards_ptr_of, game_first_of, games_per_individual):
         roles = (L.GaSelectRole * 3)()

@@ -81,7 +81,8 @@ class HostRolloutDesc(C.Structure):   # coevo_host_rollout_desc
                 ("obs_host", C.c_void_p), ("obs_dev", C.c_void_p), ("actions_host", C.c_void_p),
                 ("actions_dev", C.c_void_p), ("status", C.c_void_p), ("cohorts", C.c_void_p), ("phase_us", C.c_void_p),
                 ("n_games", C.c_int32), ("n_rows", C.c_int32), ("n_cycles", C.c_int32), ("n_cohorts", C.c_int32),
-                ("pos_first", C.c_int32), ("zero_copy", C.c_int32)]
+                ("pos_first", C.c_int32), ("zero_copy", C.c_int32), ("reset_ordinals", C.c_void_p),
+                ("reset_rng", PCG64State)]
 
 
 class FrameCohort(C.Structure):       # coevo_frame_cohort
@@ -135,6 +136,7 @@ _SIGS = {
     "coevo_mpe_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                  C.c_void_p]),
     "coevo_mpe_host_reset": (C.c_int, [C.c_void_p, C.c_int, PCG64State, C.c_void_p]),
+    "coevo_mpe_host_reset_games": (C.c_int, [C.c_void_p, C.c_int, PCG64State, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "coevo_mpe_host_observe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "coevo_mpe_host_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "coevo_mpe_host_step_games": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,

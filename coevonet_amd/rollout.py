@@ -406,6 +406,8 @@ class HostEnvRollout:
         self.rewards = None
         self._merged = None
         self.ctx = None
+        self.state = None
+        self._pending_ordinals = None   # set by reset_from_ordinals: the next run() draws these resets first
         self.phase_us = None          # set to a float64[6] array to collect the per-cohort-cycle breakdown
         self.zero_copy = os.environ.get("COEVO_HOST_ZERO_COPY", "1") == "1"
         if self.impl == "native":
@@ -456,10 +458,12 @@ class HostEnvRollout:
         """ordinals[g] = reset ordinal of game g; draws every reset up to the largest one on the host."""
         ordinals = np.ascontiguousarray(ordinals, dtype=np.int64)
         n = self.plan.n_games
-        if self.impl == "native":   # the device state layout (csrc/mpe_env.hip) in host memory; reset = the reset kernel's body
-            self.state = np.zeros((L.MPE_STATE_DOUBLES, n), dtype=np.float64)   # (PCG64 jump-ahead to each game's ordinal)
-            L._check(L.load().coevo_mpe_host_reset(self.state.ctypes.data, n, L.PCG64State.from_seed(self.env_seed),
-                                                   ordinals.ctypes.data), "coevo_mpe_host_reset")
+        if self.impl == "native":   # the device state layout (csrc/mpe_env.hip) in host memory; the resets themselves are drawn
+            if getattr(self, "state", None) is None or self.state.shape[1] != n:   # inside the rollout, cohort by cohort, by
+                self.state = np.zeros((L.MPE_STATE_DOUBLES, n), dtype=np.float64)   # the core that drives the cohort
+            if ordinals.shape != (n,) or (n and ordinals.min() < 0):
+                raise ValueError("one non-negative reset ordinal per game")
+            self._pending_ordinals = ordinals
             return
         stream = sa.ResetStream(self.env_seed, skip_initial=False)
         goal, apos, lpos = stream.take(int(ordinals.max()) + 1)
@@ -519,8 +523,11 @@ class HostEnvRollout:
                 actions_host=self.actions_host.data_ptr(), actions_dev=L._p(self.actions), status=L._p(self.status),
                 cohorts=C_cast(self._cohorts), phase_us=(self.phase_us.ctypes.data if self.phase_us is not None else None),
                 n_games=p.n_games, n_rows=p.n_rows, n_cycles=int(n_cycles), n_cohorts=p.n_cohorts,
-                pos_first=1 if sa.INTEGRATE_POS_FIRST else 0, zero_copy=1 if self.zero_copy else 0)
+                pos_first=1 if sa.INTEGRATE_POS_FIRST else 0, zero_copy=1 if self.zero_copy else 0,
+                reset_ordinals=(self._pending_ordinals.ctypes.data if self._pending_ordinals is not None else None),
+                reset_rng=L.PCG64State.from_seed(self.env_seed))
             L._check(L.load().coevo_mpe_host_rollout(self.ctx, L.C.byref(d), L._stream()), "coevo_mpe_host_rollout")
+            self._pending_ordinals = None
             # play_game's triple (agent_0, agent_1, adversary_0): state rows 20, 21, 19
             self.rewards = np.ascontiguousarray(self.state[[20, 21, 19]].T)
             return

@@ -133,6 +133,8 @@ int coevo_mpe_step(double *state, int n_games, const int32_t *game_rows, const i
  * (utils/game_logic_functions.py:138,179-190), for all of a rank's games at once.  n_rows = length of `actions`. */
 int coevo_mpe_host_reset(double *state, int n_games, coevo_pcg64 rng, const int64_t *ordinals /* [n_games] reset ordinal of
                          every game: play_game's env.reset(), utils/game_logic_functions.py:217, quirk Q6 */);
+int coevo_mpe_host_reset_games(double *state, int n_games, coevo_pcg64 rng, const int64_t *ordinals /* [n_games] */,
+                               const int32_t *games, int lo, int hi /* only games[lo..hi) are reset */);
 int coevo_mpe_host_observe(const double *state, int n_games, const int32_t *row_game, const int32_t *row_slot,
                            int n_rows, float *obs);
 int coevo_mpe_host_step(double *state, int n_games, const int32_t *game_rows, const int32_t *actions, int n_rows,
@@ -174,6 +176,11 @@ typedef struct {
     int32_t n_games, n_rows, n_cycles, n_cohorts, pos_first;
     int32_t zero_copy;            /* != 0: the launch reads obs_host / writes actions_host directly (page-locked, mapped
                                      memory: same PCIe bytes, no copy engine in the chain) */
+    const int64_t *reset_ordinals;   /* NULL: `state` holds the games' reset states already; else HOST [n_games]: every game is
+                                        reset to this ordinal of the seeded stream first (play_game's env.reset(),
+                                        utils/game_logic_functions.py:217) - by the core that drives its cohort, inside the
+                                        rollout, so that only the first cohort's resets precede the first launch */
+    coevo_pcg64 reset_rng;           /* the stream's seed state (used with reset_ordinals) */
 } coevo_host_rollout_desc;
 void *coevo_host_rollout_create(int n_threads, int n_cohorts);   /* worker threads + one stream per cohort */
 void coevo_host_rollout_destroy(void *ctx);

@@ -476,3 +476,36 @@ def test_host_cores_pool_equals_one_thread(threads):
                                            limits.ctypes.data, pos_first, bad.ctypes.data, len(bad), 0, None) == -1
     finally:
         lib.coevo_host_rollout_destroy(ctx)
+
+
+def test_host_reset_continuation_equals_jump_ahead():
+    """coevo_mpe_host_reset / coevo_mpe_host_reset_games continue the seeded stream from game to game when ordinals are
+    consecutive (two resets = 21 raw outputs) and jump ahead otherwise: runs of consecutive ordinals starting at odd and even
+    positions, isolated ones, repeats and a shuffled game list all give the state of the per-game jump-ahead, which
+    test_native_host_env_equals_numpy_env pins to numpy's Generator (utils/game_logic_functions.py:54,217; quirk Q6)"""
+    from coevonet_amd import lib as L
+    from coevonet_amd.mpe import simple_adversary as sa
+    lib = L.load()
+    rng = np.random.default_rng(5)
+    ords = np.concatenate([np.arange(7, 60), np.arange(1000, 1041), [5, 5, 6, 99, 98, 3], np.arange(2 ** 33 + 1, 2 ** 33 + 30),
+                           rng.integers(0, 10 ** 6, size=50)]).astype(np.int64)
+    n = len(ords)
+    goal, apos, lpos = None, None, None
+    want = np.zeros((L.MPE_STATE_DOUBLES, n))
+    one = np.zeros((L.MPE_STATE_DOUBLES, 1))
+    seed = L.PCG64State.from_seed(sa.ENV_SEED)
+    for g in range(n):   # every game alone: no predecessor, so the jump-ahead path
+        o = np.array([ords[g]], dtype=np.int64)
+        assert lib.coevo_mpe_host_reset(one.ctypes.data, 1, seed, o.ctypes.data) == 0
+        want[:, g] = one[:, 0]
+    got = np.full((L.MPE_STATE_DOUBLES, n), 9.0)
+    assert lib.coevo_mpe_host_reset(got.ctypes.data, n, seed, ords.ctypes.data) == 0
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    games = rng.permutation(n).astype(np.int32)
+    got2 = np.full((L.MPE_STATE_DOUBLES, n), 9.0)
+    assert lib.coevo_mpe_host_reset_games(got2.ctypes.data, n, seed, ords.ctypes.data, games.ctypes.data, 0, n // 2) == 0
+    assert lib.coevo_mpe_host_reset_games(got2.ctypes.data, n, seed, ords.ctypes.data, games.ctypes.data, n // 2, n) == 0
+    assert np.array_equal(got2.view(np.uint64), want.view(np.uint64))
+    bad = ords.copy()
+    bad[3] = -1
+    assert lib.coevo_mpe_host_reset_games(got2.ctypes.data, n, seed, bad.ctypes.data, games.ctypes.data, 0, n) == -1
