@@ -524,16 +524,17 @@ def extras(a, ctx, dev):
     # (two timed generations under-reported cfg5 by 15 %: the first ones carry one-off host work)
     leg("cfg4_shard", lambda: run_dqn(b, ctx, dev, "ga"))
     leg("cfg5_shard", lambda: run_dqn(b, ctx, dev, "es"))
-    # PCIe-inclusive: the (synthetic) env in host memory, frames up / actions down every agent-step
-    hf = copy.copy(b)
-    hf.frames, hf.steps, hf.warmup = "host", 2, 1
-    leg("cfg4_shard_host_frames", lambda: run_dqn(hf, ctx, dev, "ga"))
     # six frame planes: what the reference's wrapper stack yields (frame_stack_v1(4) + agent_indicator_v0,
     # utils/game_logic_functions.py:50-53; Atari/atari_agent.py:20); BASELINE.json words the configs as 84x84x4
     c6 = copy.copy(b)
     c6.channels = 6
     leg("cfg4_shard_6_planes", lambda: run_dqn(c6, ctx, dev, "ga"))
     leg("cfg5_shard_6_planes", lambda: run_dqn(c6, ctx, dev, "es"))
+    # PCIe-inclusive: the (synthetic) env in host memory, frames up / actions down every agent-step (last: the legs that
+    # follow a host-stepped rollout in the same process read a few per cent low, profiles/r04_experiments.md section 1)
+    hf = copy.copy(b)
+    hf.frames, hf.steps, hf.warmup = "host", 2, 1
+    leg("cfg4_shard_host_frames", lambda: run_dqn(hf, ctx, dev, "ga"))
     ex["legend"] = ("cfg2_T200: env max_cycles 67; cfg2_host_env: env on the host cores (PCIe-inclusive); cfg2_shard_1_of_N: "
                     "rank 0 of pop 200 over N GPUs rehearsed on this GPU, no collective; cfg3: Co-ES pop 1000 (extension = "
                     "antithetic + centered ranks, not in the reference); cfg4 / cfg5: per-GPU shards (pop 50, HoF 10 / pop 250) "
