@@ -509,3 +509,22 @@ def test_host_reset_continuation_equals_jump_ahead():
     bad = ords.copy()
     bad[3] = -1
     assert lib.coevo_mpe_host_reset_games(got2.ctypes.data, n, seed, bad.ctypes.data, games.ctypes.data, 0, n) == -1
+
+
+def test_bench_scaling_arguments():
+    """bench.py's reading of BASELINE.json's metric ("pop=200 ... 1/2/4/8 GPU"): `--gpus N` shards ONE population, so a rank
+    count that does not divide it is refused before anything touches a GPU; the compact() helper keeps the line short"""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "3"], capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "not divisible" in (p.stderr + p.stdout)
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "7", "--workload", "es"], capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode != 0 and "not divisible" in (p.stderr + p.stdout)
+    sys.path.insert(0, repo)
+    import bench
+    assert bench.compact({"a": 1.23456789, "b": [2.0000001, {"c": 123456.789}], "d": "x", "e": 7}) == \
+        {"a": 1.235, "b": [2.0, {"c": 123500.0}], "d": "x", "e": 7}
+    hc = bench.host_cores()
+    assert 1 <= hc["usable"] <= hc["affinity"]
