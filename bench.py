@@ -300,7 +300,7 @@ def run_es(a, ctx, dev, pop_per_gpu=None, extension=None):
     args.coevo_antithetic = args.coevo_centered_rank = bool(ext)
     env = initialize_env(args)
     env.max_cycles = a.max_cycles
-    tr = ESTrainer(env, args, rng="device_philox", env_mode="device", collect=False, dist_ctx=ctx)
+    tr = ESTrainer(env, args, rng="device_philox", env_mode=a.env, collect=False, dist_ctx=ctx)
     eng = tr.eng
     dt = _timed_steps(tr.step, a, ctx, dev)
     gens = a.steps / dt
@@ -507,13 +507,13 @@ def extras(a, ctx, dev):
     # Its own process: after the device-resident loop has run in a process (lane streams + a replayed tail graph), every
     # operation on the host rollout's cohort streams takes ~9 us longer and the leg reads 240 instead of 370 generations/s
     # (profiles/r04_experiments.md); `python bench.py --env host` is how the mode is run anyway.
-    def host_leg():
+    def host_leg(*more):
         import subprocess
-        cmd = [sys.executable, os.path.abspath(__file__), "--env", "host", "--no-extra", "--no-cpu-baseline", "--steps", "20",
-               "--warmup", "3"]
+        cmd = [sys.executable, os.path.abspath(__file__), "--env", "host", "--no-extra", "--no-cpu-baseline"] + list(more)
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, check=True)
         return json.loads(p.stdout.decode().strip().splitlines()[-1])
-    leg("cfg2_host_env", host_leg)
+    leg("cfg2_host_env", lambda: host_leg("--steps", "20", "--warmup", "3"))
+    leg("cfg3_host_env", lambda: host_leg("--workload", "es", "--steps", "5", "--warmup", "2"))
     # the metric's own split (pop 200 over 2 / 4 / 8 GPUs): what ONE rank of it does on this GPU (dist.ShardRehearsal)
     for n in (2, 4, 8):
         sh = copy.copy(b)
@@ -535,7 +535,7 @@ def extras(a, ctx, dev):
     hf = copy.copy(b)
     hf.frames, hf.steps, hf.warmup = "host", 2, 1
     leg("cfg4_shard_host_frames", lambda: run_dqn(hf, ctx, dev, "ga"))
-    ex["legend"] = ("cfg2_T200: env max_cycles 67; cfg2_host_env: env on the host cores (PCIe-inclusive); cfg2_shard_1_of_N: "
+    ex["legend"] = ("cfg2_T200: env max_cycles 67; cfg2_host_env / cfg3_host_env: env on the host cores (PCIe-inclusive); cfg2_shard_1_of_N: "
                     "rank 0 of pop 200 over N GPUs rehearsed on this GPU, no collective; cfg3: Co-ES pop 1000 (extension = "
                     "antithetic + centered ranks, not in the reference); cfg4 / cfg5: per-GPU shards (pop 50, HoF 10 / pop 250) "
                     "over DeepQN on SYNTHETIC 84x84x4 frames (6_planes: 84x84x6; host_frames: the env in host memory, frames over PCIe "

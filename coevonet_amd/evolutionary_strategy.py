@@ -141,9 +141,17 @@ class ESEngine:
         eval_games = [(net("base", "adversary_0"), net("base", "agent_0"), net("base", "agent_1"))] * N_EVAL
         cls = DeviceRollout if env == "device" else HostEnvRollout
         heavy_rows = int(os.environ.get("COEVO_HEAVY_ROWS", "32"))
-        es_cohorts = int(os.environ.get("COEVO_ES_COHORTS", "2")) if env == "device" else 1  # 114 vs 109 generations/s at cfg3
+        # device env: 2 cohorts (114 vs 109 generations/s at cfg3); env on the host cores: COEVO_HOST_COHORTS alternating
+        # cohorts (default 4), rows numbered cohort by cohort (one contiguous observation / action range each)
+        es_cohorts = (int(os.environ.get("COEVO_ES_COHORTS", "2")) if env == "device"
+                      else int(os.environ.get("COEVO_HOST_COHORTS", "4")))
+        game_cohort = None
+        if env != "device" and es_cohorts > 1 and len(games) >= es_cohorts:
+            # contiguous game ranges (a core then owns whole cache lines of the struct-of-arrays game state)
+            game_cohort = (np.arange(len(games)) * es_cohorts // len(games)).astype(np.int32)
         self.plan = RolloutPlan(np.array(games), net_off, net_D, device=device, heavy_rows=heavy_rows,
-                                n_cohorts=es_cohorts)
+                                n_cohorts=es_cohorts, game_cohort=game_cohort,
+                                row_order="class" if env == "device" else "cohort")
         self.ro = cls(self.plan, self.slab, env_seed=env_seed)
         # the 10 evaluation games: three nets x 10 rows, as two 5-row streaming tasks per net (1.0 -> 0.5 ms)
         self.eval_plan = RolloutPlan(np.array(eval_games), net_off, net_D, device=device, split_rows=5)

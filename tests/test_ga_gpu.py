@@ -200,3 +200,21 @@ def test_host_cores_rollout_equals_device_rollout(monkeypatch, cohorts, threads,
         assert np.array_equal(np.asarray(res.fitness[g], np.float32).view(np.uint32),
                               np.asarray(want.fitness[g], np.float32).view(np.uint32))
         assert [res.rewards[r][g] for r in ga.ROLES] == [want.rewards[r][g] for r in ga.ROLES]
+
+
+def test_host_cores_rollout_tiny_and_ragged(monkeypatch):
+    """edge shapes of the host-cores rollout: more cohorts asked for than individuals (clamped), a one-agent-step limit (only the
+    adversary acts: no world step at all), an evaluation horizon longer than the training one, an odd population - all equal
+    to the device env, and the env's reset counter ends where the reference's would (utils/game_logic_functions.py:197,217)"""
+    cfg = {"seed": 3, "args": dict(generations=2, population=3, hof_size=1, elites_number=1, fitness_sharing=True,
+                                   max_timesteps_per_episode=1, max_evaluation_steps=7)}
+    _, env_d, want = _run(cfg, "device_philox", "device")
+    monkeypatch.setenv("COEVO_HOST_COHORTS", "8")
+    monkeypatch.setenv("COEVO_HOST_THREADS", "5")
+    _, env_h, res = _run(cfg, "device_philox", "host")
+    assert res.engine.ro.plan.n_cohorts <= 3 and res.engine.ro.threads <= res.engine.ro.plan.n_cohorts
+    assert env_h.n_resets == env_d.n_resets
+    for g in range(2):
+        assert res.elite_ids[g] == want.elite_ids[g]
+        assert np.array_equal(np.asarray(res.game_rewards[g]).view(np.uint64), np.asarray(want.game_rewards[g]).view(np.uint64))
+        assert [res.rewards[r][g] for r in ga.ROLES] == [want.rewards[r][g] for r in ga.ROLES]

@@ -528,3 +528,34 @@ def test_bench_scaling_arguments():
         {"a": 1.235, "b": [2.0, {"c": 123500.0}], "d": "x", "e": 7}
     hc = bench.host_cores()
     assert 1 <= hc["usable"] <= hc["affinity"]
+
+
+def test_host_rollout_entry_points_refuse_bad_descriptors():
+    """argument errors of the host-side rollouts are COEVO_ERR_ARG before any GPU call (the error convention of the boundary:
+    return codes, no exceptions, nothing dereferenced that was not checked)"""
+    import ctypes as C
+    from coevonet_amd import lib as L
+    lib = L.load()
+    assert not lib.coevo_host_rollout_create(0, 1) and not lib.coevo_host_rollout_create(1, 0)
+    assert not lib.coevo_host_rollout_create(1, 9) and not lib.coevo_host_rollout_create(1000, 1)
+    ctx = lib.coevo_host_rollout_create(2, 2)
+    assert ctx and lib.coevo_host_rollout_threads(ctx) == 2 and lib.coevo_host_rollout_threads(None) == -1
+    try:
+        d = L.HostRolloutDesc()                       # every pointer NULL
+        assert lib.coevo_mpe_host_rollout(ctx, C.byref(d), None) == -1
+        assert lib.coevo_mpe_host_rollout(None, C.byref(d), None) == -1
+        f = L.FramesRolloutDesc()
+        assert lib.coevo_dqn_host_frames_rollout(ctx, C.byref(f), None) == -1
+        buf = np.zeros(84 * 84 * 4, np.uint8)
+        assert lib.coevo_synth_frame_host(None, 4, 1, 0, 0, 0xFF) == -1
+        assert lib.coevo_synth_frame_host(buf.ctypes.data, 7, 1, 0, 0, 0xFF) == -1      # C > 6
+        assert lib.coevo_synth_frame_host(buf.ctypes.data, 4, 1, 0, 70000, 0xFF) == -1  # t beyond the 16-bit key field
+        st = np.zeros((L.MPE_STATE_DOUBLES, 4))
+        gr = np.arange(12, dtype=np.int32)
+        games = np.arange(4, dtype=np.int32)
+        assert lib.coevo_mpe_host_step_games(st.ctypes.data, 4, gr.ctypes.data, None, 0, None, 1, games.ctypes.data, 0, 4, 0,
+                                             None) == -1   # a cycle to step, but no actions
+        assert lib.coevo_mpe_host_step_games(st.ctypes.data, 4, gr.ctypes.data, None, -1, None, 1, games.ctypes.data, 0, 4, 1,
+                                             None) == -1   # observations asked for, no buffer
+    finally:
+        lib.coevo_host_rollout_destroy(ctx)
