@@ -32,6 +32,7 @@ run cfg4_dqn_ga_c6 --workload dqn-ga --channels 6 --steps 2 --warmup 1
 run cfg5_dqn_es_c6 --workload dqn-es --channels 6 --steps 2 --warmup 1
 run cfg2_host_env --env host --steps 20 --warmup 3
 run cfg2_shard_1_of_4 --shard-of 4 --steps 20 --warmup 3
+run cfg3_host_env --workload es --env host --steps 5 --warmup 2
 run cfg4_host_frames --workload dqn-ga --frames host --steps 1 --warmup 1
 fi
 pmc() {  # workload name, bench args...: one pass per counter (never combined with a trace domain other than --kernel-trace)
