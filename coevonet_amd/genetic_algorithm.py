@@ -98,6 +98,7 @@ def cohort_partition(n_local, K):
 
 DEFAULT_COHORTS = 1       # independent game cohorts per rollout (rollout.RolloutPlan._assign_cohorts); see DESIGN.md
 DEVICE_LOOP_COHORTS = 2   # ... in the host-free loop, where their launches are enqueued eagerly and do overlap
+SMALL_SHARD = 80          # ... unless a rank holds fewer individuals per role than this: then one chain
 
 
 class GAEngine:
@@ -827,6 +828,11 @@ class GATrainer:
         cohorts = getattr(args, "coevo_cohorts", None)
         if cohorts is None:
             cohorts = DEVICE_LOOP_COHORTS if (self.device_loop or self.sharded_loop) else DEFAULT_COHORTS
+            # a small shard (pop 200 over 4 / 8 GPUs: 50 / 25 individuals per role) is ONE launch per env-cycle: its few
+            # hundred workgroups are all resident anyway, and a second chain only adds launches (one rank of 4: 1312 vs 1120,
+            # of 8: 1392 vs 1167 generations/s; 100 individuals per role: 850 vs 890 - profiles/r04_experiments.md)
+            if args.population // max(shard[1], 1) < SMALL_SHARD:
+                cohorts = 1
         self.eng = GAEngine(args.population, args.hof_size, args.elites_number, args.max_timesteps_per_episode,
                             args.max_evaluation_steps, max_cycles=getattr(env, "max_cycles", 25), rng=self.rng,
                             philox_seed=getattr(args, "coevo_seed", 0), env=env_mode,
