@@ -238,3 +238,32 @@ def test_cfg5_full_size_generation_vs_oracle():
         for s in range(2):
             ev[s] += w["rewards"][s]
     assert [res.rewards[r][0] for r in ROLES] == [e / 10 for e in ev]
+
+
+def test_cfg4_full_size_host_frames_equal_device_frames(monkeypatch):
+    """the cfg 4 shard at full size (pop 50, HoF 10: 1010 games per agent-step, 90 tasks per parity) with the env in host memory
+    (three alternating cohorts, 28.5 MB of frames up per agent-step) against the device-resident rollout, horizon 6, two
+    generations: all 2 x 1000 reward pairs, fitness, elite ids and evaluation means identical"""
+    pop, hof, E, C, T, Te = 50, 10, 2, 4, 6, 4
+
+    def run(frames):
+        torch.manual_seed(21)
+        args = Bag(algorithm="GA", game="pong_v3", generations=2, population=pop, hof_size=hof, elites_number=E,
+                   fitness_sharing=True, max_timesteps_per_episode=T, max_evaluation_steps=Te, coevo_channels=C,
+                   coevo_graph=False, coevo_frames=frames)
+        env = initialize_env(args)
+        tr = DQNGATrainer(env, args, collect=True)
+        tr.step()
+        tr.step()
+        res = tr.finish()
+        out = ([np.asarray(g).tolist() for g in res.game_rewards], res.fitness, res.elite_ids, [res.rewards[r] for r in ROLES],
+               type(tr.eng.ro).__name__, len(tr.eng.ro.lanes))
+        tr.close()
+        return out
+
+    for var in ("COEVO_FRAME_COHORTS", "COEVO_FRAME_THREADS"):
+        monkeypatch.delenv(var, raising=False)
+    dev = run("device")
+    host = run("host")
+    assert dev[4] == "SynthRollout" and host[4] == "HostFrameRollout" and host[5] == 3
+    assert host[:4] == dev[:4]

@@ -316,3 +316,26 @@ def test_cfg3_full_size_generation_vs_oracle():
         for s in range(3):
             ev[s] += w["rewards"][s]
     assert [res.rewards[r][0] for r in ROLES] == [e / 10 for e in ev]
+
+
+def test_cfg2_full_size_host_cores_equal_device(monkeypatch):
+    """BASELINE configs[1] at full size with the env on the host cores (north_star's first architecture: 2 cores x 4 alternating
+    cohorts of ~752 games, mapped page-locked buffers, the lean merged kernel fed with observations) against the device-resident
+    loop: every one of the 2 x 3000 play_game triples, the fitness bits, elite ids and evaluation means of two generations are
+    identical - the full-size form of test_host_cores_rollout_equals_device_rollout (utils/game_logic_functions.py:123-212)"""
+    pop, hof, E = 200, 5, 2
+    cfg = {"seed": 0, "args": dict(generations=2, population=pop, hof_size=hof, elites_number=E, fitness_sharing=True,
+                                   max_timesteps_per_episode=200, max_evaluation_steps=200)}
+    _, _, want = _ga(cfg, "device_philox")
+    for var in ("COEVO_HOST_COHORTS", "COEVO_HOST_THREADS", "COEVO_HOST_ZERO_COPY", "COEVO_HOST_SIGNAL"):
+        monkeypatch.delenv(var, raising=False)
+    _, _, res = _ga(cfg, "device_philox", env_mode="host")
+    ro = res.engine.ro
+    assert ro.impl == "native" and ro.plan.n_cohorts == 4 and ro.threads == 2 and ro.zero_copy
+    assert [len(g) for g in ro._cohort_games] == [750, 750, 750, 760] and ro.plan.heavy_max <= 16
+    for g in range(2):
+        assert res.elite_ids[g] == want.elite_ids[g]
+        assert np.array_equal(np.asarray(res.game_rewards[g]).view(np.uint64), np.asarray(want.game_rewards[g]).view(np.uint64))
+        assert np.array_equal(np.asarray(res.fitness[g], np.float32).view(np.uint32),
+                              np.asarray(want.fitness[g], np.float32).view(np.uint32))
+        assert [res.rewards[r][g] for r in ROLES] == [want.rewards[r][g] for r in ROLES]
