@@ -179,10 +179,11 @@ def test_save_and_metrics_roundtrip(tmp_path):
     assert len(out) == 3 and all(np.isfinite(out))
 
 
-@pytest.mark.parametrize("cohorts,threads,zero_copy", [(1, 1, 0), (2, 4, 0), (3, 2, 0), (2, 3, 1), (4, 8, 1)])
-def test_host_cores_rollout_equals_device_rollout(monkeypatch, cohorts, threads, zero_copy):
+@pytest.mark.parametrize("cohorts,threads,zero_copy,signal", [(1, 1, 0, "flag"), (2, 4, 0, "event"), (3, 2, 0, "flag"),
+                                                             (2, 3, 1, "event"), (4, 8, 1, "flag")])
+def test_host_cores_rollout_equals_device_rollout(monkeypatch, cohorts, threads, zero_copy, signal):
     """coevo_mpe_host_rollout (env on the host cores: K alternating cohorts, T threads, staged copies or mapped page-locked
-    buffers) against the device env: every play_game triple, fitness bits, elite ids and evaluation means of three
+    buffers, completion words or events) against the device env: every play_game triple, fitness bits, elite ids and evaluation means of three
     generations are identical - the partition and the thread count change the schedule, never a number
     (utils/game_logic_functions.py:123-212)."""
     cfg = {"seed": 11, "args": dict(generations=3, population=13, hof_size=3, elites_number=2, fitness_sharing=True,
@@ -191,6 +192,7 @@ def test_host_cores_rollout_equals_device_rollout(monkeypatch, cohorts, threads,
     monkeypatch.setenv("COEVO_HOST_COHORTS", str(cohorts))
     monkeypatch.setenv("COEVO_HOST_THREADS", str(threads))
     monkeypatch.setenv("COEVO_HOST_ZERO_COPY", str(zero_copy))
+    monkeypatch.setenv("COEVO_HOST_SIGNAL", signal)   # completion through a stream-written host word / through an event
     _, _, res = _run(cfg, "device_philox", "host")
     ro = res.engine.ro
     assert ro.impl == "native" and ro.threads == min(threads, cohorts) and ro.plan.n_cohorts == cohorts and ro.zero_copy == bool(zero_copy)
