@@ -173,8 +173,9 @@ class GAEngine:
         # (env on the host cores: the cohorts alternate between the cores and the GPU - COEVO_HOST_COHORTS, default 4: the
         # chain launch -> actions -> host step -> next launch of ONE cohort is ~90 us of latency however many cores step it;
         # four chains in flight hide most of it, six or more share hardware queues and serialise - profiles/r04_experiments.md)
-        self.K = max(1, min(int(cohorts) if env == "device" else int(os.environ.get("COEVO_HOST_COHORTS", "4")),
-                            self.n_local))
+        # ... a small batch fewer: ~700 games per cohort (550 games: one cohort 792 generations/s, four 671: tools/host_soak.py)
+        host_k = int(os.environ.get("COEVO_HOST_COHORTS", "0")) or max(1, min(4, len(games) // 700))
+        self.K = max(1, min(int(cohorts) if env == "device" else host_k, self.n_local))
         row_order = "class" if env == "device" else "cohort"
         self._set_cohort_bounds()
         game_cohort = None
