@@ -142,6 +142,16 @@ struct HostRollout {
     volatile uint32_t *flags = nullptr;   // one per cohort, 64 bytes apart
     uint32_t seq[COEVO_MAX_COHORTS] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::atomic<bool> use_flags{false};
+    // ... and the other direction: a cohort's NEXT launch is queued while the core still steps the games, behind a stream
+    // wait on a word of the same page (hipStreamWaitValue32, >=), and released by a plain store when the observations stand
+    // - no runtime call between the last observation and the launch's start (release -> completion of an empty kernel 6 us,
+    // against 16 us for launching it then: tools/wait_value_probe.hip).  COEVO_HOST_PREQUEUE=0 for A/B.
+    volatile uint32_t *gates = nullptr;   // one per cohort, 64 bytes apart (second half of the page)
+    uint32_t gate_issued[COEVO_MAX_COHORTS] = {0, 0, 0, 0, 0, 0, 0, 0};     // target of the newest queued wait
+    uint32_t gate_released[COEVO_MAX_COHORTS] = {0, 0, 0, 0, 0, 0, 0, 0};   // value last stored
+    uint32_t wait_target[COEVO_MAX_COHORTS] = {0, 0, 0, 0, 0, 0, 0, 0};     // completion number of the launch that RUNS
+    uint32_t pending_seq[COEVO_MAX_COHORTS] = {0, 0, 0, 0, 0, 0, 0, 0};     // ... of the one queued behind its gate
+    std::atomic<bool> use_gates{false};
     explicit HostRollout(int threads) : pool(threads) {}
 };
 
@@ -198,10 +208,17 @@ static int ensure_lanes(HostRollout *h)
         const char *sig = getenv("COEVO_HOST_SIGNAL");   // "event": A/B runs (374 vs 364 generations/s with two cores)
         if (!(sig && sig[0] == 'e')) {
             void *p = nullptr;
-            if (hipHostMalloc(&p, 64 * COEVO_MAX_COHORTS, hipHostMallocDefault) == hipSuccess && p) {
-                memset(p, 0, 64 * COEVO_MAX_COHORTS);
+            if (hipHostMalloc(&p, 128 * COEVO_MAX_COHORTS, hipHostMallocDefault) == hipSuccess && p) {
+                memset(p, 0, 128 * COEVO_MAX_COHORTS);
                 h->flags = static_cast<volatile uint32_t *>(p);
+                h->gates = h->flags + 16 * COEVO_MAX_COHORTS;
                 h->use_flags.store(true);
+                int can_wait = 0;
+                int dev_now = 0;
+                const char *pq = getenv("COEVO_HOST_PREQUEUE");
+                if (!(pq && pq[0] == '0') && hipGetDevice(&dev_now) == hipSuccess &&
+                    hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, dev_now) == hipSuccess && can_wait)
+                    h->use_gates.store(true);
             } else {
                 (void)hipGetLastError();
             }
@@ -282,18 +299,29 @@ struct DriveJob {
     int device;
     bool lean, timed;
     std::atomic<int> rc{COEVO_OK};
+    bool gate_mode = false;                       // launches are queued ahead behind a stream wait, released by a store
     bool flag_mode = false;                       // this rollout signals through the host flags
     bool flag_fallback[COEVO_MAX_COHORTS] = {};   // ... except this cohort, whose last enqueue had to record an event
+    bool gate_off[COEVO_MAX_COHORTS] = {};        // ... or whose stream wait was refused: it launches late from then on
     double acc[COEVO_MAX_COHORTS][6];   // per cohort: wait, step, enqueue (host clock), h2d, launch, d2h (HIP events)
     int acc_n[COEVO_MAX_COHORTS];
 };
 
-int enqueue_cohort(DriveJob &J, int k)
+int enqueue_cohort(DriveJob &J, int k, bool gated = false)
 {
     const coevo_host_rollout_desc *d = J.d;
     const coevo_host_cohort &c = d->cohorts[k];
     HostLane &ln = J.h->lanes[k];
     const size_t r0 = (size_t)c.row_first;
+    if (gated) {   // everything below waits in the stream until release_cohort() stores this target
+        const uint32_t target = J.h->gate_issued[k] + 1;
+        if (hipStreamWaitValue32(ln.s, const_cast<uint32_t *>(J.h->gates + 16 * k), target, hipStreamWaitValueGte,
+                                 0xFFFFFFFFu) != hipSuccess) {
+            (void)hipGetLastError();
+            return COEVO_ERR_UNSUPPORTED;   // (nothing was queued: the caller falls back to launching late)
+        }
+        J.h->gate_issued[k] = target;
+    }
     if (J.timed) COEVO_HIP_CHECK(hipEventRecord(ln.t[0], ln.s));
     if (!d->zero_copy)
         COEVO_HIP_CHECK(hipMemcpyAsync(d->obs_dev + r0 * COEVO_OBS_STRIDE, d->obs_host + r0 * COEVO_OBS_STRIDE,
@@ -317,9 +345,15 @@ int enqueue_cohort(DriveJob &J, int k)
     if (J.timed) COEVO_HIP_CHECK(hipEventRecord(ln.t[3], ln.s));
     if (J.flag_mode && !J.flag_fallback[k]) {
         const uint32_t v = ++J.h->seq[k];
-        if (hipStreamWriteValue32(ln.s, const_cast<uint32_t *>(J.h->flags + 16 * k), v, 0) == hipSuccess) return COEVO_OK;
+        if (hipStreamWriteValue32(ln.s, const_cast<uint32_t *>(J.h->flags + 16 * k), v, 0) == hipSuccess) {
+            if (gated) J.h->pending_seq[k] = v;
+            else J.h->wait_target[k] = v;
+            return COEVO_OK;
+        }
         (void)hipGetLastError();
+        if (gated) return COEVO_ERR_HIP;   // (a launch waits at its gate without a completion word: give up, the caller opens the gates)
         J.flag_fallback[k] = true;   // refused here: this cohort signals through its event from now on (this enqueue included)
+        J.gate_off[k] = true;        // ... and launches late (an event re-recorded behind a gate would be waited for too early)
         J.h->use_flags.store(false);
     }
     COEVO_HIP_CHECK(hipEventRecord(ln.done, ln.s));
@@ -332,7 +366,7 @@ int wait_cohort(DriveJob &J, int k)
     HostRollout *h = J.h;
     if (h->flags && !J.flag_fallback[k] && J.flag_mode) {
         const volatile uint32_t *f = h->flags + 16 * k;
-        const uint32_t want = h->seq[k];
+        const uint32_t want = h->wait_target[k];
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spin = 0;; ++spin) {
             if (*f == want) {
@@ -344,6 +378,15 @@ int wait_cohort(DriveJob &J, int k)
         }
     }
     return wait_event(h->lanes[k].done);
+}
+
+// the observations of the cohort's queued launch stand: let it go (x86 stores keep their order; the word is the last one)
+inline void release_cohort(HostRollout *h, int k)
+{
+    std::atomic_thread_fence(std::memory_order_release);
+    h->gate_released[k] = h->gate_issued[k];
+    h->wait_target[k] = h->pending_seq[k];   // the launch that now runs is the one the next wait is for
+    h->gates[16 * k] = h->gate_released[k];
 }
 
 // One host core's share of a rollout: it DRIVES cohorts part, part + parts, ... from the first observation to the last
@@ -366,6 +409,15 @@ void drive_part(void *arg, int part, int parts)
         for (int k = part; k < K; k += parts) {
             const coevo_host_cohort &c = d->cohorts[k];
             if (c.n_rows == 0) continue;
+            bool queued = false;   // this cycle's launch already sits in the stream, behind its gate
+            if (J.gate_mode && !J.gate_off[k]) {
+                if (cyc == 0 && d->n_cycles > 0) {   // the first launch is queued before the resets are even drawn
+                    const int rc = enqueue_cohort(J, k, true);
+                    if (rc == COEVO_ERR_UNSUPPORTED) J.gate_off[k] = true;
+                    else if (rc) { J.rc.store(rc); return; }
+                }
+                queued = !J.gate_off[k] && cyc < d->n_cycles;
+            }
             if (cyc == 0 && d->reset_ordinals)   // play_game's env.reset() of this cohort's games
                 (void)coevo_mpe_host_reset_games(d->state, d->n_games, d->reset_rng, d->reset_ordinals, c.games, 0, c.n_games);
             const double t0 = J.timed ? now_us() : 0.0;
@@ -391,8 +443,17 @@ void drive_part(void *arg, int part, int parts)
                                             d->pos_first, c.games, 0, c.n_games, cyc < d->n_cycles ? 1 : 0, d->obs_host);
             const double t2 = J.timed ? now_us() : 0.0;
             if (cyc < d->n_cycles) {
-                const int rc = enqueue_cohort(J, k);
-                if (rc) { J.rc.store(rc); return; }
+                if (queued) {
+                    release_cohort(J.h, k);   // the queued launch starts now
+                    if (cyc + 1 < d->n_cycles) {   // ... and the next one is queued while it runs
+                        const int rc = enqueue_cohort(J, k, true);
+                        if (rc == COEVO_ERR_UNSUPPORTED) J.gate_off[k] = true;
+                        else if (rc) { J.rc.store(rc); return; }
+                    }
+                } else {
+                    const int rc = enqueue_cohort(J, k);
+                    if (rc) { J.rc.store(rc); return; }
+                }
             }
             if (J.timed) {
                 J.acc[k][1] += t2 - t1;
@@ -456,6 +517,9 @@ extern "C" int coevo_mpe_host_rollout(void *handle, const coevo_host_rollout_des
     J.act = d->actions_dev;
     J.timed = d->phase_us != nullptr;
     J.flag_mode = h->use_flags.load();
+    // (a timed rollout launches late: its per-launch events would be re-recorded by the pre-queued next launch before they
+    // are read; the breakdown it reports is that of the late-launch form, ~10 us of enqueue + launch latency per cycle more)
+    J.gate_mode = J.flag_mode && h->use_gates.load() && !J.timed;
     for (int k = 0; k < COEVO_MAX_COHORTS; ++k) {
         J.acc_n[k] = 0;
         for (int i = 0; i < 6; ++i) J.acc[k][i] = 0.0;
@@ -491,7 +555,9 @@ extern "C" int coevo_mpe_host_rollout(void *handle, const coevo_host_rollout_des
     h->pool.run(drive_part, &J);
 
     const int rc = J.rc.load();
-    if (rc != COEVO_OK) {   // leave no launch of ours in flight behind an error
+    if (rc != COEVO_OK) {   // leave no launch of ours in flight (or waiting at a gate) behind an error
+        if (h->gates)
+            for (int k = 0; k < K; ++k) release_cohort(h, k);
         for (int k = 0; k < K; ++k) (void)hipStreamSynchronize(h->lanes[k].s);
         return rc;
     }
