@@ -685,6 +685,14 @@ __global__ __launch_bounds__(64, (HALF || NB <= DQ_FC1_NB_MANY) ? 2 : 1) void dq
     const float *net = slab + task.net_off;
     const DqnLayout L = dqn_layout(C, n_actions);
     const int ob = blockIdx.y, l = threadIdx.x;
+#ifdef COEVO_PHASE_STAMPS
+    // diagnostic build only (tools/dqn_fc1_clock.py): shader-clock and 100 MHz stamps of wave (task ti, block 0) -> the clock
+    // the chip holds during this launch
+    if (ob == 0 && l == 0 && ti < 1024) {
+        g_dqn_stamps[ti * 16 + 10] = __builtin_amdgcn_s_memrealtime();
+        g_dqn_stamps[ti * 16 + 11] = __builtin_amdgcn_s_memtime();
+    }
+#endif
     // MFMA groups of this wave (workgroup-uniform, as is shared_net: one straight-line instantiation each)
     const int ng = HALF ? (task.n_rows + 7) >> 3 : (task.n_rows + 3) >> 2;
     if constexpr (HALF) {
@@ -706,6 +714,12 @@ __global__ __launch_bounds__(64, (HALF || NB <= DQ_FC1_NB_MANY) ? 2 : 1) void dq
         else if (ng == 3) dqn_fc1_body<3, NB, false>(net, L, task, act, hid, xs, ob, l);
         else dqn_fc1_body<4, NB, false>(net, L, task, act, hid, xs, ob, l);
     }
+#ifdef COEVO_PHASE_STAMPS
+    if (ob == 0 && l == 0 && ti < 1024) {
+        g_dqn_stamps[ti * 16 + 12] = __builtin_amdgcn_s_memrealtime();
+        g_dqn_stamps[ti * 16 + 13] = __builtin_amdgcn_s_memtime();
+    }
+#endif
 }
 
 // fc1 + ReLU of a SMALL launch (a Co-ES generation's ten evaluation games: one task per agent-step, 600 dependent launches
