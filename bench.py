@@ -639,7 +639,10 @@ def run_ga(a, ctx, dev):
                                                    "host_step_observe": float(host_phase[1]),
                                                    "host_enqueue": float(host_phase[2]), "h2d_obs": float(host_phase[3]),
                                                    "launch": float(host_phase[4]), "d2h_actions": float(host_phase[5])},
-                           "pcie_bytes_per_cycle": eng.plan.n_rows * (4 * L.OBS_STRIDE + 4)}
+                           "pcie_bytes_per_cycle": eng.plan.n_rows * (4 * L.OBS_STRIDE + 4),
+                           # where the host cores run (csrc/host_placement.hip): the caller's thread is pinned to cpus[0] for
+                           # the rollout, the workers to the rest; COEVO_HOST_PIN=far reproduces the far-socket placement
+                           "placement": getattr(eng.ro, "placement", None)}
         out["roofline"] = {"bound": "hbm", "kernel": "fc_cycle16_kernel<R, MODE_OBS> (observations given; one launch per "
                            "cohort and env-cycle)", "timing": "HIP events on the cohort's stream (2 extra generations)",
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,

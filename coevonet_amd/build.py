@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libcoevo.so")
 SOURCES = ["fc_forward.hip", "mpe_env.hip", "offspring.hip", "select.hip", "rollout_api.hip", "deepqn.hip",
-           "dqn_engine.hip", "host_rollout.hip"]
+           "dqn_engine.hip", "host_rollout.hip", "host_placement.hip"]
 # -ffp-contract=off: only explicit fmaf fuses (the canonical arithmetic contract with the oracle)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
          "-Wno-unused-function"]

@@ -16,6 +16,7 @@
 #include <pthread.h>
 #include <sched.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -26,6 +27,7 @@
 #include <vector>
 
 #include "coevo_common.hip.h"
+#include "host_placement.hip.h"
 
 namespace {
 
@@ -51,21 +53,17 @@ struct HostPool {
 
     explicit HostPool(int threads) : T(threads < 1 ? 1 : threads), slots((size_t)(threads < 1 ? 1 : threads))
     {
-        // workers next to the creating thread: the cores of its own 8-core complex share an L3 and a memory controller (on
-        // the 2-socket host of a GPU box an unpinned worker landed on the far socket and stepped its games at half speed).
-        // COEVO_HOST_PIN=0 leaves the placement to the scheduler; a core outside the affinity mask is simply not taken.
-        const char *pin_env = getenv("COEVO_HOST_PIN");
-        const bool pin = !(pin_env && pin_env[0] == '0');
-        const int me = sched_getcpu();
-        for (int i = 1; i < T; ++i) {
-            th.emplace_back([this, i] { worker(i); });
-            if (pin && me >= 0 && T <= 16) {   // (up to 16 threads: two neighbouring complexes of the same socket)
-                const int span = T <= 8 ? 8 : 16, base = me & ~(span - 1);
-                cpu_set_t set;
-                CPU_ZERO(&set);
-                CPU_SET(base + ((me - base + i) & (span - 1)), &set);
-                (void)pthread_setaffinity_np(th.back().native_handle(), sizeof(set), &set);
-            }
+        for (int i = 1; i < T; ++i) th.emplace_back([this, i] { worker(i); });
+    }
+    // worker i -> cpus[i] (cpus[0] is the caller's, pinned per rollout): the placement is chosen once the device is known
+    // (host_placement.hip); workers beyond the list stay where the scheduler puts them
+    void pin_workers(const std::vector<int> &cpus)
+    {
+        for (int i = 1; i < T && i < (int)cpus.size(); ++i) {
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            CPU_SET(cpus[(size_t)i], &set);
+            (void)pthread_setaffinity_np(th[(size_t)i - 1].native_handle(), sizeof(set), &set);
         }
     }
     ~HostPool()
@@ -152,8 +150,76 @@ struct HostRollout {
     uint32_t wait_target[COEVO_MAX_COHORTS] = {0, 0, 0, 0, 0, 0, 0, 0};     // completion number of the launch that RUNS
     uint32_t pending_seq[COEVO_MAX_COHORTS] = {0, 0, 0, 0, 0, 0, 0, 0};     // ... of the one queued behind its gate
     std::atomic<bool> use_gates{false};
+    // where the cores run (host_placement.hip): chosen at the first rollout / allocation, when the device is known
+    bool placed = false, pinned = false;
+    std::vector<int> cpus;        // cpus[0]: the caller's thread during a rollout, cpus[i]: worker i
+    int gpu_node = -1, node_used = -1, place_flags = 0, ctx_index = 0;
+    char pin_mode = '1';          // COEVO_HOST_PIN: '1' the GPU's node (default), 'f' ("far") another node on purpose, '0' none
+    std::vector<void *> host_allocs;   // coevo_host_rollout_alloc
     explicit HostRollout(int threads) : pool(threads) {}
 };
+
+std::atomic<int> g_ctx_counter{0};
+
+// the caller's thread on its CPU for the duration of a rollout / an allocation; the mask it came with is put back
+struct CallerPin {
+    cpu_set_t saved;
+    bool active = false;
+    explicit CallerPin(const HostRollout *h)
+    {
+        if (!h->pinned || h->cpus.empty()) return;
+        if (sched_getaffinity(0, sizeof(saved), &saved) != 0) return;
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(h->cpus[0], &set);
+        active = sched_setaffinity(0, sizeof(set), &set) == 0;
+    }
+    ~CallerPin()
+    {
+        if (active) (void)sched_setaffinity(0, sizeof(saved), &saved);
+    }
+};
+
+// choose the context's CPUs (once): the L3 complex of the GPU's NUMA node the affinity mask allows
+void ensure_placement(HostRollout *h)
+{
+    if (h->placed) return;
+    h->placed = true;
+    const char *pin_env = getenv("COEVO_HOST_PIN");
+    h->pin_mode = (pin_env && pin_env[0] == '0') ? '0' : (pin_env && pin_env[0] == 'f') ? 'f' : '1';
+    int dev = 0;
+    char bdf[64] = {0};
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), dev) == hipSuccess)
+        h->gpu_node = coevo::numa_node_of_pci(bdf);
+    else
+        (void)hipGetLastError();
+    if (h->pin_mode == '0') return;
+    coevo::HostTopology topo;
+    coevo::probe_topology(topo);
+    const int me = sched_getcpu();
+    int want = h->gpu_node;
+    if (want < 0 || want >= (int)topo.node_cpus.size() || topo.node_cpus[(size_t)want].empty())
+        want = coevo::node_of_cpu(topo, me);   // unknown (a VM that hides it): the caller's own node
+    if (h->pin_mode == 'f') {   // A/B: a node that is NOT the wanted one, to reproduce the far-socket step on purpose
+        const std::vector<int> allowed = coevo::parse_cpulist(topo.allowed.c_str());
+        for (int n = 0; n < (int)topo.node_cpus.size(); ++n) {
+            if (n == want) continue;
+            bool any = false;
+            for (int c : coevo::parse_cpulist(topo.node_cpus[(size_t)n].c_str()))
+                if (std::binary_search(allowed.begin(), allowed.end(), c)) { any = true; break; }
+            if (any) { want = n; break; }
+        }
+    }
+    const char *lr = getenv("LOCAL_RANK");
+    h->ctx_index = 2 * (lr ? atoi(lr) : 0) + (g_ctx_counter.fetch_add(1) & 1);
+    const char *node_s = (want >= 0 && want < (int)topo.node_cpus.size()) ? topo.node_cpus[(size_t)want].c_str() : "";
+    const int n = coevo::choose_placement(topo.allowed.c_str(), node_s, topo.l3_groups.c_str(), topo.smt_groups.c_str(), me,
+                                          h->pool.T, h->ctx_index, h->cpus, h->place_flags);
+    h->node_used = (n > 0) ? coevo::node_of_cpu(topo, h->cpus[0]) : -1;
+    h->pinned = n > 0;
+    if (h->pinned) h->pool.pin_workers(h->cpus);
+}
+
 
 struct StepJob {
     const coevo_host_rollout_desc *d;
@@ -247,6 +313,7 @@ extern "C" void coevo_host_rollout_destroy(void *handle)
     }
     if (h->start) (void)hipEventDestroy(h->start);
     if (h->flags) (void)hipHostFree(const_cast<uint32_t *>(h->flags));
+    for (void *p : h->host_allocs) (void)hipHostFree(p);
     delete h;
 }
 
@@ -254,6 +321,48 @@ extern "C" int coevo_host_rollout_threads(void *handle)
 {
     auto *h = static_cast<HostRollout *>(handle);
     return h ? h->pool.T : COEVO_ERR_ARG;
+}
+
+// Page-locked, device-mapped host memory for the observation / action staging buffers, allocated FROM the context's first CPU
+// and zeroed there: the pages are first touched on the NUMA node the rollout's cores run on (hipHostMallocNumaUser leaves the
+// placement to the calling thread; without it the runtime decides).  Freed by coevo_host_rollout_destroy.
+extern "C" void *coevo_host_rollout_alloc(void *handle, size_t bytes)
+{
+    auto *h = static_cast<HostRollout *>(handle);
+    if (!h || bytes == 0) return nullptr;
+    ensure_placement(h);
+    CallerPin pin(h);
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocMapped | hipHostMallocNumaUser) != hipSuccess || !p) {
+        (void)hipGetLastError();
+        p = nullptr;
+        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess || !p) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
+    memset(p, 0, bytes);
+    h->host_allocs.push_back(p);
+    return p;
+}
+
+// what the context chose: cpus_out[0 .. n) (cpus_out[0] = the caller's thread during a rollout), info_out[0..4) = {NUMA node
+// of the GPU (-1 unknown), node of the chosen CPUs, COEVO_PLACE_* flags, pinned (0 / 1)}.  Returns n (0: not pinned).
+// Before the first rollout / allocation of the context the choice is made now (needs the current device).
+extern "C" int coevo_host_rollout_placement(void *handle, int32_t *cpus_out, int max_cpus, int32_t *info_out)
+{
+    auto *h = static_cast<HostRollout *>(handle);
+    if (!h || max_cpus < 0 || (max_cpus > 0 && !cpus_out)) return COEVO_ERR_ARG;
+    ensure_placement(h);
+    const int n = h->pinned ? (int)h->cpus.size() : 0;
+    for (int i = 0; i < n && i < max_cpus; ++i) cpus_out[i] = h->cpus[(size_t)i];
+    if (info_out) {
+        info_out[0] = h->gpu_node;
+        info_out[1] = h->node_used;
+        info_out[2] = h->place_flags;
+        info_out[3] = h->pinned ? 1 : 0;
+    }
+    return n;
 }
 
 // world step `cycle` (< 0: none) + observations (observe != 0) of the listed games on the context's host cores: what a
@@ -465,13 +574,31 @@ void drive_part(void *arg, int part, int parts)
 
 }  // namespace
 
+// tests only: leave the context's completion / gate numbering where `value` earlier cycles would have left it (a rollout
+// restarts the numbering while its lanes are idle, so it must not matter: ADVICE r4 - near 2^31 / 2^32 a stream wait on ">="
+// would otherwise be satisfied by the OLD word and a launch would run on the previous cycle's observations)
+extern "C" int coevo_host_rollout_debug_seed_counters(void *handle, uint32_t value)
+{
+    auto *h = static_cast<HostRollout *>(handle);
+    if (!h) return COEVO_ERR_ARG;
+    const int rc = ensure_lanes(h);
+    if (rc) return rc;
+    if (!h->flags) return COEVO_ERR_UNSUPPORTED;
+    for (int k = 0; k < COEVO_MAX_COHORTS; ++k) {
+        h->flags[16 * k] = value;
+        h->gates[16 * k] = value;
+        h->seq[k] = h->gate_issued[k] = h->gate_released[k] = h->wait_target[k] = h->pending_seq[k] = value;
+    }
+    return COEVO_OK;
+}
+
 extern "C" int coevo_mpe_host_rollout(void *handle, const coevo_host_rollout_desc *d, void *stream)
 {
     auto *h = static_cast<HostRollout *>(handle);
     if (!h || !d || !d->slab || !d->state || !d->game_rows || !d->obs_host || !d->obs_dev || !d->actions_host ||
         !d->actions_dev || !d->status || !d->cohorts)
         return COEVO_ERR_ARG;
-    if (d->n_games <= 0 || d->n_rows != 3 * d->n_games || d->n_cycles < 0 || d->n_cohorts < 1 ||
+    if (d->n_games <= 0 || d->n_rows != 3 * d->n_games || d->n_cycles < 0 || d->n_cycles > (1 << 24) || d->n_cohorts < 1 ||
         d->n_cohorts > h->max_cohorts)
         return COEVO_ERR_ARG;
     const int K = d->n_cohorts;
@@ -479,6 +606,8 @@ extern "C" int coevo_mpe_host_rollout(void *handle, const coevo_host_rollout_des
         const int rc_l = ensure_lanes(h);
         if (rc_l) return rc_l;
     }
+    ensure_placement(h);
+    CallerPin caller_pin(h);   // the caller's thread next to its workers for this rollout; its own mask comes back at return
     // every game in exactly one cohort, its three rows inside the cohort's row range; the ranges disjoint
     {
         std::vector<uint8_t> seen((size_t)d->n_games, 0);
@@ -528,15 +657,28 @@ extern "C" int coevo_mpe_host_rollout(void *handle, const coevo_host_rollout_des
     if (hipGetDevice(&J.device) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, J.device) != hipSuccess || cus <= 0)
         return COEVO_ERR_HIP;
-    if (d->zero_copy) {   // the launches address the page-locked host buffers themselves: they must be mapped for this device
+    {   // both staging buffers must be page-locked and mapped for this device - zero_copy: the launches address them; staged
+        // copies: a hipMemcpyAsync from pageable memory BLOCKS the calling core, here on a stream only that core can release
         void *po = nullptr, *pa = nullptr;
         if (hipHostGetDevicePointer(&po, d->obs_host, 0) != hipSuccess ||
             hipHostGetDevicePointer(&pa, d->actions_host, 0) != hipSuccess || !po || !pa) {
             (void)hipGetLastError();
             return COEVO_ERR_ARG;
         }
-        J.obs = static_cast<const float *>(po);
-        J.act = static_cast<int32_t *>(pa);
+        if (d->zero_copy) {
+            J.obs = static_cast<const float *>(po);
+            J.act = static_cast<int32_t *>(pa);
+        }
+    }
+    // every lane is idle here (the previous rollout saw its last completion word, or drained its streams on error): the
+    // sequence numbers restart, so that they never come near a 32-bit wrap (hipStreamWaitValueGte compares as written)
+    if (h->flags) {
+        for (int k = 0; k < COEVO_MAX_COHORTS; ++k) {
+            h->flags[16 * k] = 0;
+            h->gates[16 * k] = 0;
+            h->seq[k] = h->gate_issued[k] = h->gate_released[k] = h->wait_target[k] = h->pending_seq[k] = 0;
+        }
+        std::atomic_thread_fence(std::memory_order_seq_cst);
     }
     int wgs = 0;
     J.lean = true;   // the lean merged kernel needs every workgroup of every cohort in flight resident at four per CU
@@ -734,6 +876,8 @@ extern "C" int coevo_dqn_host_frames_rollout(void *handle, const coevo_frames_ro
         const int rc_l = ensure_lanes(h);
         if (rc_l) return rc_l;
     }
+    ensure_placement(h);
+    CallerPin caller_pin(h);
     const bool timed = d->phase_us != nullptr;
     double acc_host = 0.0, acc_wait = 0.0, acc_gpu[3] = {0.0, 0.0, 0.0};
     int acc_n = 0;
@@ -764,17 +908,21 @@ extern "C" int coevo_dqn_host_frames_rollout(void *handle, const coevo_frames_ro
             }
             if (t == d->T) continue;
             const int p = t & 1;
-            if (timed) COEVO_HIP_CHECK(hipEventRecord(ln.t[0], ln.s));
-            COEVO_HIP_CHECK(hipMemcpyAsync(c.frames_dev, c.frames_host, (size_t)c.n_games * nbytes, hipMemcpyHostToDevice, ln.s));
-            if (timed) COEVO_HIP_CHECK(hipEventRecord(ln.t[1], ln.s));
+            // (a HIP error leaves the loop through `rc`, so that the lanes are drained below before the caller - who may free
+            // frames_host / actions_host on an error - sees it)
+            auto ok = [&](hipError_t e) { if (e != hipSuccess && rc == COEVO_OK) rc = COEVO_ERR_HIP; return rc == COEVO_OK; };
+            if (timed && !ok(hipEventRecord(ln.t[0], ln.s))) break;
+            if (!ok(hipMemcpyAsync(c.frames_dev, c.frames_host, (size_t)c.n_games * nbytes, hipMemcpyHostToDevice, ln.s))) break;
+            if (timed && !ok(hipEventRecord(ln.t[1], ln.s))) break;
             rc = coevo_dqn_forward_argmax(d->slab, c.tasks[p], c.n_tasks[p], c.max_rows[p], c.n_games, d->C, d->n_actions,
                                           c.frames_dev, c.actions_dev, nullptr, d->status, c.workspace, ln.s);
             if (rc) break;
-            if (timed) COEVO_HIP_CHECK(hipEventRecord(ln.t[2], ln.s));
-            COEVO_HIP_CHECK(hipMemcpyAsync(c.actions_host, c.actions_dev, (size_t)c.n_games * sizeof(int32_t),
-                                           hipMemcpyDeviceToHost, ln.s));
-            if (timed) COEVO_HIP_CHECK(hipEventRecord(ln.t[3], ln.s));
-            COEVO_HIP_CHECK(hipEventRecord(ln.done, ln.s));
+            if (timed && !ok(hipEventRecord(ln.t[2], ln.s))) break;
+            if (!ok(hipMemcpyAsync(c.actions_host, c.actions_dev, (size_t)c.n_games * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                   ln.s)))
+                break;
+            if (timed && !ok(hipEventRecord(ln.t[3], ln.s))) break;
+            if (!ok(hipEventRecord(ln.done, ln.s))) break;
         }
     }
     if (rc != COEVO_OK) {

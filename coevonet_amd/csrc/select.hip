@@ -393,7 +393,7 @@ COEVO_DEFINE_TU_FLAGS(select)
 namespace coevo {
 const char *tu_flags_fc_forward(); const char *tu_flags_mpe_env(); const char *tu_flags_offspring();
 const char *tu_flags_rollout_api(); const char *tu_flags_deepqn(); const char *tu_flags_dqn_engine();
-const char *tu_flags_host_rollout();
+const char *tu_flags_host_rollout(); const char *tu_flags_host_placement();
 }
 
 extern "C" const char *coevo_build_flags(void)
@@ -401,13 +401,14 @@ extern "C" const char *coevo_build_flags(void)
     static char buf[1024];
     static bool done = false;
     if (!done) {   // (idempotent: a race between first callers writes the same bytes)
-        const char *names[] = {"fc_forward", "mpe_env", "offspring", "select", "rollout_api", "deepqn", "dqn_engine", "host_rollout"};
+        const char *names[] = {"fc_forward", "mpe_env", "offspring", "select", "rollout_api", "deepqn", "dqn_engine", "host_rollout",
+                               "host_placement"};
         const char *flags[] = {coevo::tu_flags_fc_forward(), coevo::tu_flags_mpe_env(), coevo::tu_flags_offspring(),
                                coevo::tu_flags_select(), coevo::tu_flags_rollout_api(), coevo::tu_flags_deepqn(),
-                               coevo::tu_flags_dqn_engine(), coevo::tu_flags_host_rollout()};
+                               coevo::tu_flags_dqn_engine(), coevo::tu_flags_host_rollout(), coevo::tu_flags_host_placement()};
         size_t n = 0;
         buf[0] = 0;
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 9; ++i) {
             if (!flags[i][0]) continue;
             const int w = snprintf(buf + n, sizeof(buf) - n, "%s%s: %s", n ? "; " : "", names[i], flags[i]);
             if (w < 0 || (size_t)w >= sizeof(buf) - n) break;

@@ -232,7 +232,8 @@ class HostFrameRollout(SynthRollout):
         super().__init__(*a, **k)
         n, K = self.n_games, len(self.lanes)
         if threads is None:
-            threads = int(os.environ.get("COEVO_FRAME_THREADS", "0")) or min(16, os.cpu_count() or 1)
+            # (the cores this thread may run on, not the machine's: a cgroup / taskset-limited rank gets its own share)
+            threads = int(os.environ.get("COEVO_FRAME_THREADS", "0")) or min(16, len(os.sched_getaffinity(0)) or 1)
         self.h_gstate = np.zeros((n, 4), dtype=np.int32)
         self.h_acc = np.zeros((n, 3), dtype=np.float64)
         self.h_ordinal0 = np.ascontiguousarray(self.ordinal0.cpu().numpy(), dtype=np.int64)
@@ -241,13 +242,15 @@ class HostFrameRollout(SynthRollout):
         if not self.frame_ctx:
             raise L.CoevoError("coevo_host_rollout_create failed")
         self.threads = int(L.load().coevo_host_rollout_threads(self.frame_ctx))
+        self.placement = L.host_placement(self.frame_ctx)
         self.phase_us = None          # a float64[5] array to collect the per-cohort-step breakdown
         self._cohorts = (L.FrameCohort * K)()
         self._keep = []
         for k_, ln in enumerate(self.lanes):
             m = ln["n"]
-            fh = torch.zeros(m * FRAME * self.C, dtype=torch.uint8).pin_memory()
-            ah = torch.zeros(m, dtype=torch.int32).pin_memory()
+            # page-locked, first touched on the NUMA node the context's cores run on (the GPU's: csrc/host_placement.hip)
+            fh = L.host_tensor(self.frame_ctx, (m * FRAME * self.C,), np.uint8)
+            ah = L.host_tensor(self.frame_ctx, (m,), np.int32)
             rows = [np.ascontiguousarray(ln["rows"][p].cpu().numpy(), dtype=np.int32) for p in range(2)]
             self._keep.append((fh, ah, rows))
             c = self._cohorts[k_]
@@ -283,12 +286,18 @@ class HostFrameRollout(SynthRollout):
     def close(self):
         super().close()
         if getattr(self, "frame_ctx", None):
+            self._keep = []   # (the page-locked frame / action buffers belong to the context)
             L.load().coevo_host_rollout_destroy(self.frame_ctx)
             self.frame_ctx = None
 
     def __del__(self):
+        # the destroy releases streams, events and page-locked memory (hipHostFree synchronises the device): not from a
+        # finaliser that runs while another engine captures a hipGraph - the context then lives until close() / exit
         try:
-            if getattr(self, "frame_ctx", None):   # (joins the worker threads; no device call)
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                return
+            if getattr(self, "frame_ctx", None):
+                self._keep = []
                 L.load().coevo_host_rollout_destroy(self.frame_ctx)
                 self.frame_ctx = None
         except Exception:

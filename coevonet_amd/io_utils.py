@@ -92,11 +92,26 @@ def save_state_dicts(agents, file_path, role=None):
     return path
 
 
-def load_state_dicts(path):
-    """-> (list of state_dicts, role, was_single_agent); never unpickles code"""
+def load_state_dicts(path, strict_noise=False):
+    """-> (list of state_dicts, role, was_single_agent); never unpickles code.
+
+    The file records the offspring-noise contract it was written under ("noise": "philox4x32-<rounds>"): a device_philox
+    run resumed under another contract breeds OTHER offspring from the same seed.  A mismatch warns (the weights themselves
+    are valid under any contract); strict_noise=True refuses."""
     payload = torch.load(path, weights_only=True)
     if payload.get("format") != "coevonet_amd.state_dict.v1":
         raise ValueError(f"{path} is not a coevonet_amd state_dict checkpoint")
+    saved = payload.get("noise")
+    if saved is not None:
+        from . import lib as L
+        now = f"philox4x32-{int(L.load().coevo_noise_rounds())}"
+        if saved != now:
+            msg = (f"{path} was written under offspring noise {saved!r} (coevo_version {payload.get('coevo_version')}), this "
+                   f"library breeds with {now!r}: a resumed device_philox run will not continue the saved run's offspring")
+            if strict_noise:
+                raise ValueError(msg)
+            import warnings
+            warnings.warn(msg, RuntimeWarning, stacklevel=2)
     return payload["agents"], payload["role"], bool(payload["single"])
 
 

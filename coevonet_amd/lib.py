@@ -147,6 +147,11 @@ _SIGS = {
     "coevo_host_rollout_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                           C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "coevo_mpe_host_rollout": (C.c_int, [C.c_void_p, C.POINTER(HostRolloutDesc), C.c_void_p]),
+    "coevo_host_placement_choose": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_void_p]),
+    "coevo_host_rollout_placement": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "coevo_host_rollout_alloc": (C.c_void_p, [C.c_void_p, C.c_size_t]),
+    "coevo_host_rollout_debug_seed_counters": (C.c_int, [C.c_void_p, C.c_uint32]),
     "coevo_dqn_host_frames_rollout": (C.c_int, [C.c_void_p, C.POINTER(FramesRolloutDesc), C.c_void_p]),
     "coevo_synth_frame_host": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_int, C.c_int]),
     "coevo_mpe_rewards": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -300,6 +305,31 @@ def fc_param_count(D):
 
 def fc_slab_stride(D):
     return int(load().coevo_fc_slab_stride(D))
+
+
+def host_tensor(ctx, shape, dtype):
+    """zero-filled page-locked, device-mapped host tensor owned by the host-rollout context `ctx` (coevo_host_rollout_alloc:
+    first touched on the NUMA node the context's cores run on); valid until the context is destroyed"""
+    shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    np_dtype = np.dtype(dtype)
+    nbytes = max(int(np.prod(shape)) * np_dtype.itemsize, 1)
+    ptr = load().coevo_host_rollout_alloc(ctx, nbytes)
+    if not ptr:
+        raise CoevoError("coevo_host_rollout_alloc failed")
+    buf = (C.c_char * nbytes).from_address(ptr)
+    return torch.from_numpy(np.frombuffer(buf, dtype=np_dtype, count=int(np.prod(shape))).reshape(shape))
+
+
+def host_placement(ctx, max_cpus=256):
+    """-> {"cpus": [...], "gpu_numa_node": n, "cpu_numa_node": n, "pinned": bool, "on_gpu_node": bool, "one_l3": bool}"""
+    cpus = np.zeros(max_cpus, dtype=np.int32)
+    info = np.zeros(4, dtype=np.int32)
+    n = load().coevo_host_rollout_placement(ctx, cpus.ctypes.data, max_cpus, info.ctypes.data)
+    if n < 0:
+        raise CoevoError(f"coevo_host_rollout_placement failed with code {n}")
+    return {"cpus": [int(c) for c in cpus[:n]], "gpu_numa_node": int(info[0]), "cpu_numa_node": int(info[1]),
+            "pinned": bool(info[3]), "on_gpu_node": bool(info[2] & 1), "one_l3": bool(info[2] & 2),
+            "mode": os.environ.get("COEVO_HOST_PIN", "1")}
 
 
 def tasks_to_device(tasks_np, device="cuda"):

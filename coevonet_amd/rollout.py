@@ -396,10 +396,8 @@ class HostEnvRollout:
         self.plan = plan
         self.slab = slab
         dev = plan.device
-        self.obs_host = torch.zeros(plan.n_rows, L.OBS_STRIDE, dtype=torch.float32).pin_memory()
         self.obs = torch.zeros(plan.n_rows, L.OBS_STRIDE, dtype=torch.float32, device=dev)
         self.actions = torch.zeros(plan.n_rows, dtype=torch.int32, device=dev)
-        self.actions_host = torch.zeros(plan.n_rows, dtype=torch.int32).pin_memory()
         self.status = torch.zeros(1, dtype=torch.int32, device=dev)
         self.env_seed = env_seed
         self.set_limits(np.zeros(plan.n_games, dtype=np.int64))
@@ -410,6 +408,9 @@ class HostEnvRollout:
         self._pending_ordinals = None   # set by reset_from_ordinals: the next run() draws these resets first
         self.phase_us = None          # set to a float64[6] array to collect the per-cohort-cycle breakdown
         self.zero_copy = os.environ.get("COEVO_HOST_ZERO_COPY", "1") == "1"
+        if self.impl != "native":
+            self.obs_host = torch.zeros(plan.n_rows, L.OBS_STRIDE, dtype=torch.float32).pin_memory()
+            self.actions_host = torch.zeros(plan.n_rows, dtype=torch.int32).pin_memory()
         if self.impl == "native":
             p = plan
             K = p.n_cohorts
@@ -422,6 +423,11 @@ class HostEnvRollout:
             if not self.ctx:
                 raise L.CoevoError("coevo_host_rollout_create failed")
             self.threads = int(L.load().coevo_host_rollout_threads(self.ctx))
+            # the staging buffers come from the context: page-locked, mapped, first touched on the NUMA node its cores run on
+            # (the GPU's, as far as the affinity mask allows - csrc/host_placement.hip)
+            self.obs_host = L.host_tensor(self.ctx, (plan.n_rows, L.OBS_STRIDE), np.float32)
+            self.actions_host = L.host_tensor(self.ctx, (plan.n_rows,), np.int32)
+            self.placement = L.host_placement(self.ctx)
             self._game_rows32 = np.ascontiguousarray(p.game_rows_np, dtype=np.int32)
             rows = p.cohort_row_begin_np if p.cohort_row_begin_np is not None else np.array([0, p.n_rows])
             self._cohort_games = [np.ascontiguousarray(np.nonzero(p.game_cohort_np == k)[0], dtype=np.int32)
@@ -440,12 +446,19 @@ class HostEnvRollout:
                     n_games=len(self._cohort_games[k]), row_first=int(rows[k]), n_rows=int(rows[k + 1] - rows[k]))
 
     def close(self):
+        """releases the context: its worker threads, streams, events and the page-locked buffers (obs_host / actions_host
+        are invalid afterwards)"""
         if getattr(self, "ctx", None):
+            self.obs_host = self.actions_host = None
             L.load().coevo_host_rollout_destroy(self.ctx)
             self.ctx = None
 
     def __del__(self):
+        # the destroy frees page-locked memory (hipHostFree synchronises the device): never from a finaliser that the
+        # garbage collector runs while another engine captures a hipGraph - the context then lives until close() / exit
         try:
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                return
             self.close()
         except Exception:
             pass

@@ -19,13 +19,15 @@
 #ifndef COEVO_H
 #define COEVO_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define COEVO_VERSION 101   /* 101: offspring noise = Philox4x32-7 (100: -10; other numbers for the same seed), host-cores
+#define COEVO_VERSION 102   /* 102: host-cores placement (coevo_host_placement_choose, coevo_host_rollout_placement / _alloc),
+                             * wide small-shard cycle kernel; 101: offspring noise = Philox4x32-7 (100: -10; other numbers for the same seed), host-cores
                              * rollout entry points, coevo_noise_rounds */
 
 #define COEVO_OK 0
@@ -186,6 +188,30 @@ void *coevo_host_rollout_create(int n_threads, int n_cohorts);   /* worker threa
 void coevo_host_rollout_destroy(void *ctx);
 int coevo_host_rollout_threads(void *ctx);                       /* host cores a rollout uses (caller's thread included) */
 int coevo_mpe_host_rollout(void *ctx, const coevo_host_rollout_desc *desc, void *stream);
+/* WHICH host cores (the reference steps its env on whatever core runs the interpreter, utils/game_logic_functions.py:138,
+ * 179-190; on a two-socket GPU host that choice is a factor of four in the env step).  A context runs its cores in one L3
+ * complex of the GPU's NUMA node, as far as the caller's affinity mask allows: the caller's thread is pinned to cpus[0] for
+ * the duration of a rollout (its mask is put back at return), worker i to cpus[i].  COEVO_HOST_PIN=0: no pinning; =far: a
+ * node that is NOT the GPU's (to reproduce the slow placement on purpose).
+ * coevo_host_placement_choose is the choice as a pure function of sysfs-style strings (cpulist syntax "0-7,128-135"; groups
+ * separated by ';'): -> number of CPUs written to cpus_out (<= n_threads; 0: nothing to pin to), COEVO_PLACE_* in *flags_out.
+ * allowed = the affinity mask; node_cpus = the wanted node's CPUs ("" = unknown: every allowed CPU is a candidate);
+ * l3_groups / smt_groups = the L3 complexes / SMT sibling sets; caller_cpu = where the caller runs now (its own complex is
+ * preferred, and it keeps its CPU); ctx_index moves on by whole complexes (ranks / contexts side by side). */
+#define COEVO_PLACE_ON_NODE 1       /* the CPUs are on the wanted node */
+#define COEVO_PLACE_ONE_L3 2        /* ... all in one L3 complex */
+#define COEVO_PLACE_NODE_UNKNOWN 4  /* no node given */
+#define COEVO_PLACE_SHORT 8         /* fewer CPUs than threads: the last threads stay unpinned */
+int coevo_host_placement_choose(const char *allowed, const char *node_cpus, const char *l3_groups, const char *smt_groups,
+                                int caller_cpu, int n_threads, int ctx_index, int32_t *cpus_out, int32_t *flags_out);
+/* what a context chose (made now if it has not run yet; needs the current device): cpus_out[0..n), info_out[0..4) = {NUMA node
+ * of the GPU or -1, node of the chosen CPUs, COEVO_PLACE_* flags, pinned 0/1}; returns n (0: not pinned) */
+int coevo_host_rollout_placement(void *ctx, int32_t *cpus_out, int max_cpus, int32_t *info_out);
+/* page-locked, device-mapped host memory first touched on the context's node (for obs_host / actions_host / frames_host);
+ * zero-filled; owned by the context (freed by coevo_host_rollout_destroy); NULL on failure */
+void *coevo_host_rollout_alloc(void *ctx, size_t bytes);
+/* tests only: leave the context's completion / gate sequence numbers where `value` earlier cycles would have left them */
+int coevo_host_rollout_debug_seed_counters(void *ctx, uint32_t value);
 /* one cohort-cycle's host share alone, on the context's cores: world step `cycle` (< 0: none) of the n_list listed games,
  * then (observe != 0) their observation rows.  Needs no GPU.  n_rows = length of `actions` / rows of `obs`. */
 int coevo_host_rollout_step(void *ctx, double *state, int n_games, const int32_t *game_rows, const int32_t *actions,

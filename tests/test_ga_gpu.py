@@ -220,3 +220,89 @@ def test_host_cores_rollout_tiny_and_ragged(monkeypatch):
         assert res.elite_ids[g] == want.elite_ids[g]
         assert np.array_equal(np.asarray(res.game_rewards[g]).view(np.uint64), np.asarray(want.game_rewards[g]).view(np.uint64))
         assert [res.rewards[r][g] for r in ga.ROLES] == [want.rewards[r][g] for r in ga.ROLES]
+
+
+def _host_trainer_run(cfg, before_step=None):
+    torch.manual_seed(cfg["seed"])
+    np.random.seed(cfg["seed"])
+    args = Bag(algorithm="GA", **cfg["args"])
+    env = initialize_env(args)
+    tr = ga.GATrainer(env, args, rng="device_philox", env_mode="host")
+    for _ in range(args.generations):
+        if before_step:
+            before_step(tr)
+        tr.step()
+    return tr, tr.finish()
+
+
+@pytest.mark.parametrize("pin", ["1", "0", "far"])
+def test_host_cores_placement_modes_change_no_number(monkeypatch, pin):
+    """where the host cores run (csrc/host_placement.hip: the GPU's NUMA node by default, unpinned with COEVO_HOST_PIN=0, a
+    node that is NOT the GPU's with =far) changes the schedule, never a number; the caller's affinity mask is the one it came
+    with after every rollout, the chosen CPUs lie inside it, and the page-locked staging buffers come from the context
+    (utils/game_logic_functions.py:138,179-190 on "the host cores")"""
+    import os
+    cfg = {"seed": 5, "args": dict(generations=2, population=9, hof_size=2, elites_number=2, fitness_sharing=True,
+                                   max_timesteps_per_episode=30, max_evaluation_steps=75)}
+    _, _, want = _run(cfg, "device_philox", "device")
+    monkeypatch.setenv("COEVO_HOST_PIN", pin)
+    monkeypatch.setenv("COEVO_HOST_COHORTS", "2")
+    before = os.sched_getaffinity(0)
+    tr, res = _host_trainer_run(cfg)
+    assert os.sched_getaffinity(0) == before
+    pl = tr.eng.ro.placement
+    print("placement", pin, pl)
+    assert pl["pinned"] == (pin != "0")
+    if pin != "0":
+        assert set(pl["cpus"]) <= before and len(set(pl["cpus"])) == len(pl["cpus"]) == tr.eng.ro.threads
+        if pin == "1" and pl["gpu_numa_node"] >= 0 and pl["on_gpu_node"]:
+            assert pl["cpu_numa_node"] == pl["gpu_numa_node"]
+    for g in range(2):
+        assert res.elite_ids[g] == want.elite_ids[g]
+        assert np.array_equal(np.asarray(res.game_rewards[g]).view(np.uint64), np.asarray(want.game_rewards[g]).view(np.uint64))
+    tr.eng.ro.close()
+
+
+@pytest.mark.parametrize("seeded", [0x7FFFFFF0, 0xFFFFFFF0])
+def test_host_cores_rollout_restarts_its_sequence_numbers(monkeypatch, seeded):
+    """the completion / gate words are 32-bit sequence numbers waited for with '>='; left to grow across rollouts
+    they would cross 2^31 / 2^32 after days and a pre-queued launch would then start on the previous cycle's observations.
+    A rollout restarts them while its lanes are idle: seeded just below either wrap before EVERY rollout, results stay those
+    of the device env"""
+    from coevonet_amd import lib as L
+    cfg = {"seed": 7, "args": dict(generations=2, population=8, hof_size=2, elites_number=2, fitness_sharing=True,
+                                   max_timesteps_per_episode=75, max_evaluation_steps=75)}
+    _, _, want = _run(cfg, "device_philox", "device")
+    monkeypatch.setenv("COEVO_HOST_COHORTS", "2")
+
+    def seed(tr):
+        rc = L.load().coevo_host_rollout_debug_seed_counters(tr.eng.ro.ctx, seeded)
+        assert rc in (0, -3)   # (-3: the runtime refused stream-written words - events are used, nothing to seed)
+
+    tr, res = _host_trainer_run(cfg, before_step=seed)
+    for g in range(2):
+        assert res.elite_ids[g] == want.elite_ids[g]
+        assert np.array_equal(np.asarray(res.game_rewards[g]).view(np.uint64), np.asarray(want.game_rewards[g]).view(np.uint64))
+    tr.eng.ro.close()
+
+
+@pytest.mark.parametrize("zero_copy", ["0", "1"])
+def test_host_cores_rollout_refuses_pageable_staging_buffers(monkeypatch, zero_copy):
+    """obs_host / actions_host are documented as page-locked; a pageable buffer would make the staged copy block
+    the calling core behind a stream wait only that core can release.  Both copy modes validate them: COEVO_ERR_ARG"""
+    from coevonet_amd import lib as L
+    monkeypatch.setenv("COEVO_HOST_ZERO_COPY", zero_copy)
+    cfg = {"seed": 7, "args": dict(generations=1, population=4, hof_size=1, elites_number=1, fitness_sharing=True,
+                                   max_timesteps_per_episode=6, max_evaluation_steps=6)}
+    tr, _ = _host_trainer_run(cfg)
+    ro = tr.eng.ro
+    good = ro.obs_host
+    ro.obs_host = torch.zeros_like(good)           # pageable
+    ro.reset_from_ordinals(np.arange(ro.plan.n_games))
+    with pytest.raises(L.CoevoError):
+        ro.run(1)
+    ro.obs_host = good
+    ro.reset_from_ordinals(np.arange(ro.plan.n_games))
+    ro.run(1)                                       # ... and the context still works afterwards
+    ro.check_status()
+    ro.close()

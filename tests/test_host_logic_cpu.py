@@ -206,6 +206,16 @@ def test_weights_only_safe_checkpoint_roundtrip(tmp_path):
     one = agents_from_state_dicts(env, args, "adversary_0",
                                   save_state_dicts(agents[1], os.path.join(tmp_path, "adversary.pth"), role="adversary_0"))
     assert sha(one.model.flat()) == sha(agents[1].model.flat())
+    # the file names the offspring-noise contract it was written under; another one warns, or is refused on request
+    payload = torch.load(path, weights_only=True)
+    assert payload["noise"] == "philox4x32-7"
+    payload["noise"] = "philox4x32-10"
+    other = os.path.join(tmp_path, "other.state_dict.pth")
+    torch.save(payload, other)
+    with pytest.warns(RuntimeWarning, match="philox4x32-10"):
+        assert len(load_state_dicts(other)[0]) == 3
+    with pytest.raises(ValueError, match="offspring noise"):
+        load_state_dicts(other, strict_noise=True)
 
 
 def test_u8_over_255_two_term_product_is_the_ieee_quotient():
@@ -557,5 +567,86 @@ def test_host_rollout_entry_points_refuse_bad_descriptors():
                                              None) == -1   # a cycle to step, but no actions
         assert lib.coevo_mpe_host_step_games(st.ctypes.data, 4, gr.ctypes.data, None, -1, None, 1, games.ctypes.data, 0, 4, 1,
                                              None) == -1   # observations asked for, no buffer
+    finally:
+        lib.coevo_host_rollout_destroy(ctx)
+
+
+# ---- where the host cores of an env-on-the-host rollout run (csrc/host_placement.hip) ---------------------------------------
+def _choose(allowed, node, l3, smt, caller, threads, ctx_index=0):
+    from coevonet_amd import lib as L
+    cpus = np.full(256, -1, dtype=np.int32)
+    flags = np.zeros(1, dtype=np.int32)
+    n = L.load().coevo_host_placement_choose(allowed.encode(), node.encode(), l3.encode(), smt.encode(), caller, threads,
+                                             ctx_index, cpus.ctypes.data, flags.ctypes.data)
+    return [int(c) for c in cpus[:max(n, 0)]], int(flags[0]), n
+
+
+def _epyc_2s():
+    """the host of a GPU box as sysfs shows it: 2 sockets x 64 cores x 2 SMT threads, 8 cores (16 CPUs) per L3 complex;
+    node 0 = CPUs 0-63 + 128-191, node 1 = 64-127 + 192-255; core c's sibling is c + 128"""
+    l3 = ";".join(f"{b}-{b + 7},{b + 128}-{b + 135}" for b in range(0, 128, 8))
+    smt = ";".join(f"{c},{c + 128}" for c in range(128))
+    return {0: "0-63,128-191", 1: "64-127,192-255"}, l3, smt
+
+
+def test_host_placement_is_a_pure_function_of_mask_and_sysfs_strings():
+    """coevo_host_placement_choose: the cores of a host-cores rollout (the reference steps its env on whatever core runs the
+    interpreter, utils/game_logic_functions.py:138,179-190) as a function of (affinity mask, node cpulist, L3 groups, SMT
+    sets, the caller's CPU, thread count, context index) - no GPU, no real topology"""
+    ON, ONE_L3, UNKNOWN, SHORT = 1, 2, 4, 8
+    nodes, l3, smt = _epyc_2s()
+    # the caller sits on the far socket (CPU 3, node 0), the GPU hangs off node 1: both threads go to ONE complex of node 1,
+    # on two distinct physical cores
+    cpus, fl, n = _choose("0-255", nodes[1], l3, smt, caller=3, threads=2)
+    assert n == 2 and cpus == [64, 65] and fl == ON | ONE_L3
+    # the caller already runs on the GPU's node: it keeps its CPU (slot 0) and its own complex is taken
+    cpus, fl, _ = _choose("0-255", nodes[1], l3, smt, caller=77, threads=2)
+    assert cpus[0] == 77 and cpus[1] in range(72, 80) and cpus[1] != 77 and fl == ON | ONE_L3
+    # ... on an SMT sibling of that complex: still its own CPU first, then primaries of the same complex
+    cpus, fl, _ = _choose("0-255", nodes[1], l3, smt, caller=200, threads=3)
+    assert fl == ON | ONE_L3 and set(cpus) <= set(range(72, 80)) | set(range(200, 208)) and len(set(cpus)) == 3
+    # 16 threads (the DeepQN frame renderers): two neighbouring complexes, physical cores only
+    cpus, fl, n = _choose("0-255", nodes[1], l3, smt, caller=3, threads=16)
+    assert n == 16 and sorted(cpus) == list(range(64, 80)) and fl == ON
+    # 20 threads on a mask of ONE complex: SMT siblings only once the cores run out
+    cpus, fl, n = _choose("64-71,192-199", nodes[1], l3, smt, caller=64, threads=12)
+    assert n == 12 and sorted(cpus)[:8] == list(range(64, 72)) and set(cpus[8:]) <= set(range(192, 200)) and fl == ON | ONE_L3
+    cpus, fl, n = _choose("64-71,192-199", nodes[1], l3, smt, caller=64, threads=20)
+    assert n == 16 and fl & SHORT and len(set(cpus)) == 16
+    # context index: the next contexts / ranks move on by whole complexes and wrap inside the node
+    firsts = [_choose("0-255", nodes[1], l3, smt, caller=3, threads=2, ctx_index=i)[0] for i in range(9)]
+    assert [f[0] for f in firsts] == [64, 72, 80, 88, 96, 104, 112, 120, 64]
+    # no core of the GPU's node is allowed (taskset to socket 0): say so (flag clear), stay inside the mask, one complex
+    cpus, fl, n = _choose("8-15", nodes[1], l3, smt, caller=9, threads=2)
+    assert n == 2 and cpus[0] == 9 and set(cpus) <= set(range(8, 16)) and not fl & ON and not fl & UNKNOWN and fl & ONE_L3
+    # the node is unknown (a VM that hides it): the caller's own complex
+    cpus, fl, n = _choose("0-255", "", l3, smt, caller=21, threads=2)
+    assert n == 2 and cpus[0] == 21 and cpus[1] in range(16, 24) and fl == UNKNOWN | ONE_L3
+    # no sysfs at all: consecutive CPUs of the mask, starting at the caller's
+    cpus, fl, n = _choose("2-5", "", "", "", caller=4, threads=3)
+    assert n == 3 and cpus[0] == 4 and set(cpus) <= {2, 3, 4, 5} and fl & UNKNOWN
+    # a ragged mask across both nodes, GPU on node 0, caller on node 1
+    cpus, fl, n = _choose("5,6,70-90,133", nodes[0], l3, smt, caller=80, threads=2)
+    assert n == 2 and cpus == [5, 6] and fl == ON | ONE_L3
+    # argument errors
+    assert _choose("", nodes[1], l3, smt, 0, 2)[2] == 0           # empty mask: nothing to pin to
+    assert _choose("0-255", nodes[1], l3, smt, 0, 0)[2] == -1     # COEVO_ERR_ARG
+    assert _choose("garbage", "", "", "", 0, 1)[2] == 0
+
+
+def test_host_placement_of_a_context_on_this_machine():
+    """coevo_host_rollout_placement without a GPU: the node of the device is unknown (-1), so the context takes the caller's
+    own node; its CPUs lie inside the affinity mask, the caller's own CPU stays allowed afterwards (the pin is per rollout)"""
+    from coevonet_amd import lib as L
+    lib = L.load()
+    before = os.sched_getaffinity(0)
+    ctx = lib.coevo_host_rollout_create(2, 2)
+    assert ctx
+    try:
+        pl = L.host_placement(ctx)
+        assert pl["gpu_numa_node"] == -1
+        if len(before) >= 2:
+            assert pl["pinned"] and len(pl["cpus"]) == 2 and set(pl["cpus"]) <= before and len(set(pl["cpus"])) == 2
+        assert os.sched_getaffinity(0) == before
     finally:
         lib.coevo_host_rollout_destroy(ctx)
