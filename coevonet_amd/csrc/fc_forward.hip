@@ -16,6 +16,8 @@
 // does the same sequential-k fma chains (tools/mfma4_chain_probe.hip: bit-identical) in far fewer issue slots and LDS
 // reads.  (v_mfma_f32_16x16x4_f32, tools/mfma16_chain_probe.hip, is exact as well but spends 16 tile rows on <= 8.)
 // All fp32 math follows the canonical order in coevo_common.hip.h, so logits equal the oracle's bit for bit.
+#include <cstdlib>
+
 #include "coevo_common.hip.h"
 
 namespace coevo {
@@ -473,6 +475,7 @@ struct FcSmemC {
     union {
         float par[13 * H1];                  // W1t [D][512], fc1.bias, ln1.weight, ln1.bias: contiguous in the slab
         float h1q[128][RP][4];               // A operands of fc2 (written once every wave is done with `par`)
+        float h1r[R][H1];                    // ... row-major for the vector-ALU fc2 of the small-launch kernel (FC2_DPP)
         struct { float h2[R][260]; float w3s[NACT][260]; } tail;   // after the stream
     };
     float xs0[4 * NG][COEVO_OBS_STRIDE];     // observations, rows padded to whole groups (zeros)
@@ -480,7 +483,47 @@ struct FcSmemC {
     float logit[R][COEVO_LOGIT_STRIDE];
 };
 
-template <int R, int MODE>
+// fc2 of the per-individual body, two forms with the same bits (each output is the sequential-k fmaf chain from its bias):
+//   FC2_MFMA  v_mfma_f32_4x4x1, rows in groups of four.  The form of the full launch, where several workgroups share a SIMD: a
+//             dependent 4x4x1 issues only every 40-56 cycles (tools/mfma_rate_probe.hip chain: one accumulator 40, two 2 x 28),
+//             which other workgroups' waves fill.
+//   FC2_DPP   v_fmac_f32 with the activation as a DPP row_newbcast source: one VGPR holds 16 consecutive activations of a row
+//             (lane % 16 = k), `row_newbcast:j` hands lane j's value to every lane of its 16-lane row inside the fmac - no
+//             matrix instruction, no LDS read per k, R independent chains per lane.  The form of a SMALL launch (a rank of a
+//             sharded population: fewer workgroups than CUs), where a workgroup has its SIMDs to itself and the two 4x4x1
+//             chains of a wave leave the matrix pipe idle 70 % of the time: 512 k x 56 cycles = 12.1 us of a 19 us workgroup
+//             (tools/merged_wg_times.py, COEVO_PROBE_SHARD=8), against 512 x R x 6.3 cycles = 6.8 us (tools/fmac_dpp_probe.hip).
+//             Its weight stream uses PLAIN loads: a small launch's nets (<= 256 x 0.56 MB) are re-read every env-cycle out of
+//             the 256 MiB Infinity Cache, whose shorter latency is bandwidth to a wave with ~16 loads in flight (a rank of 8:
+//             16.4 against 18.7 us per launch with nt loads; the full population, 336 MB, streams from HBM and wants nt).
+constexpr int FC2_MFMA = 0, FC2_DPP = 1;
+
+#ifndef COEVO_SMALL_U
+#define COEVO_SMALL_U 16   // 16-byte pieces per lane and buffer in the small-launch body (two buffers; <= 256 registers)
+#endif
+
+template <int J>
+__device__ __forceinline__ void fmac_bcast(float &acc, float xv, float w)
+{
+    // acc = fmaf(xv[lane j of this lane's 16-lane row], w, acc): one rounding, like __builtin_fmaf
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(xv), "v"(w), "n"(J));
+}
+
+// four k-quads (16 consecutive k) of every row's chain: xv[r] holds activations k0 .. k0 + 15 of row r (lane % 16 = k - k0)
+template <int R>
+__device__ __forceinline__ void fmac_block16(float (&acc)[R], const float (&xv)[R], const float4 &p0, const float4 &p1,
+                                             const float4 &p2, const float4 &p3)
+{
+#define COEVO_FMAC_K(J, W)                                   \
+    _Pragma("unroll") for (int r = 0; r < R; ++r) fmac_bcast<J>(acc[r], xv[r], W);
+    COEVO_FMAC_K(0, p0.x) COEVO_FMAC_K(1, p0.y) COEVO_FMAC_K(2, p0.z) COEVO_FMAC_K(3, p0.w)
+    COEVO_FMAC_K(4, p1.x) COEVO_FMAC_K(5, p1.y) COEVO_FMAC_K(6, p1.z) COEVO_FMAC_K(7, p1.w)
+    COEVO_FMAC_K(8, p2.x) COEVO_FMAC_K(9, p2.y) COEVO_FMAC_K(10, p2.z) COEVO_FMAC_K(11, p2.w)
+    COEVO_FMAC_K(12, p3.x) COEVO_FMAC_K(13, p3.y) COEVO_FMAC_K(14, p3.z) COEVO_FMAC_K(15, p3.w)
+#undef COEVO_FMAC_K
+}
+
+template <int R, int MODE, int FC2 = FC2_MFMA>
 __device__ __forceinline__ void fc_policy_body_c(const FcArgs &a, FcSmemC<R> &sm, const coevo_fc_task *tasks, int first,
                                                  int n_tasks)
 {
@@ -513,6 +556,10 @@ __device__ __forceinline__ void fc_policy_body_c(const FcArgs &a, FcSmemC<R> &sm
     }
     const float p_b2 = b2p[t], p_g2 = b2p[H2 + t], p_be2 = b2p[2 * H2 + t];
     const float p_b3 = (w == 0 && l < R * NACT) ? net[fc_off_b3(D) + l % NACT] : 0.0f;
+    constexpr int US = COEVO_SMALL_U;
+    static_assert(US % 4 == 0 && 128 % (2 * US) == 0, "buffers of whole 16-k blocks, consumed in pairs");
+    const float4 *wps = reinterpret_cast<const float4 *>(net + fc_off_w2(D)) + (size_t)w * 128 * 64 + l;
+    float4 sbufA[FC2 == FC2_DPP ? US : 1], sbufB[FC2 == FC2_DPP ? US : 1];
 
     // ---- env step + observation: one lane per row (wave 0) ----------------------------------------------------
     if (w == 0 && l < 4 * NG) {
@@ -540,6 +587,16 @@ __device__ __forceinline__ void fc_policy_body_c(const FcArgs &a, FcSmemC<R> &sm
     COEVO_WSTAMP(1);
     COEVO_CSTAMP(10);
     COEVO_STAMP(1);
+    // FC2_DPP: the first two buffers of the fc2 stream (a quarter of the net at U = 16) are requested NOW - fc1 and
+    // LayerNorm(512) take ~2 us in which nothing else is in flight; the barriers below do not drain them.  (Requested before
+    // the entry barrier they delayed it by 1.7 us: that barrier's vmcnt(0) covers the LDS-DMA and, in order, everything else,
+    // and wave 0's game-state reads queued behind 32 KiB of stream.)
+    if constexpr (FC2 == FC2_DPP) {
+#pragma unroll
+        for (int uu = 0; uu < US; ++uu) sbufA[uu] = wps[(size_t)uu * 64];
+#pragma unroll
+        for (int uu = 0; uu < US; ++uu) sbufB[uu] = wps[(size_t)(US + uu) * 64];
+    }
 
     // ---- fc1 on the matrix cores, like fc2: wave w owns features 64 w + l (block w) and 256 + 64 w + l (block 4 + w);
     //      sequential-k chains from the bias, one k per v_mfma_f32_4x4x1 (rows in groups of four) ---------------------
@@ -622,8 +679,13 @@ __device__ __forceinline__ void fc_policy_body_c(const FcArgs &a, FcSmemC<R> &sm
             const float y0 = __builtin_fmaf(v[2 * r] * rstd, p_g1a, p_be1a);
             const float y1 = __builtin_fmaf(v[2 * r + 1] * rstd, p_g1b, p_be1b);
             if (r < nrows) bad = bad || bad_post_relu(y0) || bad_post_relu(y1);
-            sm.h1q[t >> 2][r][t & 3] = relu_keep_nan(y0);
-            sm.h1q[(t + 256) >> 2][r][t & 3] = relu_keep_nan(y1);
+            if constexpr (FC2 == FC2_DPP) {
+                sm.h1r[r][t] = relu_keep_nan(y0);
+                sm.h1r[r][t + 256] = relu_keep_nan(y1);
+            } else {
+                sm.h1q[t >> 2][r][t & 3] = relu_keep_nan(y0);
+                sm.h1q[(t + 256) >> 2][r][t & 3] = relu_keep_nan(y1);
+            }
         }
         if (bad) st |= COEVO_ST_BAD_FC1;
     }
@@ -635,6 +697,8 @@ __device__ __forceinline__ void fc_policy_body_c(const FcArgs &a, FcSmemC<R> &sm
 
     // ---- fc2 on the matrix cores, as in fc_policy_body; the ping-pong loop carries its own tail ------------------
     f32x4_acc acc[NG];
+    float u[R];
+    if constexpr (FC2 == FC2_MFMA) {
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -675,13 +739,41 @@ __device__ __forceinline__ void fc_policy_body_c(const FcArgs &a, FcSmemC<R> &sm
             consume(bufB, kq + U);
         }
     }
+#pragma unroll
+    for (int r = 0; r < R; ++r) u[r] = acc[r >> 2][r & 3];
+    } else {
+        // ---- fc2 on the vector ALU (FC2_DPP, see above): lane = output column 64 w + l, R chains per lane; per 16 k one
+        //      ds_read_b32 per row (16 consecutive activations, the same in all four 16-lane rows) and 16 R fmacs ----------
+#pragma unroll
+        for (int r = 0; r < R; ++r) u[r] = p_b2;
+        const float *xrow = &sm.h1r[0][l & 15];
+        auto issue_s = [&](float4 (&buf)[FC2 == FC2_DPP ? US : 1], int kq) {
+#pragma unroll
+            for (int uu = 0; uu < US; ++uu) buf[uu] = wps[(size_t)(kq + uu) * 64];   // plain, not nt: see FC2_DPP
+        };
+        auto consume_s = [&](const float4 (&buf)[FC2 == FC2_DPP ? US : 1], int kq) {
+#pragma unroll
+            for (int b = 0; b < US / 4; ++b) {
+                float xv[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) xv[r] = xrow[r * H1 + 4 * (kq + 4 * b)];
+                fmac_block16<R>(u, xv, buf[4 * b], buf[4 * b + 1], buf[4 * b + 2], buf[4 * b + 3]);
+            }
+        };
+#pragma nounroll
+        for (int kq = 0; kq < 128; kq += 2 * US) {
+            consume_s(sbufA, kq);
+            if (kq + 2 * US < 128) issue_s(sbufA, kq + 2 * US);   // wave-uniform
+            __builtin_amdgcn_sched_barrier(0);
+            consume_s(sbufB, kq + US);
+            if (kq + 3 * US < 128) issue_s(sbufB, kq + 3 * US);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
     COEVO_STAMP(3);
     COEVO_WSTAMP(8);
     COEVO_CSTAMP(12);
     // ---- LayerNorm(256) + ReLU: canonical block b = wave b; R block sums per wave by one packed butterfly ---------------
-    float u[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) u[r] = acc[r >> 2][r & 3];
     {
         const float s = packed_totals<R>(u, l);
         if (l < R) sm.red[w][l] = s;   // (red / red2 live outside the union: no wave still needs the old contents)
@@ -724,7 +816,10 @@ __device__ __forceinline__ void fc_policy_body_c(const FcArgs &a, FcSmemC<R> &sm
             float y = p_b3;
             const float4 *wr = reinterpret_cast<const float4 *>(&sm.tail.w3s[o][0]);
             const float4 *xr = reinterpret_cast<const float4 *>(&sm.tail.h2[r][0]);
-#pragma unroll 4
+            // (the small-launch form has registers to spare: 16 k-quads of both operands requested at a time, so that the
+            // 256-step chain waits for LDS four times instead of sixteen)
+            constexpr int OUT_UNROLL = FC2 == FC2_DPP ? 16 : 4;
+#pragma unroll OUT_UNROLL
             for (int k = 0; k < H2 / 4; ++k) {
                 const float4 wv = wr[k], xv = xr[k];
                 y = __builtin_fmaf(wv.x, xv.x, y);
@@ -1438,6 +1533,21 @@ __global__ __launch_bounds__(256, 4) void fc_cycle16_kernel(FcArgs a)
     stamp_end(a.stamps);
 }
 
+// The SMALL merged cycle launch: every task (shared-opponent chunk or per-individual net) has <= 8 rows and runs the
+// per-individual body with its fc2 on the vector ALU (FC2_DPP).  For launches that leave CUs idle - one rank of a population
+// sharded over 4 / 8 GPUs (genetic_algorithm.py:125-217 split by index: 25 or 50 individuals per role), a cohort of the
+// host-stepped env - where a workgroup's life, not bytes, is the launch's duration.  <= 256 registers: two workgroups per CU.
+template <int R, int MODE = MODE_FUSED>
+__global__ __launch_bounds__(256, 2) void fc_cycle_small_kernel(FcArgs a)
+{
+    __shared__ __attribute__((aligned(16))) FcSmemC<R> sm;
+    stamp_begin(a.stamps);
+    const bool heavy = (int)blockIdx.x < a.n_heavy;   // workgroup-uniform
+    fc_policy_body_c<R, MODE, FC2_DPP>(a, sm, heavy ? a.tasks : a.light_tasks, heavy ? (int)blockIdx.x : (int)blockIdx.x - a.n_heavy,
+                                       heavy ? a.n_heavy : a.n_light);
+    stamp_end(a.stamps);
+}
+
 // One launch = one env-cycle of one cohort of games (fused env step): the shared-opponent tasks first (lowest block
 // indices: they are dispatched first and are the longer workgroups), then the per-individual tasks.  Both kinds of
 // workgroup get the MFMA path's footprint (<= 256 registers, ~73 KiB LDS: two workgroups per CU), so a launch of a
@@ -1547,6 +1657,33 @@ extern "C" int coevo_mpe_policy_cycle_fused(const float *slab, const coevo_fc_ta
     return coevo::launch_fc<coevo::MODE_FUSED>(a, n_tasks, max_rows_per_task, (hipStream_t)stream);
 }
 
+// Which kernel a merged cycle launch of this shape runs (the launcher's own decision, exposed for tests and bench records)
+extern "C" int coevo_mpe_cycle_kernel_form(int n_heavy, int n_light, int heavy_max_rows, int light_max_rows,
+                                           int concurrent_launches)
+{
+    if (n_heavy <= 0 || n_light <= 0 || light_max_rows < 1 || light_max_rows > 8) return COEVO_ERR_ARG;
+    // workgroup slots of the 32-row kernel: two per CU (<= 256 registers, ~73 KiB LDS)
+    static int slots = 0;
+    if (slots == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            return COEVO_ERR_HIP;
+        slots = 2 * cus;
+    }
+    const int conc = concurrent_launches > 1 ? concurrent_launches : 1;
+    const int wgs = (n_heavy + n_light) * conc;
+    // every task of <= 8 rows and no more workgroups in flight than CUs: the small-launch kernel (COEVO_SMALL_KERNEL=0: A/B).
+    // (Two per CU share their SIMDs' vector ALU: a rank of 4 - 360 workgroups of <= 8 rows - 27.6-30.5 us per launch against
+    // 21.8 for the lean kernel's 270 with 16-row matrix-core tiles; a rank of 8 - 231 - 16.4 against 21.0.)
+    static const bool small_ok = !(getenv("COEVO_SMALL_KERNEL") && getenv("COEVO_SMALL_KERNEL")[0] == '0');
+    if (small_ok && heavy_max_rows >= 1 && heavy_max_rows <= 8 && 2 * wgs <= slots) return COEVO_CYCLE_FORM_SMALL;
+    if (heavy_max_rows >= 1 && heavy_max_rows <= 16 && wgs <= 2 * slots) return COEVO_CYCLE_FORM_LEAN16;
+    // If one net per streaming workgroup does not fit the slots in a single round, pair the nets: the second round would
+    // otherwise wait for the slots of the (long) shared-opponent workgroups.
+    return wgs > slots ? COEVO_CYCLE_FORM_TILE32_PAIRED : COEVO_CYCLE_FORM_TILE32;
+}
+
 extern "C" int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_task *heavy_tasks, int n_heavy,
                                              const coevo_fc_task *light_tasks, int n_light, int light_max_rows,
                                              const double *state_prev, double *state_next, int n_games,
@@ -1564,22 +1701,22 @@ extern "C" int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_t
     coevo::FcArgs a{slab, heavy_tasks, nullptr, state_prev, row_game, row_slot, n_games, nullptr, nullptr, status,
                     reinterpret_cast<unsigned long long *>(stamps), state_next, act_prev, act_cur, game_limit, cycle,
                     pos_first, light_tasks, n_heavy, n_light};
-    // Workgroup slots of this kernel: two per CU (<= 256 registers, ~73 KiB LDS).  If one net per streaming workgroup
-    // does not fit them in a single round, pair the nets: the second round would otherwise wait for the slots of
-    // the (long) shared-opponent workgroups.
-    static int slots = 0;
-    if (slots == 0) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            return COEVO_ERR_HIP;
-        slots = 2 * cus;
-    }
-    const int conc = concurrent_launches > 1 ? concurrent_launches : 1;
+    const int form = coevo_mpe_cycle_kernel_form(n_heavy, n_light, heavy_max_rows, light_max_rows, concurrent_launches);
+    if (form < 0) return form;
     hipStream_t s = (hipStream_t)stream;
+    if (form == COEVO_CYCLE_FORM_SMALL) {
+        const int rows = heavy_max_rows > light_max_rows ? heavy_max_rows : light_max_rows;
+        const dim3 grid_s(n_heavy + n_light), block_s(256);
+        if (rows <= 1) hipLaunchKernelGGL((coevo::fc_cycle_small_kernel<1>), grid_s, block_s, 0, s, a);
+        else if (rows <= 2) hipLaunchKernelGGL((coevo::fc_cycle_small_kernel<2>), grid_s, block_s, 0, s, a);
+        else if (rows <= 5) hipLaunchKernelGGL((coevo::fc_cycle_small_kernel<5>), grid_s, block_s, 0, s, a);
+        else hipLaunchKernelGGL((coevo::fc_cycle_small_kernel<8>), grid_s, block_s, 0, s, a);
+        COEVO_HIP_CHECK(hipGetLastError());
+        return COEVO_OK;
+    }
     // (when not everything fits - Co-ES with 3000 nets - the 32-row tiles with two nets per streaming workgroup are
     // ahead: 109 vs 106 generations/s)
-    if (heavy_max_rows >= 1 && heavy_max_rows <= 16 && (n_heavy + n_light) * conc <= 2 * slots) {
+    if (form == COEVO_CYCLE_FORM_LEAN16) {
         // the lean kernel: four workgroups per CU hold everything at one net per streaming workgroup
         const dim3 grid16(n_heavy + n_light), block16(256);
         if (light_max_rows <= 1) hipLaunchKernelGGL((coevo::fc_cycle16_kernel<1>), grid16, block16, 0, s, a);
@@ -1589,7 +1726,7 @@ extern "C" int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_t
         COEVO_HIP_CHECK(hipGetLastError());
         return COEVO_OK;
     }
-    const bool pair = (n_heavy + n_light) * conc > slots;
+    const bool pair = form == COEVO_CYCLE_FORM_TILE32_PAIRED;
     const dim3 grid(n_heavy + (pair ? (n_light + 1) / 2 : n_light)), block(256);
 #define COEVO_LAUNCH_CYCLE(RR)                                                                    \
     do {                                                                                          \

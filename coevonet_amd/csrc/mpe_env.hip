@@ -184,8 +184,17 @@ __global__ void mpe_step_kernel(double *st, int n, const int32_t *game_rows, con
 
 // The last cycle's step in the fused scheme: its actions are applied only to close the books (credits of cycle
 // `cycle`), the play_game triples go straight to rewards[n][3]; no state is written.
+// pack (a population-sharded run, coevo_mpe_final_step_pack): the games are laid out [role][local individual][hof game]; the
+// thread that closes the LAST HoF game of an individual (the one that counts, quirk Q2) also writes that individual's record
+// of the fitness all-gather: pack[role][j] = {its play_game triple, the individual's distance to the stale agent}
+struct FinalPack {
+    double *out;            // [n_roles][n_local][4], or NULL
+    const float *dist;      // [n_roles][dist_pitch], this rank's individuals start at dist_first
+    int n_roles, n_local, hof, dist_pitch, dist_first;
+};
+
 __global__ void mpe_final_step_kernel(const double *st, int n, const int32_t *act, int cycle,
-                                      const int32_t *game_limit, int pos_first, double *rewards)
+                                      const int32_t *game_limit, int pos_first, double *rewards, FinalPack pk)
 {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
@@ -208,6 +217,14 @@ __global__ void mpe_final_step_kernel(const double *st, int n, const int32_t *ac
     rewards[3 * (size_t)g + 0] = a_a0;
     rewards[3 * (size_t)g + 1] = a_a1;
     rewards[3 * (size_t)g + 2] = a_adv;
+    if (pk.out && g < pk.n_roles * pk.n_local * pk.hof && g % pk.hof == pk.hof - 1) {
+        const int ij = g / pk.hof, role = ij / pk.n_local, j = ij % pk.n_local;
+        double *o = pk.out + 4 * (size_t)ij;
+        o[0] = a_a0;
+        o[1] = a_a1;
+        o[2] = a_adv;
+        o[3] = (double)pk.dist[(size_t)role * pk.dist_pitch + pk.dist_first + j];
+    }
 }
 
 __global__ void mpe_rewards_kernel(const double *st, int n, double *rewards)
@@ -417,7 +434,26 @@ extern "C" int coevo_mpe_final_step(const double *state, int n_games, const int3
 {
     if (!state || !rewards || n_games <= 0 || (cycle >= 0 && !actions_by_game)) return COEVO_ERR_ARG;
     hipLaunchKernelGGL(coevo::mpe_final_step_kernel, dim3((n_games + 127) / 128), dim3(128), 0, (hipStream_t)stream,
-                       state, n_games, actions_by_game, cycle, game_limit, pos_first, rewards);
+                       state, n_games, actions_by_game, cycle, game_limit, pos_first, rewards, coevo::FinalPack{});
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+// coevo_mpe_final_step + this rank's record of the fitness all-gather in the same launch (genetic_algorithm.py:140-146: only the
+// last HoF game's reward survives, quirk Q2): games [0, n_roles * n_local * hof) are laid out [role][local individual][hof
+// game]; pack[role][j] = {triple of game (role, j, hof - 1), (double)dist[role * dist_pitch + dist_first + j]}.
+extern "C" int coevo_mpe_final_step_pack(const double *state, int n_games, const int32_t *actions_by_game, int cycle,
+                                         const int32_t *game_limit, int pos_first, double *rewards, double *pack,
+                                         const float *dist, int n_roles, int n_local, int hof, int dist_pitch, int dist_first,
+                                         void *stream)
+{
+    if (!state || !rewards || n_games <= 0 || (cycle >= 0 && !actions_by_game)) return COEVO_ERR_ARG;
+    if (!pack || !dist || n_roles < 1 || n_local < 1 || hof < 1 || (int64_t)n_roles * n_local * hof > n_games ||
+        dist_first < 0 || dist_first + n_local > dist_pitch)
+        return COEVO_ERR_ARG;
+    const coevo::FinalPack pk{pack, dist, n_roles, n_local, hof, dist_pitch, dist_first};
+    hipLaunchKernelGGL(coevo::mpe_final_step_kernel, dim3((n_games + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                       state, n_games, actions_by_game, cycle, game_limit, pos_first, rewards, pk);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

@@ -188,6 +188,13 @@ __global__ __launch_bounds__(256) void fc_gather_kernel(const float *src_slab, c
 struct GaPromoteArgs {
     coevo_ga_promote_role role[3];
     int E, hof;
+    // rebuild mode (coevo_ga_promote_rebuild): the new elites are not in `elite` yet - elite[k] is individual order[k] of the
+    // generation just evaluated, i.e. the unchanged best (id 0 = old elite 0) or child c = id - 1 = old elite[c % E] +
+    // sigma * noise(c), regenerated here from the OLD elites in place
+    const float *sigma;          // [3] device: what that generation's children were bred with; NULL: not rebuild mode
+    const int32_t *gen_dev;      // device generation counter g (the children were bred with streams of g - 1), or NULL
+    uint64_t seed;
+    uint32_t stream_hi_prev;     // + role index (+ 4 (g - 1) with gen_dev)
 };
 constexpr int PROMOTE_MAX_E = 8, PROMOTE_MAX_HOF = 16;
 
@@ -222,6 +229,36 @@ __device__ __forceinline__ float4 promote_elites(const float *src, const int32_t
     }
 }
 
+// rebuild mode: every OLD elite piece a new elite needs is loaded on the way down, the new pieces are stored on the way back
+// (each slab position depends only on the old elites' values at the same position: in place, no second elite buffer)
+template <int K>
+__device__ __forceinline__ float4 promote_rebuild(float *elite, const int32_t *order, int64_t stride, int64_t s0, int E, int D,
+                                                  float sigma, uint64_t seed, uint32_t shi)
+{
+    if constexpr (K < PROMOTE_MAX_E) {
+        const int kc = K < E ? K : E - 1;
+        const int id = order[kc];
+        const int c = id > 0 ? id - 1 : 0;
+        const float4 pv = *reinterpret_cast<const float4 *>(elite + (int64_t)(id > 0 ? c % E : 0) * stride + s0);
+        promote_rebuild<K + 1>(elite, order, stride, s0, E, D, sigma, seed, shi);
+        float4 nv = pv;
+        if (id > 0) {
+            const int64_t P = fc_params(D);
+            float z[4];
+            slab_quad_normals(seed, (uint32_t)c, shi, s0, D, P, z);
+            const float in[4] = {pv.x, pv.y, pv.z, pv.w};
+            float out[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) out[i] = (s0 + i >= P) ? in[i] : in[i] + sigma * z[i];   // as fc_rebuild_elites_kernel
+            nv = make_float4(out[0], out[1], out[2], out[3]);
+        }
+        *reinterpret_cast<float4 *>(elite + (int64_t)kc * stride + s0) = nv;
+        return nv;
+    } else {
+        return make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 __global__ __launch_bounds__(256) void ga_promote_kernel(GaPromoteArgs a)
 {
     // (field-wise scalar selects: indexing the by-value argument array dynamically copies it to scratch)
@@ -236,8 +273,15 @@ __global__ __launch_bounds__(256) void ga_promote_kernel(GaPromoteArgs a)
     if (s0 >= stride) return;
     // every source piece is read before the first store that could alias it (a best individual that already sits in
     // pop[0], the in-place HoF shift)
-    const float4 e0 = from_pop ? promote_elites<0>(pop, order, elite, true, stride, s0, a.E)
-                               : *reinterpret_cast<const float4 *>(elite + s0);
+    float4 e0;
+    if (a.sigma && !from_pop) {
+        uint32_t shi = a.stream_hi_prev + y;
+        if (a.gen_dev) shi += 4u * (uint32_t)(*a.gen_dev - 1);
+        e0 = promote_rebuild<0>(elite, order, stride, s0, a.E, D, a.sigma[y], a.seed, shi);
+    } else {
+        e0 = from_pop ? promote_elites<0>(pop, order, elite, true, stride, s0, a.E)
+                      : *reinterpret_cast<const float4 *>(elite + s0);
+    }
     promote_hof_shift<1>(hof, stride, s0, a.hof);
     *reinterpret_cast<float4 *>(hof + (int64_t)(a.hof - 1) * stride + s0) = e0;
     if (to_pop0) *reinterpret_cast<float4 *>(pop + s0) = e0;
@@ -522,11 +566,37 @@ extern "C" int coevo_fc_gather(const float *src_slab, const int32_t *src_idx, fl
     return COEVO_OK;
 }
 
+static int ga_promote_launch(const coevo_ga_promote_role *roles, int n_roles, int E, int hof, const float *sigma,
+                             uint64_t seed, uint32_t stream_hi_prev, const int32_t *gen_dev, void *stream);
+
 extern "C" int coevo_ga_promote(const coevo_ga_promote_role *roles, int n_roles, int E, int hof, void *stream)
+{
+    return ga_promote_launch(roles, n_roles, E, hof, nullptr, 0, 0, nullptr, stream);
+}
+
+// Promotion with the elites REBUILT in the same launch (a population-sharded run: a rank holds only its own individuals, so
+// the new elites - individuals order[k] of the generation just evaluated - are regenerated from last generation's elites and
+// the counter-based noise their children were bred with: genetic_algorithm.py:232-252 without a weight crossing xGMI).
+// Replaces, per role, coevo_fc_gather (elite -> elite_prev) + coevo_fc_rebuild_elites + the coevo_ga_promote that followed:
+// roles with elites_from_pop == 0 rebuild in place from `elite`, roles with elites_from_pop != 0 are promoted as usual.
+// sigma: device [n_roles] floats (what the previous generation's children were bred with); noise stream of role r:
+// stream_hi_prev + r (+ 4 (g - 1) when gen_dev is given).
+extern "C" int coevo_ga_promote_rebuild(const coevo_ga_promote_role *roles, int n_roles, int E, int hof, const float *sigma,
+                                        uint64_t seed, uint32_t stream_hi_prev, const int32_t *gen_dev, void *stream)
+{
+    if (!sigma) return COEVO_ERR_ARG;
+    for (int r = 0; roles && r < n_roles && r < 3; ++r)
+        if (!roles[r].elites_from_pop && !roles[r].order) return COEVO_ERR_ARG;
+    return ga_promote_launch(roles, n_roles, E, hof, sigma, seed, stream_hi_prev, gen_dev, stream);
+}
+
+static int ga_promote_launch(const coevo_ga_promote_role *roles, int n_roles, int E, int hof, const float *sigma,
+                             uint64_t seed, uint32_t stream_hi_prev, const int32_t *gen_dev, void *stream)
 {
     if (!roles || n_roles < 1 || n_roles > 3 || E < 1 || E > PROMOTE_MAX_E || hof < 1 || hof > PROMOTE_MAX_HOF)
         return COEVO_ERR_ARG;
     GaPromoteArgs a{};
+    a.sigma = sigma; a.seed = seed; a.stream_hi_prev = stream_hi_prev; a.gen_dev = gen_dev;
     int64_t max_stride = 0;
     for (int r = 0; r < n_roles; ++r) {
         const coevo_ga_promote_role &R = roles[r];

@@ -56,10 +56,12 @@ __global__ __launch_bounds__(64) void dist_finalize_kernel(const double *partial
 
 static_assert(sizeof(coevo_fc_finalize_job) == 40, "layout mirrored by coevonet_amd/lib.py FinalizeJob");
 struct FinalizeJobs { coevo_fc_finalize_job j[COEVO_MAX_JOBS]; };
-__global__ __launch_bounds__(64) void dist_finalize_multi_kernel(FinalizeJobs jobs)
+__global__ __launch_bounds__(64) void dist_finalize_multi_kernel(FinalizeJobs jobs, int32_t *tick)
 {
     const coevo_fc_finalize_job &jb = jobs.j[blockIdx.y];
     const int c = blockIdx.x, l = threadIdx.x;
+    // (the generation counter's tick rides in the generation's last launch: nothing in this launch reads it)
+    if (tick && blockIdx.x == 0 && blockIdx.y == 0 && l == 0) *tick += 1;
     if (c >= jb.n) return;
     double v = 0.0;
     for (int b = l; b < jb.n_blocks; b += 64) v += jb.dist_partial[(size_t)c * jb.n_blocks + b];
@@ -133,6 +135,11 @@ __global__ __launch_bounds__(256) void rank_desc_kernel(const float *fitness, in
 struct GaSelectArgs {
     coevo_ga_select_role role[3];
     int pop, games_per_individual, hof;
+    // gathered form (coevo_ga_select_gathered): the all-gathered buffer [world][n_roles][n_local][4] fp64 = per rank, role and
+    // local individual {reward triple of its last HoF game, distance to the stale agent}; individual i lives on rank
+    // i / n_local.  NULL: distances / rewards through the role's own pointers.
+    const double *gathered;
+    int n_local, n_roles;
 };
 
 __global__ __launch_bounds__(256) void ga_select_kernel(GaSelectArgs a)
@@ -146,13 +153,18 @@ __global__ __launch_bounds__(256) void ga_select_kernel(GaSelectArgs a)
     const coevo_ga_select_role R = a.role[blockIdx.x];
     const int n = a.pop;
     const bool first_slice = blockIdx.y == 0;
+    // where individual i's record sits in the gathered buffer (its distance was an fp32 value: the cast back is exact)
+    auto rec = [&](int i) {
+        return a.gathered + 4 * ((size_t)((i / a.n_local) * a.n_roles + (int)blockIdx.x) * a.n_local + i % a.n_local);
+    };
+    auto dist_of = [&](int i) { return a.gathered ? (float)rec(i)[3] : R.dist[i]; };
     // sharing score (sharing_score_kernel)
     double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) s += (double)R.dist[i];
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)dist_of(i);
     const float sigma = (float)(block_sum_f64(s, scratch) / (double)n);
     double sc = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) {
-        const float sh = 1.0f - R.dist[i] / sigma;
+        const float sh = 1.0f - dist_of(i) / sigma;
         if (sh > 0.0f) sc += (double)sh;
     }
     const double tot = block_sum_f64(sc, scratch);
@@ -164,7 +176,7 @@ __global__ __launch_bounds__(256) void ga_select_kernel(GaSelectArgs a)
     // fitness (ga_fitness_kernel)
     const int gpi = a.games_per_individual;
     for (int i = threadIdx.x; i < n; i += 256) {
-        const double last = R.rewards[3 * (size_t)(R.game_first + i * gpi + gpi - 1) + R.slot];
+        const double last = a.gathered ? rec(i)[R.slot] : R.rewards[3 * (size_t)(R.game_first + i * gpi + gpi - 1) + R.slot];
         const float total = (float)(last / (double)a.hof);
         const float fit = total / (1.0f + div_s);
         f[i] = fit;
@@ -178,7 +190,7 @@ __global__ __launch_bounds__(256) void ga_select_kernel(GaSelectArgs a)
         int rank = 0;
         for (int j = 0; j < n; ++j) rank += rank_less(f[j], j, fi, i) ? 1 : 0;
         R.order[n - 1 - rank] = i;
-        if (rank == n - 1 && R.best_dist) *R.best_dist = R.dist[i];
+        if (rank == n - 1 && R.best_dist) *R.best_dist = dist_of(i);
     }
 }
 
@@ -315,7 +327,21 @@ extern "C" int coevo_fc_distance_finalize(const double *partial, int n_blocks, i
     return COEVO_OK;
 }
 
+static int finalize_multi_launch(const coevo_fc_finalize_job *jobs, int n_jobs, int32_t *tick, void *stream);
+
 extern "C" int coevo_fc_distance_finalize_multi(const coevo_fc_finalize_job *jobs, int n_jobs, void *stream)
+{
+    return finalize_multi_launch(jobs, n_jobs, nullptr, stream);
+}
+
+// ... with the generation counter's tick (coevo_counter_add(counter, 1)) in the same launch: the last launch of a generation
+extern "C" int coevo_fc_distance_finalize_multi_tick(const coevo_fc_finalize_job *jobs, int n_jobs, int32_t *counter, void *stream)
+{
+    if (!counter) return COEVO_ERR_ARG;
+    return finalize_multi_launch(jobs, n_jobs, counter, stream);
+}
+
+static int finalize_multi_launch(const coevo_fc_finalize_job *jobs, int n_jobs, int32_t *tick, void *stream)
 {
     if (!jobs || n_jobs < 1 || n_jobs > COEVO_MAX_JOBS) return COEVO_ERR_ARG;
     FinalizeJobs fj{};
@@ -326,8 +352,8 @@ extern "C" int coevo_fc_distance_finalize_multi(const coevo_fc_finalize_job *job
         fj.j[i] = j;
         nmax = j.n > nmax ? j.n : nmax;
     }
-    if (nmax == 0) return COEVO_OK;
-    hipLaunchKernelGGL(dist_finalize_multi_kernel, dim3(nmax, n_jobs), dim3(64), 0, (hipStream_t)stream, fj);
+    if (nmax == 0 && !tick) return COEVO_OK;
+    hipLaunchKernelGGL(dist_finalize_multi_kernel, dim3(nmax > 0 ? nmax : 1, n_jobs), dim3(64), 0, (hipStream_t)stream, fj, tick);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }
@@ -368,19 +394,40 @@ extern "C" int coevo_rank_desc(const float *fitness, int n, int32_t *order, void
     return COEVO_OK;
 }
 
+static int ga_select_launch(const coevo_ga_select_role *roles, int n_roles, int pop, int games_per_individual, int hof,
+                            const double *gathered, int n_local, void *stream);
+
 extern "C" int coevo_ga_select(const coevo_ga_select_role *roles, int n_roles, int pop, int games_per_individual,
                                int hof, void *stream)
+{
+    return ga_select_launch(roles, n_roles, pop, games_per_individual, hof, nullptr, 0, stream);
+}
+
+// The selection of a population-sharded run straight off the all-gathered buffer: gathered[rank][role][j][0..2] = the
+// play_game triple of the last HoF game of rank `rank`'s j-th individual (quirk Q2), [3] = its distance to the stale agent
+// (quirk Q3); individual i = rank i / n_local, j = i % n_local (pop = world * n_local).  The roles' `dist` / `rewards`
+// pointers are not read.  Same arithmetic as coevo_ga_select (genetic_algorithm.py:140-146, 223-225).
+extern "C" int coevo_ga_select_gathered(const coevo_ga_select_role *roles, int n_roles, int pop, int hof,
+                                        const double *gathered, int n_local, void *stream)
+{
+    if (!gathered || n_local <= 0 || pop % n_local) return COEVO_ERR_ARG;
+    return ga_select_launch(roles, n_roles, pop, 1, hof, gathered, n_local, stream);
+}
+
+static int ga_select_launch(const coevo_ga_select_role *roles, int n_roles, int pop, int games_per_individual, int hof,
+                            const double *gathered, int n_local, void *stream)
 {
     if (!roles || n_roles < 1 || n_roles > 3 || pop <= 0 || pop > 4096 || hof <= 0 || games_per_individual <= 0)
         return COEVO_ERR_ARG;
     coevo::GaSelectArgs a{};
     for (int r = 0; r < n_roles; ++r) {
         const coevo_ga_select_role &R = roles[r];
-        if (!R.dist || !R.rewards || !R.diversity || !R.fitness || !R.order || R.slot < 0 || R.slot > 2 ||
+        if ((!gathered && (!R.dist || !R.rewards)) || !R.diversity || !R.fitness || !R.order || R.slot < 0 || R.slot > 2 ||
             R.game_first < 0)
             return COEVO_ERR_ARG;
         a.role[r] = R;
     }
+    a.gathered = gathered; a.n_local = n_local; a.n_roles = n_roles;
     a.pop = pop; a.games_per_individual = games_per_individual; a.hof = hof;
     hipLaunchKernelGGL(coevo::ga_select_kernel, dim3(n_roles, (pop + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     COEVO_HIP_CHECK(hipGetLastError());

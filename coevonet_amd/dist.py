@@ -64,6 +64,11 @@ class ShardRehearsal:
 
     gather_ga = gather_ga2 = _tile
 
+    def gather_ga_packed(self, eng):
+        """the fused exchange (GAEngine._packed_exchange): every rank's record := this rank's, in ONE copy launch (what the
+        collective is on hardware: one kernel)"""
+        eng.pack_all.copy_(eng.pack_local.unsqueeze(0).expand_as(eng.pack_all))
+
     def start_gather_timing(self):
         pass
 
@@ -126,6 +131,12 @@ class DistContext:
         """the same exchange for the two-role DeepQN engine (dqn_population.DQNGAEngine)"""
         self._bracket(self._gather_ga2, eng)
 
+    def gather_ga_packed(self, eng):
+        """the fused form (round 5): eng.pack_local [role][n_local][4] fp64 - written by the rollout's closing launch,
+        coevo_mpe_final_step_pack - all-gathered rank-major into eng.pack_all [world][role][n_local][4], which
+        coevo_ga_select_gathered reads as it is: ONE collective, no pack / unpack launch around it"""
+        self._bracket(self._gather_ga_packed, eng)
+
     def gather_es(self, eng, what):
         """Co-ES exchanges (evolutionary_strategy.ESEngine.update_device): "stats" = per role and individual the reward
         in the role's slot + the distance to the base net (fp64 pairs, 16 bytes per individual and role); "partials" =
@@ -140,6 +151,15 @@ class DistContext:
         full = allgather_shards(local, self.world)
         eng.last_reward.copy_(full[:, :, :3])
         eng.dist_all.copy_(full[:, :, 3])               # back to fp32 (exact: they were fp32 values)
+
+    def _gather_ga_packed(self, eng):
+        src, out = eng.pack_local.view(-1), eng.pack_all.view(-1)
+        if dist.get_backend() == "gloo" and src.is_cuda:   # (a rehearsal of several ranks on one GPU: through the host)
+            host_out = torch.empty(out.numel(), dtype=out.dtype)
+            dist.all_gather_into_tensor(host_out, src.cpu())
+            out.copy_(host_out)
+            return
+        dist.all_gather_into_tensor(out, src)
 
     def _gather_ga2(self, eng):
         lo, hi = eng.lo, eng.hi

@@ -89,6 +89,19 @@ def adapt_mutation_power(args, gen, hist):
         args.mutation_power_adversary = max(args.mutation_power_adversary * 0.95, args.min_mutation_power)
 
 
+def small_shard_rows(n_local, hof, cus, pop):
+    """Rows per shared-opponent task of a rank that holds n_local individuals per role.  A launch of one env-cycle is 3 n_local
+    per-individual workgroups + 6 hof ceil(n_local / rows) shared-opponent ones (3 phases x hof games x 2 opponent seats, each
+    opponent against all of the rank's individuals).  While they fit ONE per CU (a rank of pop 200 over 8 GPUs: 75 + 150) the
+    launch lasts as long as one workgroup, and tasks are cut to hof rows (25 = 5 x 5: no padding) for the small-launch kernel
+    (<= 8 rows, vector-ALU fc2: csrc/fc_forward.hip fc_cycle_small_kernel); else the 16-row tiles of the lean kernel."""
+    if n_local >= pop or not 1 <= hof <= 8:   # the whole population on this GPU: the full launch
+        return 16
+    if 3 * n_local + 6 * hof * -(-n_local // hof) <= cus:
+        return hof
+    return 16
+
+
 def cohort_partition(n_local, K):
     """The ONE partition of a rank's individuals into K contiguous cohorts that the rollout plan, the breeding and the
     resets all use: -> (bounds [K+1], cohort of each individual [n_local])."""
@@ -109,13 +122,14 @@ class GAEngine:
 
     def __init__(self, pop, hof, elites, limit_train=None, limit_eval=None, max_cycles=25, device="cuda",
                  env_seed=ENV_SEED, rng="device_philox", philox_seed=0, env="device", first_ordinal=1,
-                 shard=(0, 1), gather=None, timing_pairs=4096, cohorts=1):
+                 shard=(0, 1), gather=None, timing_pairs=4096, cohorts=1, gather_packed=None):
         assert 1 <= elites <= pop and hof >= 1
         self.pop, self.hof, self.E = pop, hof, elites
         self.rng_mode, self.philox_seed, self.env_mode = rng, int(philox_seed), env
         self.device = device
         self.rank, self.world = shard
         self.gather = gather
+        self.gather_packed = gather_packed   # (eng) -> eng.pack_all from every rank's eng.pack_local: ONE collective
         if self.world > 1 and pop % self.world:
             # the fitness all-gather (dist.allgather_shards) moves equal shards: unequal ones would hang RCCL
             raise ValueError(f"population {pop} is not divisible by the number of ranks {self.world}")
@@ -167,7 +181,10 @@ class GAEngine:
         # 16-row shared-opponent tasks select the lean merged cycle kernel (four workgroups per CU); COEVO_HEAVY_ROWS=32
         # keeps the 32-row tiles for A/B runs
         # (host-stepped env: the same 16-row tasks, for the observation-fed merged launch coevo_fc_forward_merged)
-        heavy_rows = int(os.environ.get("COEVO_HEAVY_ROWS", "16"))
+        heavy_rows = int(os.environ.get("COEVO_HEAVY_ROWS", "0"))
+        if heavy_rows <= 0:
+            cus = torch.cuda.get_device_properties(device).multi_processor_count if (env == "device" and str(device) != "cpu") else 0
+            heavy_rows = small_shard_rows(self.n_local, hof, cus, pop) if (cus and cohorts <= 1) else 16
         # cohorts = contiguous ranges of this rank's individuals (so that offspring can be bred cohort by cohort and a
         # cohort's chain can start while the next cohort is still being bred); the evaluation games go with the last
         # (env on the host cores: the cohorts alternate between the cores and the GPU - COEVO_HOST_COHORTS, default 4: the
@@ -206,6 +223,10 @@ class GAEngine:
         self.sigma = {r: torch.zeros(1, **f32) for r in ROLES}
         self.sigma_prev = {r: torch.zeros(1, **f32) for r in ROLES}
         self.last_reward = torch.zeros(3, pop, 3, dtype=torch.float64, device=device)  # [role][i][triple]
+        # the fused form of the exchange: this rank's record [role][j] = {triple of the last HoF game, distance}, written by
+        # the rollout's closing launch, and the all-gathered [rank][role][j][4] buffer the selection reads as it is
+        self.pack_local = torch.zeros(3, self.n_local, 4, dtype=torch.float64, device=device)
+        self.pack_all = torch.zeros(self.world, 3, self.n_local, 4, dtype=torch.float64, device=device)
         self.parent_idx = torch.tensor([c % elites for c in range(max(pop - 1, 1))], dtype=torch.int32, device=device)
         self.hof_shift_idx = torch.arange(1, max(hof, 2), dtype=torch.int32, device=device)
         self.iota = torch.arange(max(hof, elites, 2), dtype=torch.int32, device=device)
@@ -530,10 +551,12 @@ class GAEngine:
     def _cohort_individuals(self, k):
         return self.lo + int(self.cohort_bounds[k]), self.lo + int(self.cohort_bounds[k + 1])
 
-    def _breed_cohort(self, k, noise_gen):
+    def _breed_cohort(self, k, noise_gen, gen_dev=None, tick=False):
         """children of the individuals of cohort k (child c = individual c + 1; individual 0 is the unchanged best),
         bred from the elites of generation `noise_gen` with that generation's noise streams: the three roles in ONE
-        perturb launch and one distance reduction (as six launches they queued in front of the cohort's chain)"""
+        perturb launch and one distance reduction (as six launches they queued in front of the cohort's chain).
+        gen_dev: the generation comes from the device counter instead (replayable graph); tick: the counter's increment
+        rides in the distance reduction (the generation's last launch)"""
         lo_k, hi_k = self._cohort_individuals(k)
         c_lo, c_hi = max(lo_k, 1) - 1, hi_k - 1
         if c_hi > c_lo:
@@ -544,15 +567,21 @@ class GAEngine:
                 part = self.dist_partial[r].data_ptr() + 8 * c_lo * self.pblocks[r]
                 pj[ri] = L.PerturbJob(self._ptr(r, "elite"), self.parent_idx.data_ptr() + 4 * c_lo, self._ptr(r, "pop"),
                                       self.sigma32.data_ptr() + 4 * ri, self._ptr(r, "stale"), part, 1 + c_lo,
-                                      c_hi - c_lo, ROLE_D[r], c_lo, noise_gen * 4 + ri, 0)
+                                      c_hi - c_lo, ROLE_D[r], c_lo, ri if gen_dev is not None else noise_gen * 4 + ri, 0)
                 fj[ri] = L.FinalizeJob(part, self.dist[r].data_ptr(),
                                        self.best_dist[r].data_ptr() if c_lo == 0 else None, self.pblocks[r],
                                        c_hi - c_lo, 1 + c_lo, 0)
-            L.call("coevo_fc_perturb_dist_multi", ct.cast(pj, ct.c_void_p), 3, self.philox_seed, 0, None)
-            L.call("coevo_fc_distance_finalize_multi", ct.cast(fj, ct.c_void_p), 3)
-        elif lo_k == 0:
+            L.call("coevo_fc_perturb_dist_multi", ct.cast(pj, ct.c_void_p), 3, self.philox_seed, 0, gen_dev)
+            if tick:
+                L.call("coevo_fc_distance_finalize_multi_tick", ct.cast(fj, ct.c_void_p), 3, L._p(self.gen_dev))
+            else:
+                L.call("coevo_fc_distance_finalize_multi", ct.cast(fj, ct.c_void_p), 3)
+            return
+        if lo_k == 0:
             for r in ROLES:
                 self.dist[r][0:1].copy_(self.best_dist[r])
+        if tick:
+            L.call("coevo_counter_add", L._p(self.gen_dev), 1)
 
     def _reset_cohort(self, k, gen):
         lo_k, hi_k = self._cohort_individuals(k)
@@ -627,7 +656,16 @@ class GAEngine:
         self._breeding_pending = False
         for ev in self._cohort_done[1:]:
             main.wait_event(ev)
-        ro.enqueue_final_step(self.n_cycles)
+        ro.enqueue_final_step(self.n_cycles, pack=self._pack_args() if self._packed_exchange() else None)
+
+    def _packed_exchange(self):
+        """the fused exchange of a sharded generation: the rollout's closing launch writes this rank's all-gather record,
+        the selection reads the gathered buffer as it is, elites are rebuilt inside the promotion launch"""
+        return (getattr(self, "sharded_run", False) and self.fused_tail and self.gather_packed is not None
+                and os.environ.get("COEVO_PACKED_EXCHANGE", "1") != "0")
+
+    def _pack_args(self):
+        return (self.pack_local, self.dist_all, 3, self.n_local, self.hof, self.pop, self.lo)
 
     def step_sharded(self, gen):
         """One generation of the population-sharded run (world > 1) without a host round trip: the same launches as
@@ -635,8 +673,14 @@ class GAEngine:
         between the rollout and the selection.  Evaluation means and the adaptive sigma rule run on the device on every
         rank alike (the 10 evaluation games are replicated), elites are rebuilt from last generation's elites, children
         are bred with their stale-agent distance fused in.  Enqueued eagerly - the host knows `gen`, only data-dependent
-        values (sigma, ranks, distances) have to stay on the device."""
+        values (sigma, ranks, distances) have to stay on the device.
+
+        Launches per generation outside the rollout's n_cycles (round 5, the packed exchange): one reset, the closing step
+        (+ this rank's all-gather record), ONE collective, selection, promotion (+ elite rebuild), sigma rule, children,
+        their distances (+ counter tick) = 7 + the collective, where the separate form took ~32 (a rank of 8: 0.16 ms of a
+        0.72 ms generation - profiles/r04_cfg2_shard_1_of_4_kernel_stats.csv)."""
         assert self.env_mode == "device" and self.rng_mode == "device_philox"
+        self.sharded_run = True
         ro, M = self.ro, 3 * self.pop * self.hof
         if self.K > 1 and self.fused_tail and self.pipelined and ro.desc.merged:
             # as on one GPU: each cohort stream breeds its children (deferred), resets its games, runs its chain
@@ -653,39 +697,75 @@ class GAEngine:
             ro.set_limits(limits)
         base = self._ordinal_base(gen)
         per_phase = self.n_local * self.hof
-        for ph in range(3):
-            ro.reset(ph * per_phase, per_phase, base + ph * self.pop * self.hof + self.lo * self.hof)
+        segs = [(ph * per_phase, per_phase, base + ph * self.pop * self.hof + self.lo * self.hof) for ph in range(3)]
         if gen > 0:
-            ro.reset(self.n_main, N_EVAL, self._ordinal_base(gen - 1) + M)
-        ro.enqueue(self.n_cycles)
+            segs.append((self.n_main, N_EVAL, self._ordinal_base(gen - 1) + M))
+        ro.reset_segments(segs)   # one launch (three phases + the evaluation games)
+        if self._packed_exchange():
+            ro.enqueue(self.n_cycles, final=False)
+            ro.enqueue_final_step(self.n_cycles, pack=self._pack_args())
+        else:
+            ro.enqueue(self.n_cycles)
         self._sharded_tail(gen, breed=True)
 
     def _sharded_tail(self, gen, breed):
-        """all-gather of the fitness inputs -> selection -> sigma rule -> elites (rebuilt) / HoF / best -> [children]"""
+        """all-gather of the fitness inputs -> selection -> elites (rebuilt) / HoF / best -> sigma rule -> [children]"""
         ro = self.ro
         per_phase = self.n_local * self.hof
-        # last HoF game of every local individual (Q2) + its stale-agent distance -> every rank (one fused all-gather)
-        if getattr(self, "_last_game_idx", None) is None:  # built once: one gather launch per generation
-            one = torch.arange(self.n_local, device=self.device) * self.hof + self.hof - 1
-            self._last_game_idx = torch.cat([ph * per_phase + one for ph in range(3)])
-        self.last_reward[:, self.lo:self.hi] = ro.rewards[self._last_game_idx].view(3, self.n_local, 3)
-        if self.world > 1:
-            self.gather(self)
-        # everything after the all-gather replays as one graph from generation 1 on (the elite rebuild then takes the
-        # generation from the device counter); generation 0 (elites out of the initial population) runs eagerly
-        if not breed and gen > 0 and self.fused_tail and self.ro.use_graph:
-            if getattr(self, "_sharded_tail_graph", None) is None:
+        packed = self._packed_exchange()
+        if packed:
+            self.gather_packed(self)   # pack_local (written by the closing step) -> pack_all on every rank
+        else:
+            # last HoF game of every local individual (Q2) + its stale-agent distance -> every rank (one fused all-gather)
+            if getattr(self, "_last_game_idx", None) is None:  # built once: one gather launch per generation
+                one = torch.arange(self.n_local, device=self.device) * self.hof + self.hof - 1
+                self._last_game_idx = torch.cat([ph * per_phase + one for ph in range(3)])
+            self.last_reward[:, self.lo:self.hi] = ro.rewards[self._last_game_idx].view(3, self.n_local, 3)
+            if self.world > 1:
+                self.gather(self)
+        # everything after the all-gather replays as one graph from generation 1 on (the elite rebuild and the children then
+        # take the generation from the device counter); generation 0 (elites out of the initial population) runs eagerly
+        if gen > 0 and self.fused_tail and self.ro.use_graph and (packed or not breed):
+            key = (bool(breed), packed)
+            graphs = self.__dict__.setdefault("_sharded_tail_graphs", {})
+            if key not in graphs:
                 torch.cuda.synchronize()
                 gr = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gr, capture_error_mode="thread_local"):
-                    self._sharded_tail_post(gen, breed=False, gen_from_device=True)
-                self._sharded_tail_graph = gr
-            self._sharded_tail_graph.replay()
+                    self._sharded_tail_post(gen, breed=breed, gen_from_device=True, packed=packed)
+                graphs[key] = gr
+            graphs[key].replay()
             return
-        self._sharded_tail_post(gen, breed, gen_from_device=False)
+        self._sharded_tail_post(gen, breed, gen_from_device=False, packed=packed)
 
-    def _sharded_tail_post(self, gen, breed, gen_from_device):
+    def _sharded_tail_post(self, gen, breed, gen_from_device, packed=False):
         ro = self.ro
+        g = L._p(self.gen_dev)
+        mn, mx, adaptive = self.loop_args
+        if packed:
+            # selection off the gathered buffer; promotion with the elites rebuilt in the same launch from the sigma their
+            # children were bred with (sigma32 BEFORE this generation's sigma rule: no copy of the previous value needed)
+            roles = (L.GaSelectRole * 3)()
+            for ri, r in enumerate(ROLES):
+                roles[ri] = L.GaSelectRole(None, None, L._p(self.div[r]), L._p(self.fitness[r]), L._p(self.order[r]),
+                                           L._p(self.best_dist[r]), 0, RET_SLOT[r])
+            L.call("coevo_ga_select_gathered", roles, 3, self.pop, self.hof, L._p(self.pack_all), self.n_local)
+            pr = (L.GaPromoteRole * 3)()
+            for ri, r in enumerate(ROLES):
+                pr[ri] = L.GaPromoteRole(self._ptr(r, "pop"), self._ptr(r, "hof"), self._ptr(r, "elite"), L._p(self.order[r]),
+                                         ROLE_D[r], 1 if gen == 0 else 0, 1 if self.lo == 0 else 0, 0)
+            if gen == 0:   # generation 0's population is the host-initialised one, present on every rank
+                L.call("coevo_ga_promote", pr, 3, self.E, self.hof)
+            else:
+                L.call("coevo_ga_promote_rebuild", pr, 3, self.E, self.hof, L._p(self.sigma32), self.philox_seed,
+                       0 if gen_from_device else (gen - 1) * 4, g if gen_from_device else None)
+            L.call("coevo_ga_adapt_sigma", L._p(ro.rewards), self.n_main, g, L._p(self.hist), L._p(self.sig_hist), self.cap,
+                   L._p(self.sigma64), L._p(self.sigma32), mn, mx, adaptive)
+            if breed:   # K = 1: the rank's children now, their distances + the counter's tick in the last launch
+                self._breed_cohort(0, gen, gen_dev=g if gen_from_device else None, tick=True)
+            else:
+                L.call("coevo_counter_add", g, 1)
+            return
         if self.fused_tail:
             self._select_roles(lambda ri: self.last_reward[ri].data_ptr(), lambda ri: 0, 1)
         else:
@@ -694,8 +774,6 @@ class GAEngine:
                 L.call("coevo_ga_fitness", self.last_reward[ph].data_ptr(), 0, self.pop, 1, self.hof, RET_SLOT[r],
                        L._p(self.div[r]), L._p(self.fitness[r]))
                 L.call("coevo_rank_desc", L._p(self.fitness[r]), self.pop, L._p(self.order[r]))
-        g = L._p(self.gen_dev)
-        mn, mx, adaptive = self.loop_args
         self.sigma32_prev.copy_(self.sigma32)  # what last generation's children were bred with (elite rebuild)
         L.call("coevo_ga_adapt_sigma", L._p(ro.rewards), self.n_main, g, L._p(self.hist), L._p(self.sig_hist), self.cap,
                L._p(self.sigma64), L._p(self.sigma32), mn, mx, adaptive)
@@ -813,9 +891,10 @@ class GATrainer:
         env_mode = env_mode or getattr(args, "coevo_env", "device")
         self.first_ordinal = getattr(env, "n_resets", 1)
         pop_flat, hof_flat = initial_population(env, args)
-        shard, gather = (0, 1), None
+        shard, gather, gather_packed = (0, 1), None, None
         if dist_ctx is not None and dist_ctx.world > 1:
             shard, gather = (dist_ctx.rank, dist_ctx.world), dist_ctx.gather_ga
+            gather_packed = getattr(dist_ctx, "gather_ga_packed", None)
         # the host-free generation loop needs device-built offspring, the device env and a single rank
         self.device_loop = (self.rng == "device_philox" and env_mode == "device" and shard == (0, 1)
                             and getattr(args, "coevo_device_loop", True))
@@ -839,7 +918,7 @@ class GATrainer:
                             philox_seed=getattr(args, "coevo_seed", 0), env=env_mode,
                             first_ordinal=self.first_ordinal,
                             env_seed=getattr(env, "seed_value", ENV_SEED) or ENV_SEED, shard=shard, gather=gather,
-                            cohorts=int(cohorts))
+                            cohorts=int(cohorts), gather_packed=gather_packed)
         self.eng.load_initial(pop_flat, hof_flat)
         self.res = GAResult()
         self.res.engine = self.eng

@@ -157,10 +157,17 @@ _SIGS = {
     "coevo_mpe_rewards": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "coevo_mpe_policy_cycle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "coevo_mpe_cycle_kernel_form": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "coevo_rollout_ctx_create": (C.c_void_p, [C.c_int]),
     "coevo_rollout_ctx_destroy": (None, [C.c_void_p]),
     "coevo_ga_select": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "coevo_ga_select_gathered": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "coevo_ga_promote": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "coevo_ga_promote_rebuild": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32,
+                                           C.c_void_p, C.c_void_p]),
+    "coevo_mpe_final_step_pack": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "coevo_fc_distance_finalize_multi_tick": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "coevo_rollout_ctx_reserve_cohorts": (C.c_int, [C.c_void_p, C.c_int]),
     "coevo_rollout_ctx_cohort_stream": (C.c_void_p, [C.c_void_p, C.c_int]),
     "coevo_rollout_ctx_reset_timing": (C.c_int, [C.c_void_p]),

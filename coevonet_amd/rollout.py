@@ -302,11 +302,19 @@ class DeviceRollout:
         self.desc.n_cycles = n_cycles
         L.call("coevo_mpe_rollout", L.C.byref(self.desc), ctx, 1 if timed else 0)
 
-    def enqueue(self, n_cycles):
-        """plain enqueue on the current stream (no graph of its own): for callers that capture a larger graph"""
+    def enqueue(self, n_cycles, final=True):
+        """plain enqueue on the current stream (no graph of its own): for callers that capture a larger graph.
+        final=False: without the closing step (the caller runs enqueue_final_step itself, e.g. with its all-gather pack)"""
         self.desc.light_stamps = L._p(self.stamps) if self.time_light else None
         self.desc.n_cycles = int(n_cycles)
-        L.call("coevo_mpe_rollout", L.C.byref(self.desc), self.ctx if (self.overlap or self.n_cohorts > 1) else None, 0)
+        keep = self.desc.rewards
+        if not final:
+            assert self.desc.state_alt, "only the fused-step rollout can leave its books open"
+            self.desc.rewards = None
+        try:
+            L.call("coevo_mpe_rollout", L.C.byref(self.desc), self.ctx if (self.overlap or self.n_cohorts > 1) else None, 0)
+        finally:
+            self.desc.rewards = keep
         if self.time_light:
             self._pending_stamps = int(n_cycles)
 
@@ -333,11 +341,18 @@ class DeviceRollout:
         if self.time_light:
             self._pending_stamps = int(n_cycles)
 
-    def enqueue_final_step(self, n_cycles):
-        """close the books of a rollout whose chains were enqueued with enqueue_cohort (current stream)"""
+    def enqueue_final_step(self, n_cycles, pack=None):
+        """close the books of a rollout whose chains were enqueued with enqueue_cohort / enqueue(final=False) (current stream).
+        pack = (out [n_roles][n_local][4] fp64, dist [n_roles][pitch] fp32, n_roles, n_local, hof, pitch, first): this rank's
+        record of the fitness all-gather written by the same launch (coevo_mpe_final_step_pack)"""
         n, last = self.plan.n_games, int(n_cycles) - 1
         st_last = self.state2[0] if last <= 0 or (last & 1) == 0 else self.state2[1]
         act = self.actions_by_game[(last if last > 0 else 0) & 1]
+        if pack is not None:
+            out, dist, n_roles, n_local, hof, pitch, first = pack
+            L.call("coevo_mpe_final_step_pack", L._p(st_last), n, L._p(act), last, L._p(self.limits), self.pos_first,
+                   L._p(self.rewards), L._p(out), L._p(dist), n_roles, n_local, hof, pitch, first)
+            return
         L.call("coevo_mpe_final_step", L._p(st_last), n, L._p(act), last, L._p(self.limits), self.pos_first,
                L._p(self.rewards))
 

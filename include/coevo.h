@@ -294,7 +294,15 @@ int coevo_mpe_policy_cycle_fused(const float *slab, const coevo_fc_task *tasks, 
  * for every row of the cohort at once).  The kernel holds two workgroups per CU; when the workgroups of
  * `concurrent_launches` such launches (cohorts running side by side, else 1) exceed those slots, a streaming workgroup
  * carries two nets so that everything is resident in one round.  heavy_max_rows <= 16 selects the lean kernel (four
- * workgroups per CU, 16-row shared-opponent tiles) when everything then fits at one net per workgroup. */
+ * workgroups per CU, 16-row shared-opponent tiles) when everything then fits at one net per workgroup; heavy_max_rows <= 8
+ * with at most two workgroups per CU in flight selects the small-launch kernel (every task through the per-individual body,
+ * fc2 on the vector ALU: a rank of a population sharded over several GPUs, genetic_algorithm.py:125-217 split by index). */
+#define COEVO_CYCLE_FORM_TILE32 0         /* 32-row shared-opponent tiles, one net per streaming workgroup, two per CU */
+#define COEVO_CYCLE_FORM_TILE32_PAIRED 1  /* ... two nets per streaming workgroup */
+#define COEVO_CYCLE_FORM_LEAN16 2         /* 16-row tiles, four workgroups per CU (the full-population launch) */
+#define COEVO_CYCLE_FORM_SMALL 3          /* every task <= 8 rows, vector-ALU fc2 (launches that leave CUs idle) */
+/* which of them a launch of this shape runs (needs the current device: the choice depends on its CU count) */
+int coevo_mpe_cycle_kernel_form(int n_heavy, int n_light, int heavy_max_rows, int light_max_rows, int concurrent_launches);
 int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_task *heavy_tasks, int n_heavy,
                                   const coevo_fc_task *light_tasks, int n_light, int light_max_rows,
                                   const double *state_prev, double *state_next, int n_games,
@@ -304,6 +312,14 @@ int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_task *heavy_
                                   void *stream);
 int coevo_mpe_final_step(const double *state, int n_games, const int32_t *actions_by_game, int cycle,
                          const int32_t *game_limit, int pos_first, double *rewards, void *stream);
+/* ... + this rank's record of the fitness all-gather in the same launch (a population-sharded run; genetic_algorithm.py:
+ * 140-146: only the last HoF game's reward survives, quirk Q2).  Games [0, n_roles * n_local * hof) are laid out
+ * [role][local individual][hof game]; pack[role][j][0..2] = the play_game triple of game (role, j, hof - 1), [3] =
+ * (double)dist[role * dist_pitch + dist_first + j] (the individual's distance to the stale agent, quirk Q3).  The ranks'
+ * packs, all-gathered rank-major, are what coevo_ga_select_gathered reads: no copy kernel between rollout and selection. */
+int coevo_mpe_final_step_pack(const double *state, int n_games, const int32_t *actions_by_game, int cycle,
+                              const int32_t *game_limit, int pos_first, double *rewards, double *pack, const float *dist,
+                              int n_roles, int n_local, int hof, int dist_pitch, int dist_first, void *stream);
 
 /* ---------------------------------------------------------------- K3/K4/K8: offspring on device ------------- */
 /* The noise contract: rounds of the Philox4x32 generator behind every device-built offspring (7).  A checkpoint / a binding
@@ -366,6 +382,8 @@ typedef struct {
     const double *dist_partial; float *dist; const float *head; int32_t n_blocks, n, first, pad;
 } coevo_fc_finalize_job;
 int coevo_fc_distance_finalize_multi(const coevo_fc_finalize_job *jobs, int n_jobs, void *stream);
+/* ... with coevo_counter_add(counter, 1) in the same launch: the last launch of a device-resident generation */
+int coevo_fc_distance_finalize_multi_tick(const coevo_fc_finalize_job *jobs, int n_jobs, int32_t *counter, void *stream);
 /* Multi-GPU Co-GA: this generation's elites (ids order[0..E-1] on the device) rebuilt from LAST generation's elites
  * and the counter-based noise their children were bred with (id 0 = last best unchanged, id >= 1 = elite_prev[(id-1)%E]
  * + sigma_prev*eps(stream (id-1, stream_hi_prev))): no weight crosses xGMI, every rank gets identical bits.
@@ -388,6 +406,12 @@ typedef struct coevo_ga_select_role {
 } coevo_ga_select_role;
 int coevo_ga_select(const coevo_ga_select_role *roles, int n_roles, int pop, int games_per_individual, int hof,
                     void *stream);
+/* ... of a population-sharded run, straight off the all-gathered buffer (genetic_algorithm.py:125-217 split by individual
+ * index, :223-225 on every rank): gathered[rank][role][j][0..2] = play_game triple of the last HoF game of rank `rank`'s j-th
+ * individual (what coevo_mpe_final_step_pack wrote on that rank), [3] = its distance to the stale agent; individual i =
+ * rank i / n_local, j = i % n_local.  The roles' `dist` / `rewards` are not read. */
+int coevo_ga_select_gathered(const coevo_ga_select_role *roles, int n_roles, int pop, int hof, const double *gathered,
+                             int n_local, void *stream);
 /* Promotion of up to three roles in ONE launch (replaces five coevo_fc_gather launches per role;
  * genetic_algorithm.py:262-275): elite[k] = pop[order[k]] (k < E <= 8; skipped when elites_from_pop == 0: the elites
  * are already in `elite`, e.g. rebuilt by coevo_fc_rebuild_elites), hof.pop(0); hof.append(elite[0]) (hof <= 16 nets,
@@ -398,6 +422,13 @@ typedef struct coevo_ga_promote_role {
     int32_t D, elites_from_pop, best_to_pop0, reserved;
 } coevo_ga_promote_role;
 int coevo_ga_promote(const coevo_ga_promote_role *roles, int n_roles, int E, int hof, void *stream);
+/* ... with the elites REBUILT in the same launch (roles with elites_from_pop == 0; `order` required): elite[k] = individual
+ * order[k] of the generation just evaluated = the unchanged best (id 0: old elite 0) or child c = id - 1 = old elite[c % E] +
+ * sigma[role] * noise(stream (c, stream_hi_prev + role [+ 4 (g - 1) with gen_dev])), regenerated in place from the OLD elites
+ * (a rank of a sharded population holds only its own individuals: no weight crosses xGMI).  One launch instead of, per role,
+ * coevo_fc_gather + coevo_fc_rebuild_elites + the promotion.  sigma: device [n_roles]. */
+int coevo_ga_promote_rebuild(const coevo_ga_promote_role *roles, int n_roles, int E, int hof, const float *sigma,
+                             uint64_t seed, uint32_t stream_hi_prev, const int32_t *gen_dev, void *stream);
 /* net copies inside/between slabs driven by device-resident indices: dst[dst_first+i] = src[src_idx[i]] */
 int coevo_fc_gather(const float *src_slab, const int32_t *src_idx, float *dst_slab, int dst_first, int n, int D,
                     void *stream);

@@ -110,3 +110,36 @@ def test_es_cohort_bounds_cover_every_game():
         b = es_cohort_bounds(n_local, K)
         assert b[0] == 0 and b[-1] == 2 * n_local and len(b) == min(K, n_local) + 1
         assert all(b1 > b0 and b1 % 2 == 0 for b0, b1 in zip(b, b[1:]))
+
+
+class _FakePackedEngine:
+    """the fields DistContext.gather_ga_packed touches (genetic_algorithm.GAEngine), on the CPU"""
+
+    def __init__(self, rank, world, n_local):
+        self.pack_local = torch.zeros(3, n_local, 4, dtype=torch.float64)
+        self.pack_all = torch.zeros(world, 3, n_local, 4, dtype=torch.float64)
+
+
+def _worker_packed(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from coevonet_amd.dist import DistContext
+    ctx = DistContext(backend="gloo")
+    n_local = 5
+    full = torch.arange(world * 3 * n_local * 4, dtype=torch.float64).reshape(world, 3, n_local, 4) / 3
+    eng = _FakePackedEngine(rank, world, n_local)
+    eng.pack_local.copy_(full[rank])
+    ctx.start_gather_timing() if torch.cuda.is_available() else None
+    ctx._gather_ga_packed(eng)
+    ret[rank] = bool(torch.equal(eng.pack_all, full))
+    ctx.shutdown()
+
+
+def test_gather_ga_packed_world2_gloo():
+    """the fused Co-GA exchange: each rank's [role][j][4] record lands rank-major in every rank's gathered buffer - the layout
+    coevo_ga_select_gathered indexes (individual i = rank i // n_local, j = i % n_local; genetic_algorithm.py:223-225 on
+    every rank)"""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_packed, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}

@@ -320,6 +320,43 @@ def test_rollout_variants_match_oracle(mode, nh, heavy_rows):
         assert list(r[g]) == want["rewards"], (mode, g, r[g], want["rewards"])
 
 
+@pytest.mark.parametrize("npop,nh,heavy_rows,cohorts", [(25, 5, 5, 1), (50, 5, 8, 1), (20, 8, 8, 1), (20, 2, 5, 1), (23, 1, 7, 1),
+                                                        (26, 5, 5, 2)])
+def test_small_launch_kernel_matches_oracle(npop, nh, heavy_rows, cohorts):
+    """fc_cycle_small_kernel (every task <= 8 rows through the per-individual body, fc2 as v_fmac_f32 with DPP row_newbcast
+    activations - the launch shape of ONE RANK of a sharded population, genetic_algorithm.py:125-217 split by index: 25 / 50
+    individuals per role, shared opponents cut into hof- or 8-row chunks) == the oracle's play_game, bit for bit: every row-count
+    instantiation (1, 2, 5, 8), ragged last chunks, two cohorts side by side"""
+    from coevonet_amd.rollout import RolloutPlan, DeviceRollout
+    limit, max_cycles = 40, 25
+    nets10 = make_nets(npop + nh, 10, seed=191, mutate=False)
+    nets8 = make_nets(nh, 8, seed=192, mutate=False)
+    s10, s8 = L.fc_slab_stride(10), L.fc_slab_stride(8)
+    slab = torch.cat([to_slab(nets10, 10).reshape(-1), to_slab(nets8, 8).reshape(-1)]).contiguous()
+    off = [i * s10 for i in range(npop + nh)] + [(npop + nh) * s10 + k * s8 for k in range(nh)]
+    D = [10] * (npop + nh) + [8] * nh
+    games = [(npop + nh + k, i, npop + k) for i in range(npop) for k in range(nh)]   # (adversary, agent_0, agent_1)
+    plan = RolloutPlan(np.array(games), off, D, device=DEV, n_cohorts=cohorts, heavy_rows=heavy_rows)
+    assert plan.n_cohorts == cohorts and plan.heavy_max <= heavy_rows <= 8 and plan.light_max == nh
+    for k in range(cohorts):
+        n_h = int(plan.heavy_begin_np[k + 1] - plan.heavy_begin_np[k])
+        n_l = int(plan.light_begin_np[k + 1] - plan.light_begin_np[k])
+        assert L.load().coevo_mpe_cycle_kernel_form(n_h, n_l, plan.heavy_max, plan.light_max, cohorts) == 3   # COEVO_CYCLE_FORM_SMALL
+    ro = DeviceRollout(plan, slab, merged=True)
+    T = min(limit, 3 * max_cycles)
+    ro.set_limits(np.full(plan.n_games, T))
+    first = 3
+    ro.reset(0, plan.n_games, first)
+    ro.run((T + 2) // 3)
+    torch.cuda.synchronize()
+    ro.check_status()
+    r = ro.rewards.cpu().numpy()
+    stream = rp.Stream()
+    for g, (adv, a0, a1) in enumerate(games):
+        want = rp.play_game(stream, nets10[a0], nets10[a1], nets8[adv - npop - nh], limit, max_cycles, ordinal=first + g)
+        assert list(r[g]) == want["rewards"], (g, r[g], want["rewards"])
+
+
 def test_paired_streaming_workgroups_odd_count():
     """more tasks than the 32-row merged kernel has workgroup slots -> two per-individual nets per workgroup; an odd
     number of them leaves the last workgroup's second net absent (it must write nothing).  523 one-row tasks."""
@@ -552,6 +589,107 @@ def test_fused_select_and_promote_equal_separate_launches(pop):
     for slabs, ref, _ in checks:
         for got, exp in zip(slabs, ref[:3]):
             assert torch.equal(got, exp)
+
+
+@pytest.mark.parametrize("world,n_local,hof,E", [(8, 25, 5, 2), (4, 50, 5, 3), (2, 7, 3, 1)])
+def test_packed_exchange_launches_equal_separate_launches(world, n_local, hof, E):
+    """the fused exchange of a population-sharded generation (genetic_algorithm.py:125-217 by individual index, :223-252 on every
+    rank) against the launches it replaces: coevo_mpe_final_step_pack == coevo_mpe_final_step + the pack copies;
+    coevo_ga_select_gathered off the rank-major gathered buffer == coevo_ga_select on the unpacked arrays;
+    coevo_ga_promote_rebuild == coevo_fc_gather + coevo_fc_rebuild_elites + coevo_ga_promote (host generation and device
+    counter forms); coevo_fc_distance_finalize_multi_tick == finalize + counter_add - bit for bit"""
+    import ctypes as ct
+    rng = np.random.default_rng(world)
+    pop = world * n_local
+    # ---- closing step + pack: random state / actions of 3 * n_local * hof + 10 games
+    n = 3 * n_local * hof + 10
+    st = torch.from_numpy(rng.normal(size=(L.MPE_STATE_DOUBLES, n))).to(DEV)
+    act = torch.from_numpy(rng.integers(0, 5, size=(n, 3)).astype(np.int32)).to(DEV)
+    lim = torch.from_numpy(rng.integers(60, 76, size=n).astype(np.int32)).to(DEV)
+    dist_all = torch.from_numpy(rng.random((3, pop)).astype(np.float32) * 3).to(DEV)
+    lo = (world - 1) * n_local
+    rew0, rew1 = torch.zeros(n, 3, dtype=torch.float64, device=DEV), torch.zeros(n, 3, dtype=torch.float64, device=DEV)
+    pack = torch.full((3, n_local, 4), -7.0, dtype=torch.float64, device=DEV)
+    L.call("coevo_mpe_final_step", L._p(st), n, L._p(act), 24, L._p(lim), 1, L._p(rew0))
+    L.call("coevo_mpe_final_step_pack", L._p(st), n, L._p(act), 24, L._p(lim), 1, L._p(rew1), L._p(pack), L._p(dist_all), 3,
+           n_local, hof, pop, lo)
+    torch.cuda.synchronize()
+    assert torch.equal(rew0, rew1)
+    last = rew0[:3 * n_local * hof].view(3, n_local, hof, 3)[:, :, hof - 1]
+    assert torch.equal(pack[:, :, :3], last) and torch.equal(pack[:, :, 3], dist_all[:, lo:lo + n_local].double())
+    # ---- selection off the gathered buffer
+    gathered = torch.from_numpy(rng.normal(size=(world, 3, n_local, 4)) * 10).to(DEV)
+    gathered[..., 3] = torch.from_numpy(rng.random((world, 3, n_local)).astype(np.float32) * 3).to(DEV).double()
+    unpack = gathered.permute(1, 0, 2, 3).reshape(3, pop, 4).contiguous()
+    outs = []
+    for form in ("separate", "gathered"):
+        sel = (L.GaSelectRole * 3)()
+        keep = []
+        for ri in range(3):
+            d32 = unpack[ri, :, 3].float().contiguous()
+            r3 = unpack[ri, :, :3].contiguous()
+            div, fit = torch.zeros(1, device=DEV), torch.zeros(pop, device=DEV)
+            order, best = torch.zeros(pop, dtype=torch.int32, device=DEV), torch.zeros(1, device=DEV)
+            sel[ri] = L.GaSelectRole(L._p(d32) if form == "separate" else None, L._p(r3) if form == "separate" else None,
+                                     L._p(div), L._p(fit), L._p(order), L._p(best), 0, [0, 1, 2][ri])
+            keep.append((d32, r3, div, fit, order, best))
+        if form == "separate":
+            L.call("coevo_ga_select", sel, 3, pop, 1, hof)
+        else:
+            L.call("coevo_ga_select_gathered", sel, 3, pop, hof, L._p(gathered), n_local)
+        torch.cuda.synchronize()
+        outs.append([(k[2].clone(), k[3].clone(), k[4].clone(), k[5].clone()) for k in keep])
+    for a, b in zip(*outs):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert L.load().coevo_ga_select_gathered(sel, 3, pop + 1, hof, L._p(gathered), n_local, None) == -1   # pop % n_local
+    # ---- promotion with the elites rebuilt in the launch
+    Ds = [10, 10, 8]
+    iota = torch.arange(16, dtype=torch.int32, device=DEV)
+    gen = 5
+    sigma = torch.tensor([0.05, 0.031, 0.07], dtype=torch.float32, device=DEV)
+    gen_dev = torch.tensor([gen], dtype=torch.int32, device=DEV)
+    for device_gen in (False, True):
+        pro = (L.GaPromoteRole * 3)()
+        checks = []
+        for ri, D in enumerate(Ds):
+            stride = L.fc_slab_stride(D)
+            order = torch.from_numpy(rng.permutation(pop).astype(np.int32)).to(DEV)
+            if ri == 1:
+                order[0] = 0          # the unchanged best stays the best
+            if ri == 2 and E > 1:
+                order[E - 1] = 0      # ... or survives as a lesser elite
+            slabs = [torch.from_numpy(rng.normal(size=k * stride).astype(np.float32)).to(DEV) for k in (1, hof, E)]
+            rp_, rh, re_ = [x.clone() for x in slabs]
+            prev = torch.zeros(E * stride, device=DEV)
+            L.call("coevo_fc_gather", L._p(re_), L._p(iota), L._p(prev), 0, E, D)
+            L.call("coevo_fc_rebuild_elites", L._p(prev), L._p(order), L._p(re_), E, D, sigma.data_ptr() + 4 * ri, 77,
+                   ri if device_gen else (gen - 1) * 4 + ri, L._p(gen_dev) if device_gen else None)
+            one = (L.GaPromoteRole * 1)(L.GaPromoteRole(L._p(rp_), L._p(rh), L._p(re_), L._p(order), D, 0, 1, 0))
+            L.call("coevo_ga_promote", one, 1, E, hof)
+            pro[ri] = L.GaPromoteRole(L._p(slabs[0]), L._p(slabs[1]), L._p(slabs[2]), L._p(order), D, 0, 1, 0)
+            checks.append((slabs, (rp_, rh, re_), order))
+        L.call("coevo_ga_promote_rebuild", pro, 3, E, hof, L._p(sigma), 77, 0 if device_gen else (gen - 1) * 4,
+               L._p(gen_dev) if device_gen else None)
+        torch.cuda.synchronize()
+        for slabs, ref, _ in checks:
+            for got, exp in zip(slabs, ref):
+                assert torch.equal(got, exp)
+    # ---- distance reduction + counter tick
+    nb = 7
+    part = torch.from_numpy(rng.random((3, 9, nb))).to(DEV)
+    d0, d1 = torch.zeros(3, 12, device=DEV), torch.zeros(3, 12, device=DEV)
+    head = torch.tensor([4.5], device=DEV)
+    cnt = torch.tensor([41], dtype=torch.int32, device=DEV)
+    for dst, tick in ((d0, False), (d1, True)):
+        fj = (L.FinalizeJob * 3)()
+        for ri in range(3):
+            fj[ri] = L.FinalizeJob(part[ri].data_ptr(), dst[ri].data_ptr(), L._p(head) if ri == 0 else None, nb, 9 - ri, 1, 0)
+        if tick:
+            L.call("coevo_fc_distance_finalize_multi_tick", ct.cast(fj, ct.c_void_p), 3, L._p(cnt))
+        else:
+            L.call("coevo_fc_distance_finalize_multi", ct.cast(fj, ct.c_void_p), 3)
+    torch.cuda.synchronize()
+    assert torch.equal(d0, d1) and cnt.item() == 42 and d0[0, 0].item() == 4.5
 
 
 def test_multi_job_launches_equal_per_role_launches():

@@ -339,3 +339,55 @@ def test_cfg2_full_size_host_cores_equal_device(monkeypatch):
         assert np.array_equal(np.asarray(res.fitness[g], np.float32).view(np.uint32),
                               np.asarray(want.fitness[g], np.float32).view(np.uint32))
         assert [res.rewards[r][g] for r in ROLES] == [want.rewards[r][g] for r in ROLES]
+
+
+@pytest.mark.parametrize("world,rank", [(8, 0), (8, 5), (4, 3)])
+def test_cfg2_one_rank_of_the_split_vs_oracle(world, rank):
+    """BASELINE's own split (pop 200 over 4 / 8 GPUs: `--gpus N`, genetic_algorithm.py:125-217 by individual index): the
+    launches ONE rank runs - a rank of 8: 25 individuals per role, shared opponents in hof-row chunks, every task through the
+    small-launch kernel (fc2 on the vector ALU, one workgroup per CU); a rank of 4: 50 per role on the lean kernel with 16-row
+    tiles - against the oracle: all of the rank's deciding games of generation 0, a
+    sample of the others, and generation 1's games of bred children (the rank's own children; the elites are whatever
+    dist.ShardRehearsal's made-up gather selected, read back from the engine)"""
+    from coevonet_amd.dist import ShardRehearsal
+    pop, hof, E = 200, 5, 2
+    n_local = pop // world
+    lo = rank * n_local
+    cfg = {"seed": 0, "args": dict(generations=2, population=pop, hof_size=hof, elites_number=E, fitness_sharing=True,
+                                   max_timesteps_per_episode=200, max_evaluation_steps=200)}
+    args, env, res = _ga(cfg, "device_philox", dist_ctx=ShardRehearsal(rank, world))
+    eng = res.engine
+    assert (eng.lo, eng.hi, eng.K) == (lo, lo + n_local, 1) and eng.plan.light_max == hof
+    assert eng.plan.heavy_max == (hof if world == 8 else 16)
+    form = L.load().coevo_mpe_cycle_kernel_form(len(eng.plan.heavy_np), len(eng.plan.light_np), eng.plan.heavy_max,
+                                                eng.plan.light_max, 1)
+    assert form == (3 if world == 8 else 2)   # COEVO_CYCLE_FORM_SMALL / _LEAN16
+    _seed(0)
+    hofs, popu = rp.ga_initial(pop, hof)
+    M = 3 * pop * hof
+    st = rp.Stream()
+    got0 = res.game_rewards[0].reshape(3, n_local, hof, 3)
+    for ph, role in enumerate(ROLES):
+        for j in range(n_local):
+            i = lo + j
+            for k in ([hof - 1] if (j + ph) % 5 else range(hof)):   # Q2: the deciding game of everyone, all games of a fifth
+                a0, a1, adv = rp.ga_game_nets(role, popu[role][i], hofs, k, hof)
+                w = rp.play_game(st, a0, a1, adv, 200, 25, ordinal=1 + ph * pop * hof + i * hof + k)
+                assert list(got0[ph, j, k]) == w["rewards"], (ph, i, k)
+    # generation 1: the elites every rank rebuilt are generation 0's individuals order[:E] (ids read back); child c =
+    # individual c + 1 = mutate(elite[c % E]) with stream (c, role); HoF pushed
+    ids = res.elite_ids[0]
+    got1 = res.game_rewards[1].reshape(3, n_local, hof, 3)
+    elites = {role: [popu[role][i] for i in ids[ph]] for ph, role in enumerate(ROLES)}
+    for role in ROLES:
+        hofs[role].append(elites[role][0])
+        hofs[role].pop(0)
+    for ph, role in enumerate(ROLES):
+        for j in range(0, n_local, 4):
+            i = lo + j
+            net = elites[role][0] if i == 0 else rp.mutate_philox(elites[role][(i - 1) % E], rp.ROLE_D[role], np.float32(0.05),
+                                                                  0, i - 1, ph)
+            for k in (0, hof - 1):
+                a0, a1, adv = rp.ga_game_nets(role, net, hofs, k, hof)
+                w = rp.play_game(st, a0, a1, adv, 200, 25, ordinal=1 + (M + 10) + ph * pop * hof + i * hof + k)
+                assert list(got1[ph, j, k]) == w["rewards"], (ph, i, k)

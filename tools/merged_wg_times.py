@@ -14,7 +14,13 @@ args = bench.make_args(200, 5, 2, 200)
 args.coevo_cohorts = 1
 args.coevo_device_loop = False
 env = initialize_env(args)
-tr = GATrainer(env, args, rng="device_philox", env_mode="device", collect=False)
+shard = int(os.environ.get("COEVO_PROBE_SHARD", "1"))   # N: rank 0 of pop 200 over N GPUs (dist.ShardRehearsal)
+if shard > 1:
+    from coevonet_amd.dist import ShardRehearsal
+    args.coevo_device_loop = True
+    tr = GATrainer(env, args, rng="device_philox", env_mode="device", collect=False, dist_ctx=ShardRehearsal(0, shard))
+else:
+    tr = GATrainer(env, args, rng="device_philox", env_mode="device", collect=False)
 eng, ro = tr.eng, tr.eng.ro
 tr.step()
 ro.use_graph = False

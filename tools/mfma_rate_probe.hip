@@ -143,8 +143,18 @@ void run(int waves_per_simd, const char *name)
     hipFree(out); hipFree(clk);
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    if (argc > 1 && argv[1][0] == 'c') {   // "chain": what ONE dependent accumulator chain costs per step (round 5: the small-shard
+        for (int w : {1, 2, 4}) {          // cycle kernel is one or two chains per wave)
+            run<1, 1, 0>(w, "4x4x1");
+            run<1, 2, 0>(w, "4x4x1");
+            run<1, 3, 0>(w, "4x4x1");
+            run<0, 1, 0>(w, "16x16x4");
+            run<0, 2, 0>(w, "16x16x4");
+        }
+        return 0;
+    }
     for (int w : {1, 2, 6}) {
         run<0, 1, 0>(w, "16x16x4");
         run<0, 2, 0>(w, "16x16x4");
