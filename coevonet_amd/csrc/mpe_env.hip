@@ -66,10 +66,17 @@ __global__ void mpe_reset_kernel(double *st, int n, int game_first, int count, c
 
 static_assert(sizeof(coevo_reset_seg) == 16, "layout mirrored by coevonet_amd/lib.py ResetSeg");
 struct ResetSegs { coevo_reset_seg s[COEVO_MAX_JOBS]; };
-__global__ void mpe_reset_multi_kernel(double *st, int n, ResetSegs segs, coevo_pcg64 rng)
+__global__ void mpe_reset_multi_kernel(double *st, int n, ResetSegs segs, coevo_pcg64 rng, uint64_t *stamps, int n_stamps)
 {
     const coevo_reset_seg &sg = segs.s[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // the clock-stamp slot pairs of the rollout that follows, re-armed to {UINT64_MAX, 0} (what stamps_init_kernel did in a
+    // launch of its own in front of every timed rollout)
+    if (stamps && blockIdx.y == 0)
+        for (int j = i; j < n_stamps; j += gridDim.x * blockDim.x) {
+            stamps[2 * j] = ~0ull;
+            stamps[2 * j + 1] = 0ull;
+        }
     if (i >= sg.count) return;
     mpe_reset_game(st, n, sg.game_first + i, rng, sg.first_ordinal + (uint64_t)i);
 }
@@ -251,8 +258,26 @@ extern "C" int coevo_mpe_reset_gen(double *state, int n_games, int game_first, i
     return COEVO_OK;
 }
 
+static int reset_multi_launch(double *state, int n_games, const coevo_reset_seg *segs, int n_segs, coevo_pcg64 rng,
+                              uint64_t *stamps, int n_stamps, void *stream);
+
 extern "C" int coevo_mpe_reset_multi(double *state, int n_games, const coevo_reset_seg *segs, int n_segs, coevo_pcg64 rng,
                                      void *stream)
+{
+    return reset_multi_launch(state, n_games, segs, n_segs, rng, nullptr, 0, stream);
+}
+
+// ... that also re-arms n_stamps {start, end} clock-stamp slot pairs for the timed rollout that follows (coevo_rollout_desc.
+// stamps_armed): a timed rollout then needs no launch of its own for it
+extern "C" int coevo_mpe_reset_multi_arm(double *state, int n_games, const coevo_reset_seg *segs, int n_segs, coevo_pcg64 rng,
+                                         uint64_t *stamps, int n_stamps, void *stream)
+{
+    if (!stamps || n_stamps <= 0) return COEVO_ERR_ARG;
+    return reset_multi_launch(state, n_games, segs, n_segs, rng, stamps, n_stamps, stream);
+}
+
+static int reset_multi_launch(double *state, int n_games, const coevo_reset_seg *segs, int n_segs, coevo_pcg64 rng,
+                              uint64_t *stamps, int n_stamps, void *stream)
 {
     if (!state || n_games <= 0 || !segs || n_segs < 1 || n_segs > COEVO_MAX_JOBS) return COEVO_ERR_ARG;
     coevo::ResetSegs rs{};
@@ -262,9 +287,9 @@ extern "C" int coevo_mpe_reset_multi(double *state, int n_games, const coevo_res
         rs.s[i] = segs[i];
         cmax = segs[i].count > cmax ? segs[i].count : cmax;
     }
-    if (cmax == 0) return COEVO_OK;
-    hipLaunchKernelGGL(coevo::mpe_reset_multi_kernel, dim3((cmax + 127) / 128, n_segs), dim3(128), 0, (hipStream_t)stream,
-                       state, n_games, rs, rng);
+    if (cmax == 0 && !stamps) return COEVO_OK;
+    hipLaunchKernelGGL(coevo::mpe_reset_multi_kernel, dim3((cmax > 0 ? cmax + 127 : 128) / 128, n_segs), dim3(128), 0,
+                       (hipStream_t)stream, state, n_games, rs, rng, stamps, n_stamps);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

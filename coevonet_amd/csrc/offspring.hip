@@ -195,6 +195,8 @@ struct GaPromoteArgs {
     const int32_t *gen_dev;      // device generation counter g (the children were bred with streams of g - 1), or NULL
     uint64_t seed;
     uint32_t stream_hi_prev;     // + role index (+ 4 (g - 1) with gen_dev)
+    int32_t *tick;               // NULL, or the generation counter this launch increments (nothing in it reads the counter
+                                 // after the first instructions of its blocks: see ga_promote_kernel)
 };
 constexpr int PROMOTE_MAX_E = 8, PROMOTE_MAX_HOF = 16;
 
@@ -242,7 +244,7 @@ __device__ __forceinline__ float4 promote_rebuild(float *elite, const int32_t *o
         const float4 pv = *reinterpret_cast<const float4 *>(elite + (int64_t)(id > 0 ? c % E : 0) * stride + s0);
         promote_rebuild<K + 1>(elite, order, stride, s0, E, D, sigma, seed, shi);
         float4 nv = pv;
-        if (id > 0) {
+        if (id > 0 && K < E) {   // (a surplus level re-stores slot E - 1 with the piece it loaded; level E - 1 overwrites it after)
             const int64_t P = fc_params(D);
             float z[4];
             slab_quad_normals(seed, (uint32_t)c, shi, s0, D, P, z);
@@ -285,6 +287,8 @@ __global__ __launch_bounds__(256) void ga_promote_kernel(GaPromoteArgs a)
     promote_hof_shift<1>(hof, stride, s0, a.hof);
     *reinterpret_cast<float4 *>(hof + (int64_t)(a.hof - 1) * stride + s0) = e0;
     if (to_pop0) *reinterpret_cast<float4 *>(pop + s0) = e0;
+    // the generation counter's tick (coevo_ga_promote_tick: only without gen_dev - no block of this launch reads the counter)
+    if (a.tick && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.tick += 1;
 }
 
 // theta[p] += lr/(n*sigma) * sum_i fitness[i] * (pert_i[p] - theta[p]), i ascending, one fmaf per term.
@@ -567,11 +571,19 @@ extern "C" int coevo_fc_gather(const float *src_slab, const int32_t *src_idx, fl
 }
 
 static int ga_promote_launch(const coevo_ga_promote_role *roles, int n_roles, int E, int hof, const float *sigma,
-                             uint64_t seed, uint32_t stream_hi_prev, const int32_t *gen_dev, void *stream);
+                             uint64_t seed, uint32_t stream_hi_prev, const int32_t *gen_dev, int32_t *tick, void *stream);
 
 extern "C" int coevo_ga_promote(const coevo_ga_promote_role *roles, int n_roles, int E, int hof, void *stream)
 {
-    return ga_promote_launch(roles, n_roles, E, hof, nullptr, 0, 0, nullptr, stream);
+    return ga_promote_launch(roles, n_roles, E, hof, nullptr, 0, 0, nullptr, nullptr, stream);
+}
+
+// ... with coevo_counter_add(counter, 1) in the same launch (the last launch of a device-resident generation's tail)
+extern "C" int coevo_ga_promote_tick(const coevo_ga_promote_role *roles, int n_roles, int E, int hof, int32_t *counter,
+                                     void *stream)
+{
+    if (!counter) return COEVO_ERR_ARG;
+    return ga_promote_launch(roles, n_roles, E, hof, nullptr, 0, 0, nullptr, counter, stream);
 }
 
 // Promotion with the elites REBUILT in the same launch (a population-sharded run: a rank holds only its own individuals, so
@@ -587,16 +599,16 @@ extern "C" int coevo_ga_promote_rebuild(const coevo_ga_promote_role *roles, int 
     if (!sigma) return COEVO_ERR_ARG;
     for (int r = 0; roles && r < n_roles && r < 3; ++r)
         if (!roles[r].elites_from_pop && !roles[r].order) return COEVO_ERR_ARG;
-    return ga_promote_launch(roles, n_roles, E, hof, sigma, seed, stream_hi_prev, gen_dev, stream);
+    return ga_promote_launch(roles, n_roles, E, hof, sigma, seed, stream_hi_prev, gen_dev, nullptr, stream);
 }
 
 static int ga_promote_launch(const coevo_ga_promote_role *roles, int n_roles, int E, int hof, const float *sigma,
-                             uint64_t seed, uint32_t stream_hi_prev, const int32_t *gen_dev, void *stream)
+                             uint64_t seed, uint32_t stream_hi_prev, const int32_t *gen_dev, int32_t *tick, void *stream)
 {
     if (!roles || n_roles < 1 || n_roles > 3 || E < 1 || E > PROMOTE_MAX_E || hof < 1 || hof > PROMOTE_MAX_HOF)
         return COEVO_ERR_ARG;
     GaPromoteArgs a{};
-    a.sigma = sigma; a.seed = seed; a.stream_hi_prev = stream_hi_prev; a.gen_dev = gen_dev;
+    a.sigma = sigma; a.seed = seed; a.stream_hi_prev = stream_hi_prev; a.gen_dev = gen_dev; a.tick = tick;
     int64_t max_stride = 0;
     for (int r = 0; r < n_roles; ++r) {
         const coevo_ga_promote_role &R = roles[r];

@@ -10,6 +10,8 @@
 
 #include "coevo_common.hip.h"
 
+static_assert(sizeof(coevo_rollout_desc) == 176, "layout mirrored by coevonet_amd/lib.py RolloutDesc");
+
 __global__ void stamps_init_kernel(uint64_t *stamps, int n)
 {
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -145,7 +147,7 @@ extern "C" int coevo_mpe_rollout(const coevo_rollout_desc *d, void *ctx, int tim
     // HIP events cannot be read back from inside a captured graph (external event-record nodes are rejected by this
     // runtime), so event timing is for eager enqueues only; graph replays use the kernels' own clock stamps instead
     auto record_timing = [&](hipEvent_t e) { return hipEventRecord(e, main_s); };
-    if (d->light_stamps && d->n_cycles > 0) {  // [cycle][2] = {UINT64_MAX, 0}, re-armed by every enqueue / replay
+    if (d->light_stamps && d->n_cycles > 0 && !d->stamps_armed) {  // [cycle][2] = {UINT64_MAX, 0}, re-armed by every enqueue / replay
         hipLaunchKernelGGL(stamps_init_kernel, dim3(1), dim3(256), 0, main_s, d->light_stamps,
                            (d->n_cohorts > 1 ? d->n_cohorts : 1) * d->n_cycles * COEVO_STAMP_SLOTS);
         COEVO_HIP_CHECK(hipGetLastError());

@@ -140,7 +140,13 @@ struct GaSelectArgs {
     // i / n_local.  NULL: distances / rewards through the role's own pointers.
     const double *gathered;
     int n_local, n_roles;
+    // the sigma rule in the same launch (coevo_ga_select_adapt): block (n_roles, 0) runs it beside the roles' blocks
+    coevo_ga_adapt_args adapt;
+    int with_adapt, n_roles_launched;
 };
+
+static_assert(sizeof(coevo_ga_adapt_args) == 88, "layout mirrored by coevonet_amd/lib.py GaAdaptArgs");
+__device__ inline void ga_adapt_body(const coevo_ga_adapt_args &a);
 
 __global__ __launch_bounds__(256) void ga_select_kernel(GaSelectArgs a)
 {
@@ -150,6 +156,10 @@ __global__ __launch_bounds__(256) void ga_select_kernel(GaSelectArgs a)
     __shared__ double scratch[4];
     __shared__ float f[4096];
     __shared__ float div_s;
+    if ((int)blockIdx.x >= a.n_roles_launched) {   // the extra block: evaluation means + adaptive sigma (ga_adapt_kernel)
+        if (a.with_adapt && blockIdx.y == 0 && threadIdx.x == 0) ga_adapt_body(a.adapt);
+        return;
+    }
     const coevo_ga_select_role R = a.role[blockIdx.x];
     const int n = a.pop;
     const bool first_slice = blockIdx.y == 0;
@@ -212,12 +222,14 @@ __device__ inline double np_mean_le10(const double *a, int n)
 // evaluate_current_weights' means (genetic_algorithm.py:12-29) of the generation that finished one generation ago +
 // the adaptive mutation power rule (:323-345, quirk Q5: agent_0's increase starts from agent_1's sigma), on the device
 // so that a generation needs no host round trip.  *gen_dev = g: the evaluation games in `rewards` belong to g-1.
-__global__ void ga_adapt_kernel(const double *rewards, int eval_first, const int32_t *gen_dev, double *hist,
-                                double *sig_hist, int cap, double *sigma64, float *sigma32, double sig_min,
-                                double sig_max, int adaptive)
+__device__ inline void ga_adapt_body(const coevo_ga_adapt_args &a)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const int g = *gen_dev;
+    const double *rewards = a.rewards;
+    double *hist = a.hist, *sig_hist = a.sig_hist, *sigma64 = a.sigma64;
+    const int cap = a.cap, eval_first = a.eval_first_game;
+    const int g = *a.gen_dev;
+    if (a.sigma32_prev)   // what the children evaluated in this generation were bred with (elite rebuild of a sharded run)
+        for (int s = 0; s < 3; ++s) a.sigma32_prev[s] = a.sigma32[s];
     if (g > 0 && g - 1 < cap) {
         const int e = g - 1;
         for (int s = 0; s < 3; ++s) {
@@ -225,7 +237,7 @@ __global__ void ga_adapt_kernel(const double *rewards, int eval_first, const int
             for (int i = 0; i < 10; ++i) tot += rewards[3 * (size_t)(eval_first + i) + s];
             hist[(size_t)s * cap + e] = tot / 10;
         }
-        if (adaptive) {
+        if (a.adaptive) {
             bool worse[3];
             for (int s = 0; s < 3; ++s) {
                 const double *h = hist + (size_t)s * cap;
@@ -240,13 +252,19 @@ __global__ void ga_adapt_kernel(const double *rewards, int eval_first, const int
                 }
             }
             const double s1_before = sigma64[1];
-            sigma64[0] = worse[0] ? fmin(s1_before * 1.2, sig_max) : fmax(sigma64[0] * 0.95, sig_min);
-            sigma64[1] = worse[1] ? fmin(sigma64[1] * 1.2, sig_max) : fmax(sigma64[1] * 0.95, sig_min);
-            sigma64[2] = worse[2] ? fmin(sigma64[2] * 1.2, sig_max) : fmax(sigma64[2] * 0.95, sig_min);
+            sigma64[0] = worse[0] ? fmin(s1_before * 1.2, a.sig_max) : fmax(sigma64[0] * 0.95, a.sig_min);
+            sigma64[1] = worse[1] ? fmin(sigma64[1] * 1.2, a.sig_max) : fmax(sigma64[1] * 0.95, a.sig_min);
+            sigma64[2] = worse[2] ? fmin(sigma64[2] * 1.2, a.sig_max) : fmax(sigma64[2] * 0.95, a.sig_min);
         }
         for (int s = 0; s < 3; ++s) sig_hist[(size_t)s * cap + e] = sigma64[s];
     }
-    for (int s = 0; s < 3; ++s) sigma32[s] = (float)sigma64[s];
+    for (int s = 0; s < 3; ++s) a.sigma32[s] = (float)sigma64[s];
+}
+
+__global__ void ga_adapt_kernel(coevo_ga_adapt_args a)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    ga_adapt_body(a);
 }
 
 // cfg 3 extension mode (NOT in the reference, which has its normalisation commented out at
@@ -277,8 +295,9 @@ extern "C" int coevo_ga_adapt_sigma(const double *rewards, int eval_first_game, 
 {
     if (!rewards || !gen_dev || !hist || !sig_hist || !sigma64 || !sigma32 || cap <= 0 || eval_first_game < 0)
         return COEVO_ERR_ARG;
-    hipLaunchKernelGGL(ga_adapt_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rewards, eval_first_game, gen_dev,
-                       hist, sig_hist, cap, sigma64, sigma32, sig_min, sig_max, adaptive);
+    const coevo_ga_adapt_args a{rewards, gen_dev, hist, sig_hist, sigma64, sigma32, nullptr, sig_min, sig_max, eval_first_game,
+                                cap, adaptive, 0};
+    hipLaunchKernelGGL(ga_adapt_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }
@@ -395,12 +414,25 @@ extern "C" int coevo_rank_desc(const float *fitness, int n, int32_t *order, void
 }
 
 static int ga_select_launch(const coevo_ga_select_role *roles, int n_roles, int pop, int games_per_individual, int hof,
-                            const double *gathered, int n_local, void *stream);
+                            const double *gathered, int n_local, const coevo_ga_adapt_args *adapt, void *stream);
 
 extern "C" int coevo_ga_select(const coevo_ga_select_role *roles, int n_roles, int pop, int games_per_individual,
                                int hof, void *stream)
 {
-    return ga_select_launch(roles, n_roles, pop, games_per_individual, hof, nullptr, 0, stream);
+    return ga_select_launch(roles, n_roles, pop, games_per_individual, hof, nullptr, 0, nullptr, stream);
+}
+
+// coevo_ga_select (gathered == NULL) or coevo_ga_select_gathered, with coevo_ga_adapt_sigma's work in the same launch (an extra
+// block beside the roles' blocks; the two are independent: the rule reads the evaluation games, the selection the training
+// games): one launch less on the chain selection -> promotion -> offspring (genetic_algorithm.py:223-225 + :323-345).
+extern "C" int coevo_ga_select_adapt(const coevo_ga_select_role *roles, int n_roles, int pop, int games_per_individual, int hof,
+                                     const double *gathered, int n_local, const coevo_ga_adapt_args *adapt, void *stream)
+{
+    if (!adapt || !adapt->rewards || !adapt->gen_dev || !adapt->hist || !adapt->sig_hist || !adapt->sigma64 || !adapt->sigma32 ||
+        adapt->cap <= 0 || adapt->eval_first_game < 0)
+        return COEVO_ERR_ARG;
+    if (gathered && (n_local <= 0 || pop % n_local)) return COEVO_ERR_ARG;
+    return ga_select_launch(roles, n_roles, pop, gathered ? 1 : games_per_individual, hof, gathered, n_local, adapt, stream);
 }
 
 // The selection of a population-sharded run straight off the all-gathered buffer: gathered[rank][role][j][0..2] = the
@@ -411,11 +443,11 @@ extern "C" int coevo_ga_select_gathered(const coevo_ga_select_role *roles, int n
                                         const double *gathered, int n_local, void *stream)
 {
     if (!gathered || n_local <= 0 || pop % n_local) return COEVO_ERR_ARG;
-    return ga_select_launch(roles, n_roles, pop, 1, hof, gathered, n_local, stream);
+    return ga_select_launch(roles, n_roles, pop, 1, hof, gathered, n_local, nullptr, stream);
 }
 
 static int ga_select_launch(const coevo_ga_select_role *roles, int n_roles, int pop, int games_per_individual, int hof,
-                            const double *gathered, int n_local, void *stream)
+                            const double *gathered, int n_local, const coevo_ga_adapt_args *adapt, void *stream)
 {
     if (!roles || n_roles < 1 || n_roles > 3 || pop <= 0 || pop > 4096 || hof <= 0 || games_per_individual <= 0)
         return COEVO_ERR_ARG;
@@ -429,7 +461,10 @@ static int ga_select_launch(const coevo_ga_select_role *roles, int n_roles, int 
     }
     a.gathered = gathered; a.n_local = n_local; a.n_roles = n_roles;
     a.pop = pop; a.games_per_individual = games_per_individual; a.hof = hof;
-    hipLaunchKernelGGL(coevo::ga_select_kernel, dim3(n_roles, (pop + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    a.n_roles_launched = n_roles;
+    if (adapt) { a.adapt = *adapt; a.with_adapt = 1; }
+    hipLaunchKernelGGL(coevo::ga_select_kernel, dim3(n_roles + (adapt ? 1 : 0), (pop + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, a);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

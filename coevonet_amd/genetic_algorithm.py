@@ -483,12 +483,33 @@ class GAEngine:
                                        L._p(self.order[r]), L._p(self.best_dist[r]), game_first_of(ri), RET_SLOT[r])
         L.call("coevo_ga_select", roles, 3, self.pop, games_per_individual, self.hof)
 
-    def _promote_roles(self, elites_from_pop, best_to_pop0):
+    def _adapt_args(self, with_prev=False):
+        mn, mx, adaptive = self.loop_args
+        return L.GaAdaptArgs(L._p(self.ro.rewards), L._p(self.gen_dev), L._p(self.hist), L._p(self.sig_hist),
+                             L._p(self.sigma64), L._p(self.sigma32), L._p(self.sigma32_prev) if with_prev else None, mn, mx,
+                             self.n_main, self.cap, adaptive, 0)
+
+    def _select_adapt_roles(self, rewards_ptr_of, game_first_of, games_per_individual, gathered=None, with_prev=False):
+        """selection of the three roles + the sigma rule (evaluation means, adaptive mutation power) in ONE launch"""
+        roles = (L.GaSelectRole * 3)()
+        for ri, r in enumerate(ROLES):
+            roles[ri] = L.GaSelectRole(None if gathered is not None else L._p(self.dist[r]),
+                                       None if gathered is not None else rewards_ptr_of(ri), L._p(self.div[r]),
+                                       L._p(self.fitness[r]), L._p(self.order[r]), L._p(self.best_dist[r]),
+                                       0 if gathered is not None else game_first_of(ri), RET_SLOT[r])
+        ad = self._adapt_args(with_prev)
+        L.call("coevo_ga_select_adapt", roles, 3, self.pop, games_per_individual, self.hof,
+               L._p(gathered) if gathered is not None else None, self.n_local if gathered is not None else 0, L.C.byref(ad))
+
+    def _promote_roles(self, elites_from_pop, best_to_pop0, tick=False):
         roles = (L.GaPromoteRole * 3)()
         for ri, r in enumerate(ROLES):
             roles[ri] = L.GaPromoteRole(self._ptr(r, "pop"), self._ptr(r, "hof"), self._ptr(r, "elite"),
                                         L._p(self.order[r]), ROLE_D[r], 1 if elites_from_pop else 0,
                                         1 if best_to_pop0 else 0, 0)
+        if tick:   # + the generation counter's increment: the last launch of the generation's tail
+            L.call("coevo_ga_promote_tick", roles, 3, self.E, self.hof, L._p(self.gen_dev))
+            return
         L.call("coevo_ga_promote", roles, 3, self.E, self.hof)
 
     def enqueue_generation(self):
@@ -518,17 +539,20 @@ class GAEngine:
         g = L._p(self.gen_dev)
         mn, mx, adaptive = self.loop_args
         if self.fused_tail:
-            self._select_roles(lambda ri: L._p(ro.rewards), lambda ri: ri * per_phase, self.hof)
+            # selection + sigma rule in one launch, promotion (+ the counter's tick when nothing follows) in one: the tail of a
+            # pipelined generation is closing step -> these two (round 4: five launches)
+            self._select_adapt_roles(lambda ri: L._p(ro.rewards), lambda ri: ri * per_phase, self.hof)
+            self._promote_roles(elites_from_pop=True, best_to_pop0=True, tick=not (self.pop > 1 and breed))
+            if not (self.pop > 1 and breed):
+                return
         else:
             for ph, r in enumerate(ROLES):
                 L.call("coevo_sharing_score", L._p(self.dist[r]), self.pop, L._p(self.div[r]))
                 L.call("coevo_ga_fitness", L._p(ro.rewards), ph * per_phase, self.pop, self.hof, self.hof, RET_SLOT[r],
                        L._p(self.div[r]), L._p(self.fitness[r]))
                 L.call("coevo_rank_desc", L._p(self.fitness[r]), self.pop, L._p(self.order[r]))
-        L.call("coevo_ga_adapt_sigma", L._p(ro.rewards), self.n_main, g, L._p(self.hist), L._p(self.sig_hist), self.cap,
-               L._p(self.sigma64), L._p(self.sigma32), mn, mx, adaptive)
-        if self.fused_tail:
-            self._promote_roles(elites_from_pop=True, best_to_pop0=True)
+            L.call("coevo_ga_adapt_sigma", L._p(ro.rewards), self.n_main, g, L._p(self.hist), L._p(self.sig_hist), self.cap,
+                   L._p(self.sigma64), L._p(self.sigma32), mn, mx, adaptive)
         for ri, r in enumerate(ROLES):
             D = ROLE_D[r]
             if not self.fused_tail:
@@ -591,7 +615,7 @@ class GAEngine:
                  base + ph * self.pop * self.hof + lo_k * self.hof) for ph in range(3)]
         if k == self.K - 1 and gen > 0:
             segs.append((self.n_main, N_EVAL, self._ordinal_base(gen - 1) + M))
-        self.ro.reset_segments(segs)
+        self.ro.reset_segments(segs, arm=(k, self.n_cycles))   # (+ the cohort's clock stamps, when launches are timed)
 
     def flush_breeding(self):
         """the pipelined loop breeds generation g+1's population at the start of call g+1; anything that reads the
@@ -650,7 +674,7 @@ class GAEngine:
                 if self._breeding_pending:
                     self._breed_cohort(k, gen - 1)
                 self._reset_cohort(k, gen)
-                ro.enqueue_cohort(k, self.n_cycles, s)
+                ro.enqueue_cohort(k, self.n_cycles, s, armed=True)
             if k:
                 self._cohort_done[k].record(s)
         self._breeding_pending = False
@@ -700,12 +724,12 @@ class GAEngine:
         segs = [(ph * per_phase, per_phase, base + ph * self.pop * self.hof + self.lo * self.hof) for ph in range(3)]
         if gen > 0:
             segs.append((self.n_main, N_EVAL, self._ordinal_base(gen - 1) + M))
-        ro.reset_segments(segs)   # one launch (three phases + the evaluation games)
+        ro.reset_segments(segs, arm=(0, self.n_cycles))   # one launch (three phases + the evaluation games + clock stamps)
         if self._packed_exchange():
-            ro.enqueue(self.n_cycles, final=False)
+            ro.enqueue(self.n_cycles, final=False, armed=True)
             ro.enqueue_final_step(self.n_cycles, pack=self._pack_args())
         else:
-            ro.enqueue(self.n_cycles)
+            ro.enqueue(self.n_cycles, armed=True)
         self._sharded_tail(gen, breed=True)
 
     def _sharded_tail(self, gen, breed):
@@ -743,13 +767,10 @@ class GAEngine:
         g = L._p(self.gen_dev)
         mn, mx, adaptive = self.loop_args
         if packed:
-            # selection off the gathered buffer; promotion with the elites rebuilt in the same launch from the sigma their
-            # children were bred with (sigma32 BEFORE this generation's sigma rule: no copy of the previous value needed)
-            roles = (L.GaSelectRole * 3)()
-            for ri, r in enumerate(ROLES):
-                roles[ri] = L.GaSelectRole(None, None, L._p(self.div[r]), L._p(self.fitness[r]), L._p(self.order[r]),
-                                           L._p(self.best_dist[r]), 0, RET_SLOT[r])
-            L.call("coevo_ga_select_gathered", roles, 3, self.pop, self.hof, L._p(self.pack_all), self.n_local)
+            # selection off the gathered buffer + the sigma rule (which also saves the sigma the evaluated children were bred
+            # with) in one launch; promotion with the elites rebuilt from that sigma in one; then the rank's children and
+            # their distances (+ the counter's tick): four launches behind the collective
+            self._select_adapt_roles(None, None, 1, gathered=self.pack_all, with_prev=True)
             pr = (L.GaPromoteRole * 3)()
             for ri, r in enumerate(ROLES):
                 pr[ri] = L.GaPromoteRole(self._ptr(r, "pop"), self._ptr(r, "hof"), self._ptr(r, "elite"), L._p(self.order[r]),
@@ -757,10 +778,8 @@ class GAEngine:
             if gen == 0:   # generation 0's population is the host-initialised one, present on every rank
                 L.call("coevo_ga_promote", pr, 3, self.E, self.hof)
             else:
-                L.call("coevo_ga_promote_rebuild", pr, 3, self.E, self.hof, L._p(self.sigma32), self.philox_seed,
+                L.call("coevo_ga_promote_rebuild", pr, 3, self.E, self.hof, L._p(self.sigma32_prev), self.philox_seed,
                        0 if gen_from_device else (gen - 1) * 4, g if gen_from_device else None)
-            L.call("coevo_ga_adapt_sigma", L._p(ro.rewards), self.n_main, g, L._p(self.hist), L._p(self.sig_hist), self.cap,
-                   L._p(self.sigma64), L._p(self.sigma32), mn, mx, adaptive)
             if breed:   # K = 1: the rank's children now, their distances + the counter's tick in the last launch
                 self._breed_cohort(0, gen, gen_dev=g if gen_from_device else None, tick=True)
             else:

@@ -67,7 +67,7 @@ class RolloutDesc(C.Structure):
                 ("rewards", C.c_void_p), ("pos_first", C.c_int32), ("n_cohorts", C.c_int32),
                 ("state_alt", C.c_void_p), ("actions_by_game", C.c_void_p), ("light_stamps", C.c_void_p),
                 ("heavy_begin", C.c_void_p), ("light_begin", C.c_void_p),
-                ("merged", C.c_int32), ("concurrent_hint", C.c_int32)]
+                ("merged", C.c_int32), ("concurrent_hint", C.c_int32), ("stamps_armed", C.c_int32), ("reserved", C.c_int32)]
 
 
 class HostCohort(C.Structure):        # coevo_host_cohort
@@ -105,6 +105,13 @@ class GaSelectRole(C.Structure):
                 ("order", C.c_void_p), ("best_dist", C.c_void_p), ("game_first", C.c_int32), ("slot", C.c_int32)]
 
 
+class GaAdaptArgs(C.Structure):     # coevo_ga_adapt_args
+    _fields_ = [("rewards", C.c_void_p), ("gen_dev", C.c_void_p), ("hist", C.c_void_p), ("sig_hist", C.c_void_p),
+                ("sigma64", C.c_void_p), ("sigma32", C.c_void_p), ("sigma32_prev", C.c_void_p), ("sig_min", C.c_double),
+                ("sig_max", C.c_double), ("eval_first_game", C.c_int32), ("cap", C.c_int32), ("adaptive", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class GaPromoteRole(C.Structure):
     _fields_ = [("pop", C.c_void_p), ("hof", C.c_void_p), ("elite", C.c_void_p), ("order", C.c_void_p),
                 ("D", C.c_int32), ("elites_from_pop", C.c_int32), ("best_to_pop0", C.c_int32), ("reserved", C.c_int32)]
@@ -128,6 +135,11 @@ _SIGS = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "coevo_mpe_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, PCG64State, C.c_uint64, C.c_void_p]),
     "coevo_mpe_reset_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, PCG64State, C.c_void_p]),
+    "coevo_mpe_reset_multi_arm": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, PCG64State, C.c_void_p, C.c_int,
+                                            C.c_void_p]),
+    "coevo_ga_select_adapt": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                        C.c_void_p]),
+    "coevo_ga_promote_tick": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "coevo_fc_perturb_dist_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]),
     "coevo_fc_distance_finalize_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "coevo_mpe_reset_gen": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, PCG64State, C.c_int64, C.c_void_p,

@@ -269,9 +269,16 @@ class DeviceRollout:
         L.call("coevo_mpe_reset", L._p(self.state), self.plan.n_games, int(game_first), int(n_games), self.rng,
                int(first_ordinal))
 
-    def reset_segments(self, segs):
-        """several (game_first, n_games, first_ordinal) resets in ONE launch (<= 4 segments)"""
+    def reset_segments(self, segs, arm=None):
+        """several (game_first, n_games, first_ordinal) resets in ONE launch (<= 4 segments).  arm = (cohort k, n_cycles):
+        the launch also re-arms the clock stamps of that cohort's timed chain (time_light), which then needs no launch of
+        its own for it - the caller passes armed=True to the enqueue that follows"""
         arr = (L.ResetSeg * len(segs))(*[L.ResetSeg(int(a), int(b), int(c)) for a, b, c in segs])
+        if arm is not None and self.time_light:
+            k, n_cycles = arm
+            L.call("coevo_mpe_reset_multi_arm", L._p(self.state), self.plan.n_games, _ct.cast(arr, _ct.c_void_p), len(segs),
+                   self.rng, self.stamps.data_ptr() + 16 * L.STAMP_SLOTS * int(k) * int(n_cycles), int(n_cycles) * L.STAMP_SLOTS)
+            return
         L.call("coevo_mpe_reset_multi", L._p(self.state), self.plan.n_games, _ct.cast(arr, _ct.c_void_p), len(segs), self.rng)
 
     def run(self, n_cycles):
@@ -302,11 +309,13 @@ class DeviceRollout:
         self.desc.n_cycles = n_cycles
         L.call("coevo_mpe_rollout", L.C.byref(self.desc), ctx, 1 if timed else 0)
 
-    def enqueue(self, n_cycles, final=True):
+    def enqueue(self, n_cycles, final=True, armed=False):
         """plain enqueue on the current stream (no graph of its own): for callers that capture a larger graph.
-        final=False: without the closing step (the caller runs enqueue_final_step itself, e.g. with its all-gather pack)"""
+        final=False: without the closing step (the caller runs enqueue_final_step itself, e.g. with its all-gather pack);
+        armed: the reset launch in front of it re-armed the clock stamps (reset_segments(arm=...))"""
         self.desc.light_stamps = L._p(self.stamps) if self.time_light else None
         self.desc.n_cycles = int(n_cycles)
+        self.desc.stamps_armed = 1 if (armed and self.time_light) else 0
         keep = self.desc.rewards
         if not final:
             assert self.desc.state_alt, "only the fused-step rollout can leave its books open"
@@ -315,10 +324,11 @@ class DeviceRollout:
             L.call("coevo_mpe_rollout", L.C.byref(self.desc), self.ctx if (self.overlap or self.n_cohorts > 1) else None, 0)
         finally:
             self.desc.rewards = keep
+            self.desc.stamps_armed = 0
         if self.time_light:
             self._pending_stamps = int(n_cycles)
 
-    def enqueue_cohort(self, k, n_cycles, stream):
+    def enqueue_cohort(self, k, n_cycles, stream, armed=False):
         """the cycle chain of cohort k alone on `stream` (a torch stream), without the closing step: callers that breed
         and reset cohort by cohort run one such call per cohort on its own stream, then enqueue_final_step() once"""
         assert self.n_cohorts > 1 and self.desc.merged
@@ -337,6 +347,7 @@ class DeviceRollout:
         d.n_cycles = int(n_cycles)
         d.rewards = None
         d.light_stamps = (self.stamps.data_ptr() + 16 * L.STAMP_SLOTS * k * int(n_cycles)) if self.time_light else None
+        d.stamps_armed = 1 if (armed and self.time_light) else 0
         L._check(L.load().coevo_mpe_rollout(L.C.byref(d), self.ctx, 0, stream.cuda_stream), "coevo_mpe_rollout")
         if self.time_light:
             self._pending_stamps = int(n_cycles)

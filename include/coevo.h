@@ -115,6 +115,10 @@ int coevo_mpe_reset(double *state, int n_games, int game_first, int count, coevo
 typedef struct { int32_t game_first, count; uint64_t first_ordinal; } coevo_reset_seg;
 int coevo_mpe_reset_multi(double *state, int n_games, const coevo_reset_seg *segs /* host */, int n_segs,
                           coevo_pcg64 rng, void *stream);
+/* ... that also re-arms n_stamps clock-stamp slot pairs ({UINT64_MAX, 0}) for the timed rollout it precedes
+ * (coevo_rollout_desc.light_stamps with stamps_armed = 1) */
+int coevo_mpe_reset_multi_arm(double *state, int n_games, const coevo_reset_seg *segs /* host */, int n_segs,
+                              coevo_pcg64 rng, uint64_t *stamps, int n_stamps, void *stream);
 /* the same with the generation taken from a device counter: first ordinal = first_ordinal + (*gen_dev) *
  * ordinals_per_gen (clamped at 0), so a captured hipGraph of a whole generation can be replayed unchanged */
 int coevo_mpe_reset_gen(double *state, int n_games, int game_first, int count, coevo_pcg64 rng, int64_t first_ordinal,
@@ -262,6 +266,9 @@ typedef struct {
                                     instead of the shared-opponent launch beside / before the per-individual one */
     int32_t concurrent_hint;     /* how many such rollouts the caller runs side by side on other streams (one call per
                                     cohort); 0 = none.  Only sizes the merged launch (coevo_mpe_policy_cycle_merged) */
+    int32_t stamps_armed;        /* != 0: the caller has re-armed light_stamps to {UINT64_MAX, 0} itself (coevo_mpe_reset_multi_arm,
+                                    in the reset launch that precedes the rollout anyway): no launch of its own for it */
+    int32_t reserved;
 } coevo_rollout_desc;
 #define COEVO_MAX_COHORTS 8
 void *coevo_rollout_ctx_create(int n_timing_pairs);
@@ -412,6 +419,15 @@ int coevo_ga_select(const coevo_ga_select_role *roles, int n_roles, int pop, int
  * rank i / n_local, j = i % n_local.  The roles' `dist` / `rewards` are not read. */
 int coevo_ga_select_gathered(const coevo_ga_select_role *roles, int n_roles, int pop, int hof, const double *gathered,
                              int n_local, void *stream);
+/* the arguments of coevo_ga_adapt_sigma as a block, + sigma32_prev: NULL, or device [3] that receives sigma32 as it was BEFORE
+ * the rule ran (what the children evaluated in this generation were bred with: coevo_ga_promote_rebuild's sigma) */
+typedef struct coevo_ga_adapt_args {
+    const double *rewards; const int32_t *gen_dev; double *hist; double *sig_hist; double *sigma64; float *sigma32;
+    float *sigma32_prev; double sig_min, sig_max; int32_t eval_first_game, cap, adaptive, reserved;
+} coevo_ga_adapt_args;
+/* coevo_ga_select (gathered == NULL) or coevo_ga_select_gathered with coevo_ga_adapt_sigma's work in the same launch */
+int coevo_ga_select_adapt(const coevo_ga_select_role *roles, int n_roles, int pop, int games_per_individual, int hof,
+                          const double *gathered, int n_local, const coevo_ga_adapt_args *adapt, void *stream);
 /* Promotion of up to three roles in ONE launch (replaces five coevo_fc_gather launches per role;
  * genetic_algorithm.py:262-275): elite[k] = pop[order[k]] (k < E <= 8; skipped when elites_from_pop == 0: the elites
  * are already in `elite`, e.g. rebuilt by coevo_fc_rebuild_elites), hof.pop(0); hof.append(elite[0]) (hof <= 16 nets,
@@ -422,6 +438,8 @@ typedef struct coevo_ga_promote_role {
     int32_t D, elites_from_pop, best_to_pop0, reserved;
 } coevo_ga_promote_role;
 int coevo_ga_promote(const coevo_ga_promote_role *roles, int n_roles, int E, int hof, void *stream);
+/* ... with coevo_counter_add(counter, 1) in the same launch: the last launch of a device-resident generation's tail */
+int coevo_ga_promote_tick(const coevo_ga_promote_role *roles, int n_roles, int E, int hof, int32_t *counter, void *stream);
 /* ... with the elites REBUILT in the same launch (roles with elites_from_pop == 0; `order` required): elite[k] = individual
  * order[k] of the generation just evaluated = the unchanged best (id 0: old elite 0) or child c = id - 1 = old elite[c % E] +
  * sigma[role] * noise(stream (c, stream_hi_prev + role [+ 4 (g - 1) with gen_dev])), regenerated in place from the OLD elites

@@ -254,6 +254,8 @@ def test_job_struct_layouts_match_the_header():
     assert (C.sizeof(L.PerturbJob), C.sizeof(L.FinalizeJob), C.sizeof(L.ResetSeg)) == (72, 40, 16)
     assert L.PerturbJob.child_first.offset == 48 and L.FinalizeJob.n_blocks.offset == 24
     assert L.ResetSeg.first_ordinal.offset == 8
+    assert C.sizeof(L.GaAdaptArgs) == 88 and L.GaAdaptArgs.sig_min.offset == 56 and L.GaAdaptArgs.eval_first_game.offset == 72
+    assert C.sizeof(L.RolloutDesc) == 176 and L.RolloutDesc.stamps_armed.offset == 168
 
 
 def test_bench_reads_tracked_pmc_traffic():

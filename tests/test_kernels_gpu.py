@@ -690,6 +690,58 @@ def test_packed_exchange_launches_equal_separate_launches(world, n_local, hof, E
             L.call("coevo_fc_distance_finalize_multi", ct.cast(fj, ct.c_void_p), 3)
     torch.cuda.synchronize()
     assert torch.equal(d0, d1) and cnt.item() == 42 and d0[0, 0].item() == 4.5
+    # ---- selection + sigma rule in one launch == the two launches; promotion + tick; reset + stamp re-arm
+    cap, genv = 40, 14
+    ev = torch.from_numpy(rng.normal(size=(n_local * 3 + 10, 3))).to(DEV)
+    res = []
+    for fusedf in (False, True):
+        hist = torch.from_numpy(np.random.default_rng(9).normal(size=(3, cap))).to(DEV)
+        sigh = torch.zeros(3, cap, dtype=torch.float64, device=DEV)
+        s64 = torch.tensor([0.05, 0.08, 0.03], dtype=torch.float64, device=DEV)
+        s32, s32p = torch.zeros(3, device=DEV), torch.full((3,), -1.0, device=DEV)
+        s32.copy_(s64.float())
+        gd = torch.tensor([genv], dtype=torch.int32, device=DEV)
+        sel = (L.GaSelectRole * 3)()
+        keep = []
+        for ri in range(3):
+            div, fit = torch.zeros(1, device=DEV), torch.zeros(pop, device=DEV)
+            order, best = torch.zeros(pop, dtype=torch.int32, device=DEV), torch.zeros(1, device=DEV)
+            sel[ri] = L.GaSelectRole(None, None, L._p(div), L._p(fit), L._p(order), L._p(best), 0, ri)
+            keep.append((div, fit, order, best))
+        if fusedf:
+            ad = L.GaAdaptArgs(L._p(ev), L._p(gd), L._p(hist), L._p(sigh), L._p(s64), L._p(s32), L._p(s32p), 0.02, 0.1,
+                               3 * n_local, cap, 1, 0)
+            L.call("coevo_ga_select_adapt", sel, 3, pop, 1, hof, L._p(gathered), n_local, L.C.byref(ad))
+        else:
+            L.call("coevo_ga_select_gathered", sel, 3, pop, hof, L._p(gathered), n_local)
+            s32p.copy_(s32)
+            L.call("coevo_ga_adapt_sigma", L._p(ev), 3 * n_local, L._p(gd), L._p(hist), L._p(sigh), cap, L._p(s64), L._p(s32),
+                   0.02, 0.1, 1)
+        torch.cuda.synchronize()
+        res.append([t.clone() for k in keep for t in k] + [hist, sigh, s64, s32, s32p])
+    assert all(torch.equal(x, y) for x, y in zip(*res))
+    D = 8
+    stride = L.fc_slab_stride(D)
+    order = torch.from_numpy(rng.permutation(pop).astype(np.int32)).to(DEV)
+    base = [torch.from_numpy(rng.normal(size=k * stride).astype(np.float32)).to(DEV) for k in (pop, hof, E)]
+    a_, b_ = [x.clone() for x in base], [x.clone() for x in base]
+    cnt2 = torch.tensor([7], dtype=torch.int32, device=DEV)
+    L.call("coevo_ga_promote", (L.GaPromoteRole * 1)(L.GaPromoteRole(L._p(a_[0]), L._p(a_[1]), L._p(a_[2]), L._p(order), D, 1, 1, 0)),
+           1, E, hof)
+    L.call("coevo_ga_promote_tick", (L.GaPromoteRole * 1)(L.GaPromoteRole(L._p(b_[0]), L._p(b_[1]), L._p(b_[2]), L._p(order), D, 1, 1, 0)),
+           1, E, hof, L._p(cnt2))
+    torch.cuda.synchronize()
+    assert all(torch.equal(x, y) for x, y in zip(a_, b_)) and cnt2.item() == 8
+    st_a, st_b = torch.zeros(L.MPE_STATE_DOUBLES, n, dtype=torch.float64, device=DEV), torch.zeros(L.MPE_STATE_DOUBLES, n, dtype=torch.float64, device=DEV)
+    segs = (L.ResetSeg * 2)(L.ResetSeg(0, n - 10, 1000), L.ResetSeg(n - 10, 10, 5))
+    rngst = L.PCG64State.from_seed(1870300)
+    stamps = torch.full((3 * L.STAMP_SLOTS, 2), 5, dtype=torch.int64, device=DEV)
+    L.call("coevo_mpe_reset_multi", L._p(st_a), n, ct.cast(segs, ct.c_void_p), 2, rngst)
+    L.call("coevo_mpe_reset_multi_arm", L._p(st_b), n, ct.cast(segs, ct.c_void_p), 2, rngst, L._p(stamps), 2 * L.STAMP_SLOTS)
+    torch.cuda.synchronize()
+    assert torch.equal(st_a, st_b)
+    armed = stamps[:2 * L.STAMP_SLOTS]
+    assert bool((armed[:, 0] == -1).all()) and bool((armed[:, 1] == 0).all()) and bool((stamps[2 * L.STAMP_SLOTS:] == 5).all())
 
 
 def test_multi_job_launches_equal_per_role_launches():
