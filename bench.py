@@ -22,6 +22,9 @@ import time
 # cohort stream of a later workload in the same process landed on the caller's queue and its launches serialised (cfg5 in
 # the `extra` block: 8.3 instead of 10.1 generations/s).  Read by the runtime when it starts: set before torch loads it.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# ... and streams take a free hardware queue when they have work instead of keeping the one dealt at creation: without it
+# every stream created after a process's first hipGraph launch shares queues (coevonet_amd/__init__.py)
+os.environ.setdefault("DEBUG_HIP_DYNAMIC_QUEUES", "1")
 
 import numpy as np
 import torch
@@ -237,6 +240,7 @@ def main():
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "noise": f"philox4x32-{L.load().coevo_noise_rounds()}", "coevo_version": L.load().coevo_version(),
                 "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                "hip_dynamic_queues": os.environ.get("DEBUG_HIP_DYNAMIC_QUEUES"),
                 "dist_backend": (torch.distributed.get_backend() if real_world > 1 else None),
                 "rccl_ranks": (torch.distributed.get_world_size() if real_world > 1 else 1)})
     if rehearsal:

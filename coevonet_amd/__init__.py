@@ -14,3 +14,12 @@ if "GPU_MAX_HW_QUEUES" not in _os.environ:
         _w.warn("coevonet_amd: the HIP runtime started before this import, so GPU_MAX_HW_QUEUES=8 cannot take effect; "
                 "export it before the process starts (cohort streams otherwise share hardware queues)")
     _os.environ["GPU_MAX_HW_QUEUES"] = "8"
+# DEBUG_HIP_DYNAMIC_QUEUES: with the runtime's default (static) mapping a stream keeps the hardware queue it was dealt when
+# it was created; the first hipGraph launch of a process creates the graph executor's own parallel streams, and streams
+# created after that share hardware queues - every operation on them queues behind its neighbours' (~9 us per operation: the
+# host-cores env mode after the device-resident loop ran 233-303 instead of 440-455 generations/s, the device loop after a
+# host-mode run 395 instead of 585; bisected to ONE replayed graph in round 4, the mechanism and this switch found in round 5:
+# profiles/r05_experiments.md).  With dynamic queues a stream takes a free hardware queue when it has work: both orders run
+# at a fresh process's rate.  Same rule as above: read when the runtime starts.
+if "DEBUG_HIP_DYNAMIC_QUEUES" not in _os.environ:
+    _os.environ["DEBUG_HIP_DYNAMIC_QUEUES"] = "1"

@@ -13,7 +13,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # the profiler starts the HIP runtime before python runs: the package's own setdefault would come too late
-export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8}
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8} DEBUG_HIP_DYNAMIC_QUEUES=${DEBUG_HIP_DYNAMIC_QUEUES:-1}
 run() {  # name, bench args...
     local name=$1; shift
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -- python3 $ROOT/bench.py --no-extra --no-cpu-baseline "$@" \
