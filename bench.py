@@ -22,9 +22,6 @@ import time
 # cohort stream of a later workload in the same process landed on the caller's queue and its launches serialised (cfg5 in
 # the `extra` block: 8.3 instead of 10.1 generations/s).  Read by the runtime when it starts: set before torch loads it.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-# ... and streams take a free hardware queue when they have work instead of keeping the one dealt at creation: without it
-# every stream created after a process's first hipGraph launch shares queues (coevonet_amd/__init__.py)
-os.environ.setdefault("DEBUG_HIP_DYNAMIC_QUEUES", "1")
 
 import numpy as np
 import torch
@@ -448,7 +445,7 @@ def L_load():
 def pmc_traffic(workload, kernel_substr):
     """HBM bytes per launch of a kernel from the tracked PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter
     per pass, gfx950 correction applied: tools/pmc_traffic_all.py), newest round first: (bytes, source) or (None, None)"""
-    for tag in ("r04", "r03"):
+    for tag in ("r05", "r04", "r03"):
         path = os.path.join(REPO, "profiles", f"{tag}_pmc_hbm_traffic.json")
         if not os.path.exists(path):
             continue
@@ -516,7 +513,7 @@ def extras(a, ctx, dev):
         cmd = [sys.executable, os.path.abspath(__file__), "--env", "host", "--no-extra", "--no-cpu-baseline"] + list(more)
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, check=True)
         return json.loads(p.stdout.decode().strip().splitlines()[-1])
-    leg("cfg2_host_env", lambda: host_leg("--steps", "20", "--warmup", "3"))
+    leg("cfg2_host_env", lambda: host_leg("--steps", "40", "--warmup", "3"))
     leg("cfg3_host_env", lambda: host_leg("--workload", "es", "--steps", "5", "--warmup", "2"))
     # the metric's own split (pop 200 over 2 / 4 / 8 GPUs): what ONE rank of it does on this GPU (dist.ShardRehearsal)
     for n in (2, 4, 8):

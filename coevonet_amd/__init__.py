@@ -14,12 +14,13 @@ if "GPU_MAX_HW_QUEUES" not in _os.environ:
         _w.warn("coevonet_amd: the HIP runtime started before this import, so GPU_MAX_HW_QUEUES=8 cannot take effect; "
                 "export it before the process starts (cohort streams otherwise share hardware queues)")
     _os.environ["GPU_MAX_HW_QUEUES"] = "8"
-# DEBUG_HIP_DYNAMIC_QUEUES: with the runtime's default (static) mapping a stream keeps the hardware queue it was dealt when
-# it was created; the first hipGraph launch of a process creates the graph executor's own parallel streams, and streams
-# created after that share hardware queues - every operation on them queues behind its neighbours' (~9 us per operation: the
-# host-cores env mode after the device-resident loop ran 233-303 instead of 440-455 generations/s, the device loop after a
-# host-mode run 395 instead of 585; bisected to ONE replayed graph in round 4, the mechanism and this switch found in round 5:
-# profiles/r05_experiments.md).  With dynamic queues a stream takes a free hardware queue when it has work: both orders run
-# at a fresh process's rate.  Same rule as above: read when the runtime starts.
-if "DEBUG_HIP_DYNAMIC_QUEUES" not in _os.environ:
-    _os.environ["DEBUG_HIP_DYNAMIC_QUEUES"] = "1"
+# DEBUG_HIP_DYNAMIC_QUEUES (NOT set here).  With the runtime's default (static) mapping a stream keeps the hardware queue it was
+# dealt when it was created; the first hipGraph launch of a process creates the graph executor's own parallel streams, and
+# streams created after that share hardware queues - every operation on them queues behind its neighbours' (~9 us per
+# operation: the host-cores env mode after the device-resident loop ran 233-303 instead of 440-455 generations/s; bisected to
+# ONE replayed graph in round 4, mechanism found in round 5: profiles/r05_experiments.md section 1).  DEBUG_HIP_DYNAMIC_QUEUES=1
+# (a stream takes a free hardware queue when it has work) removes the cliff - both orders then run at a fresh process's rate -
+# but it is a debug switch of the runtime: a long process that builds and tears down many engines (the DeepQN GPU tests, 34
+# in one process) died with a segmentation fault inside hipDeviceSynchronize under it, twice out of two, and never without.
+# So: export it yourself for a process that runs the host-cores mode after a graph-replaying mode and is short-lived, or do
+# what bench.py does - run the host-cores mode in a process of its own.

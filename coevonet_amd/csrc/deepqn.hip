@@ -56,6 +56,12 @@ namespace coevo {
 #ifndef DQ_FC1_NB_MANY
 #define DQ_FC1_NB_MANY 2   // ... of a launch with more waves than the chip has SIMDs (fewer registers: several waves per SIMD)
 #endif
+#ifndef DQ_FC1_TQ
+#define DQ_FC1_TQ 2    // tiled fc1: super-quads (16 k: four 16-byte loads per lane, one per 16-output tile) per chunk of the ring
+#endif
+#ifndef DQ_FC1_TNB
+#define DQ_FC1_TNB 7   // ... and chunks in the ring (196 / DQ_FC1_TQ a multiple of it): 6 x 8 KiB in flight per wave
+#endif
 #ifndef DQ_WPE
 #define DQ_WPE 6   // waves per SIMD the register budget is set for: 3 workgroups x 8 waves / 4 SIMDs
 #endif
@@ -70,13 +76,13 @@ namespace coevo {
 #endif
 
 
-__global__ __launch_bounds__(256) void dqn_pack_kernel(const float *flat, float *slab, int C, int n)
+__global__ __launch_bounds__(256) void dqn_pack_kernel(const float *flat, float *slab, int C, int n, int fc1_tiled)
 {
     const DqnLayout L = dqn_layout(C, n);
     const int64_t P = dqn_param_count(C, n);
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= L.stride) return;
-    const int64_t f = dqn_slab_to_flat(s, C, n);
+    const int64_t f = dqn_slab_to_flat(s, C, n, fc1_tiled);
     slab[(int64_t)blockIdx.y * L.stride + s] = (f >= 0) ? flat[(int64_t)blockIdx.y * P + f] : 0.0f;
 }
 
@@ -722,6 +728,124 @@ __global__ __launch_bounds__(64, (HALF || NB <= DQ_FC1_NB_MANY) ? 2 : 1) void dq
 #endif
 }
 
+// fc1 + ReLU over the TILED fc1 block (dqn_common.hip.h: the layout of a Co-GA engine, whose tasks carry 10 / 16 rows): grid
+// (task, 8), one wavefront per workgroup as dqn_fc1_kernel, but the wave's 64 outputs are four 16-column tiles on
+// v_mfma_f32_16x16x4 (bit-identical to the sequential-k chain: tools/mfma16_chain_probe.hip).  Per super-quad (16 k): four
+// 16-byte weight loads per lane - piece j of lane (c, kk) of tile T IS the B operand of k-quad 4 Q + j - one ds_read_b128 of
+// the activations (staged per chunk as [Q][kk][row][j]: lane (c = row, kk) reads its four A operands in one piece) and sixteen
+// matrix instructions: no vector instruction touches an operand.  Round 4 found the streamed form's 16-row waves bound by
+// their own matrix issue (12 544 v_mfma_f32_4x4x1 at 13.6 cycles for a lone wave = 71 us of an 84 us wave life); here a wave
+// issues 3 136 instructions of 32 cycles on four independent accumulators = 43 us, and the launch sits on its weight stream.
+template <int NB, bool SHARED_NET>
+__device__ __forceinline__ void dqn_fc1_tiled_body(const float *net, const DqnLayout &L, const coevo_dqn_task &task,
+                                                   const float *act, float *hid, float (*xs)[DQ_FC1_TQ][4][16][4], int ob, int l)
+{
+    constexpr int CQ = DQ_FC1_TQ, NSQ = 196, NCHUNK = NSQ / CQ;
+    static_assert(NSQ % CQ == 0 && NCHUNK % NB == 0 && NB >= 2, "whole rounds of the ring");
+    constexpr int XI = (16 * 4 * CQ + 63) / 64;   // activation pieces (row, k-quad) of a chunk per lane
+    typedef float f32x4_nt __attribute__((ext_vector_type(4))) __attribute__((unused));
+    const int nrows = task.n_rows, c = l & 15, kk = l >> 4;
+    f32x4_acc acc[4];
+#pragma unroll
+    for (int T = 0; T < 4; ++T) {
+        const float bb = net[L.bf + 64 * ob + 16 * T + c];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[T][i] = bb;
+    }
+    const float4 *wp = reinterpret_cast<const float4 *>(net + L.wf) + (size_t)ob * NSQ * 4 * 64 + l;
+    const float *arow = act + (size_t)task.row_begin * DQ_FC1_IN;
+    float4 wv[NB][CQ][4], xr[NB][XI];
+    auto issue = [&](float4 (&w)[CQ][4], float4 (&x)[XI], int sq) {
+#pragma unroll
+        for (int q = 0; q < CQ; ++q)
+#pragma unroll
+            for (int T = 0; T < 4; ++T) {
+                const float4 *p = wp + (size_t)((sq + q) * 4 + T) * 64;
+                if constexpr (SHARED_NET) {
+                    w[q][T] = *p;
+                } else {
+                    const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt *>(p));
+                    w[q][T] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {   // piece i: row i / (4 CQ), k-quad 4 sq + i % (4 CQ) of the chunk (coalesced per row)
+            const int i = l + 64 * j, r = i / (4 * CQ), q = i % (4 * CQ);
+            x[j] = (i < 16 * 4 * CQ && r < nrows)
+                       ? *reinterpret_cast<const float4 *>(arow + (size_t)r * DQ_FC1_IN + 4 * (4 * sq + q))
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto consume = [&](const float4 (&w)[CQ][4], const float4 (&xin)[XI], float (*x_lds)[4][16][4]) {
+#pragma unroll
+        for (int j = 0; j < XI; ++j) {   // element e of k-quad 4 Q + jq is k = 16 Q + 4 jq + e: plane kk = e, slot jq
+            const int i = l + 64 * j, r = i / (4 * CQ), q = i % (4 * CQ);
+            if (i < 16 * 4 * CQ) {
+                x_lds[q >> 2][0][r][q & 3] = xin[j].x;
+                x_lds[q >> 2][1][r][q & 3] = xin[j].y;
+                x_lds[q >> 2][2][r][q & 3] = xin[j].z;
+                x_lds[q >> 2][3][r][q & 3] = xin[j].w;
+            }
+        }
+        __syncthreads();   // one wave per workgroup: orders the LDS round trip
+        float4 a[CQ];
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) a[q] = *reinterpret_cast<const float4 *>(&x_lds[q][kk][c][0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) {
+#pragma unroll
+            for (int T = 0; T < 4; ++T) acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, w[q][T].x, acc[T], 0, 0, 0);
+#pragma unroll
+            for (int T = 0; T < 4; ++T) acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].y, w[q][T].y, acc[T], 0, 0, 0);
+#pragma unroll
+            for (int T = 0; T < 4; ++T) acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].z, w[q][T].z, acc[T], 0, 0, 0);
+#pragma unroll
+            for (int T = 0; T < 4; ++T) acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].w, w[q][T].w, acc[T], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#pragma unroll
+    for (int b = 0; b < NB - 1; ++b) issue(wv[b], xr[b], b * CQ);
+#pragma nounroll
+    for (int c0 = 0; c0 < NCHUNK; c0 += NB) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int nxt = c0 + b + NB - 1;
+            if (nxt < NCHUNK) issue(wv[(b + NB - 1) % NB], xr[(b + NB - 1) % NB], nxt * CQ);   // wave-uniform
+            __builtin_amdgcn_sched_barrier(0);
+            consume(wv[b], xr[b], xs[b & 1]);
+        }
+    }
+#pragma unroll
+    for (int T = 0; T < 4; ++T)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * kk + i;
+            if (r < nrows) hid[(size_t)(task.row_begin + r) * DQ_FC1_OUT + 64 * ob + 16 * T + c] = relu_keep_nan(acc[T][i]);
+        }
+}
+
+template <int NB>
+__global__ __launch_bounds__(64, 1) void dqn_fc1_tiled_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int C,
+                                                              int n_actions, const float *act, float *hid)
+{
+    __shared__ __attribute__((aligned(16))) float xs[2][DQ_FC1_TQ][4][16][4];
+#ifdef DQ_NO_XCD_MAP
+    const int ti = blockIdx.x;
+#else
+    const int ti = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // as dqn_fc1_kernel: a net's tasks meet in one L2
+#endif
+    if (ti >= n_tasks) return;
+    const coevo_dqn_task task = tasks[ti];
+    const bool shared_net = !DQ_FC1_ALLNT && ((ti > 0 && tasks[ti - 1].net_off == task.net_off) ||
+                                              (ti + 1 < n_tasks && tasks[ti + 1].net_off == task.net_off));
+    const float *net = slab + task.net_off;
+    const DqnLayout L = dqn_layout(C, n_actions);
+    if (shared_net) dqn_fc1_tiled_body<NB, true>(net, L, task, act, hid, xs, blockIdx.y, threadIdx.x);
+    else dqn_fc1_tiled_body<NB, false>(net, L, task, act, hid, xs, blockIdx.y, threadIdx.x);
+}
+
 // fc1 + ReLU of a SMALL launch (a Co-ES generation's ten evaluation games: one task per agent-step, 600 dependent launches
 // per generation).  Such a launch is bound by the LATENCY of the k chain, not by throughput: 8 waves with 3 - 4 independent
 // accumulators each advance one k per dependent v_mfma_f32_4x4x1 (~40 cycles): 3136 x 40 cycles = 52 us + the stream =
@@ -843,11 +967,12 @@ extern "C" int64_t coevo_dqn_workspace_bytes(int n_rows_total)
                             : COEVO_ERR_ARG;
 }
 
-extern "C" int coevo_dqn_pack(const float *flat, float *slab, int n, int C, int n_actions, void *stream)
+extern "C" int coevo_dqn_pack(const float *flat, float *slab, int n, int c_arg, int n_actions, void *stream)
 {
-    if (!flat || !slab || n <= 0 || !dqn_shape_ok(C, n_actions)) return COEVO_ERR_ARG;
+    const int C = dqn_channels(c_arg), tiled = dqn_fc1_tiled(c_arg);
+    if (!flat || !slab || n <= 0 || !dqn_shape_ok(C, n_actions) || (c_arg & ~(0xff | COEVO_DQN_FC1_TILED))) return COEVO_ERR_ARG;
     const dim3 grid((unsigned)((dqn_layout(C, n_actions).stride + 255) / 256), (unsigned)n);
-    hipLaunchKernelGGL(dqn_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, flat, slab, C, n_actions);
+    hipLaunchKernelGGL(dqn_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, flat, slab, C, n_actions, tiled);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }
@@ -863,9 +988,11 @@ extern "C" int coevo_dqn_forward_argmax(const float *slab, const coevo_dqn_task 
 
 // conv stack + fc1 (+ the output layer when `actions` is given)
 static int dqn_forward_launch(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int max_rows_per_task,
-                              int n_rows_total, int C, int n_actions, const uint8_t *frames, int32_t *actions, float *logits,
+                              int n_rows_total, int c_arg, int n_actions, const uint8_t *frames, int32_t *actions, float *logits,
                               int32_t *status, void *workspace, void *timing_ctx, int timed_kernel, void *stream)
 {
+    const int C = dqn_channels(c_arg), tiled = dqn_fc1_tiled(c_arg);   // (the slab's fc1 layout rides in the channel argument)
+    if (c_arg & ~(0xff | COEVO_DQN_FC1_TILED)) return COEVO_ERR_ARG;
     if (!slab || !tasks || !frames || !workspace) return COEVO_ERR_ARG;
     if (n_tasks <= 0 || n_rows_total <= 0 || !dqn_shape_ok(C, n_actions)) return COEVO_ERR_ARG;
     if (max_rows_per_task < 1 || max_rows_per_task > DQ_RMAX) return COEVO_ERR_ARG;
@@ -892,7 +1019,9 @@ static int dqn_forward_launch(const float *slab, const coevo_dqn_task *tasks, in
     if (timing_ctx && timed_kernel == 0 && coevo_timing_end(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     if (timing_ctx && timed_kernel == 1 && coevo_timing_begin(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     const dim3 fg(8 * ((n_tasks + 7) / 8), 8);
-    if (n_tasks <= DQ_FC1_NARROW_MAX_TASKS)
+    if (tiled)   // the Co-GA engines' layout: every launch size through the 16x16x4 kernel
+        hipLaunchKernelGGL(dqn_fc1_tiled_kernel<DQ_FC1_TNB>, fg, dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, act, hid);
+    else if (n_tasks <= DQ_FC1_NARROW_MAX_TASKS)
         hipLaunchKernelGGL(dqn_fc1_narrow_kernel<DQ_FC1_NBN>, dim3(n_tasks, 32), dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions,
                            act, hid);
     else if (DQ_FC1_HALF && n_tasks * 8 <= 1024)

@@ -6,6 +6,10 @@ namespace coevo {
 
 constexpr int DQ_FC1_IN = 3136, DQ_FC1_OUT = 512;
 
+// the channel argument of the layout-dependent entry points: channels | COEVO_DQN_FC1_TILED
+__host__ __device__ inline int dqn_channels(int c_arg) { return c_arg & 0xff; }
+__host__ __device__ inline int dqn_fc1_tiled(int c_arg) { return (c_arg & COEVO_DQN_FC1_TILED) ? 1 : 0; }
+
 struct DqnLayout {
     int64_t w1, b1, w2, b2, w3, b3, wf, bf, wo, bo, total, stride;
 };
@@ -28,6 +32,10 @@ __host__ __device__ inline DqnLayout dqn_layout(int C, int n)
     return L;
 }
 
+// quads by which dqn_perturb_kernel shifts its thread -> slab mapping for the tiled fc1 block (see there): the block's first
+// quad then falls on lane 0 of a wave
+__host__ __device__ inline int dqn_perturb_shift(const DqnLayout &L) { return (int)((64 - ((L.wf >> 2) & 63)) & 63); }
+
 __host__ __device__ inline int64_t dqn_param_count(int C, int n)
 {
     return 32LL * C * 64 + 32 + 64LL * 512 + 64 + 64LL * 576 + 64 + 512LL * DQ_FC1_IN + 512 + 512LL * n + n + 320;
@@ -47,9 +55,27 @@ __host__ __device__ inline int64_t dqn_conv_slab_to_flat(int64_t i, int cout, in
     return co * taps + tap;
 }
 
+// The fc1 block has two layouts, an attribute of the engine that owns the slab (every entry point that depends on it takes it
+// as COEVO_DQN_FC1_TILED or-ed into its channel argument, include/coevo.h):
+//   streamed (0)  wfq[ob][kq][l][c] = fc1.w[64 ob + l][4 kq + c]: lane l of a wave owns output 64 ob + l and streams its row as
+//                 16-byte pieces - the B operand of v_mfma_f32_4x4x1 as it is (rows in groups of four; Co-ES: one row per task)
+//   tiled (1)     wft[ob][Q][T][l][j] = fc1.w[64 ob + 16 T + l % 16][16 Q + 4 j + l / 16]: the 16-byte piece of lane (c = l % 16,
+//                 kk = l / 16) holds, for tile T and the four k-quads 4 Q + j, exactly the B operands of v_mfma_f32_16x16x4 -
+//                 B[k = 4 q + kk][column c] - so a 16-row task runs sixteen matrix instructions per 16 k with no vector
+//                 instruction touching an operand (Co-GA: 10 / 16 rows per task; profiles/r04_experiments.md section 8)
+__host__ __device__ inline int64_t dqn_fc1_slab_to_flat(int64_t i, int tiled)   // i: position inside the block -> out * 3136 + k
+{
+    if (tiled) {
+        const int64_t j = i & 3, l = (i >> 2) & 63, T = (i >> 8) & 3, Q = (i >> 10) % 196, ob = (i >> 10) / 196;
+        return (ob * 64 + 16 * T + (l & 15)) * DQ_FC1_IN + 16 * Q + 4 * j + (l >> 4);
+    }
+    const int64_t c = i & 3, l = (i >> 2) & 63, kq = (i >> 8) % 784, ob = (i >> 8) / 784;
+    return (ob * 64 + l) * DQ_FC1_IN + kq * 4 + c;
+}
+
 // slab position -> canonical flat index (parameters() order: conv1.w conv1.b conv2.w conv2.b conv3.w conv3.b fc1.w
 // fc1.b output.w output.b vbn1.w vbn1.b vbn2.w vbn2.b vbn3.w vbn3.b); -1 for padding
-__host__ __device__ inline int64_t dqn_slab_to_flat(int64_t s, int C, int n)
+__host__ __device__ inline int64_t dqn_slab_to_flat(int64_t s, int C, int n, int fc1_tiled = 0)
 {
     const DqnLayout L = dqn_layout(C, n);
     const int64_t T1 = (int64_t)C * 64;
@@ -64,10 +90,7 @@ __host__ __device__ inline int64_t dqn_slab_to_flat(int64_t s, int C, int n)
     if (s < L.w3) { const int64_t i = s - L.b2; return i < 64 ? F_b2 + i : (i < 128 ? F_g2 + i - 64 : F_be2 + i - 128); }
     if (s < L.b3) return F_w3 + dqn_conv_slab_to_flat(s - L.w3, 64, 576);
     if (s < L.wf) { const int64_t i = s - L.b3; return i < 64 ? F_b3 + i : (i < 128 ? F_g3 + i - 64 : F_be3 + i - 128); }
-    if (s < L.bf) {  // wfq[ob][kq][l][c] = fc1.w[64 ob + l][4 kq + c]
-        const int64_t i = s - L.wf, c = i & 3, l = (i >> 2) & 63, kq = (i >> 8) % 784, ob = (i >> 8) / 784;
-        return F_wf + (ob * 64 + l) * DQ_FC1_IN + kq * 4 + c;
-    }
+    if (s < L.bf) return F_wf + dqn_fc1_slab_to_flat(s - L.wf, fc1_tiled);
     if (s < L.wo) return F_bf + (s - L.bf);
     if (s < L.bo) return F_wo + (s - L.wo);
     return F_bo + (s - L.bo);

@@ -25,15 +25,17 @@ __global__ __launch_bounds__(256) void dqn_perturb_kernel(const float *parent_sl
                                                            const float *sigma_dev, uint64_t seed,
                                                            uint32_t stream_lo_first, uint32_t stream_hi, int flags,
                                                            int E, const int32_t *gen_dev, int gen_bias,
-                                                           const float *dist_ref, double *dist_partial)
+                                                           const float *dist_ref, double *dist_partial, int fc1_tiled)
 {
     __shared__ double scratch[4];
     if (gen_dev) stream_hi += 4u * (uint32_t)(*gen_dev + gen_bias);
     const int c = blockIdx.y;
     const DqnLayout L = dqn_layout(C, n_actions);
-    const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    // tiled fc1 block: the thread -> slab mapping is shifted by dqn_perturb_shift() quads, so that a wave's 64 lanes are the 64
+    // lanes of ONE (output block, super-quad, tile) of the block (whose first quad is not a multiple of 64)
+    const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x - (fc1_tiled ? dqn_perturb_shift(L) : 0)) * 4;
     double d2 = 0.0;
-    if (s0 < L.stride) {
+    if (s0 >= 0 && s0 < L.stride) {
         int parent = parent_idx ? parent_idx[c] : 0;
         uint32_t ind = stream_lo_first + (uint32_t)c;
         bool copy = (flags & DQP_COPY) != 0;
@@ -53,6 +55,30 @@ __global__ __launch_bounds__(256) void dqn_perturb_kernel(const float *parent_sl
         if (copy) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) { out[i] = in[i]; live[i] = s0 + i < L.total; }
+        } else if (fc1_tiled && s0 >= L.wf && s0 < L.bf) {
+            // tiled fc1 block: the quad of lane (cc = lane % 16, kk = lane / 16) of tile (ob, Q, T) holds k = 16 Q + 4 j + kk,
+            // j = 0 .. 3, of output 64 ob + 16 T + cc - one element of each of FOUR Philox blocks (k-quads 4 Q + j).  The lane
+            // draws the block of k-quad 4 Q + kk instead (whose four normals belong to lanes (cc, 0 .. 3), slot j = kk) and a
+            // 4x4 (register x 16-lane row) transpose hands every lane its own four: one Philox block per lane, not four.
+            const int64_t i = s0 - L.wf;
+            const int lane = (int)((i >> 2) & 63), cc = lane & 15, kk = lane >> 4;
+            const int64_t T = (i >> 8) & 3, Q = (i >> 10) % 196, ob = (i >> 10) / 196;
+            const int64_t F_wf = 2048LL * C + 69792;
+            const int64_t p0 = F_wf + (ob * 64 + 16 * T + cc) * DQ_FC1_IN + 16 * Q + 4 * kk;
+            float zl[4], z[4];
+            philox_normal4(seed, slo, stream_hi, (uint32_t)(p0 >> 2), zl);
+            typedef unsigned u32x2_s __attribute__((ext_vector_type(2)));
+            const u32x2_s s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(zl[0]), __float_as_uint(zl[2]), false, false);
+            const u32x2_s s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(zl[1]), __float_as_uint(zl[3]), false, false);
+            const u32x2_s y01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+            const u32x2_s y23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+            z[0] = __uint_as_float(y01[0]); z[1] = __uint_as_float(y01[1]); z[2] = __uint_as_float(y23[0]); z[3] = __uint_as_float(y23[1]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float noise = sigma * z[k];
+                out[k] = in[k] + (negate ? -noise : noise);
+                live[k] = true;
+            }
         } else if (s0 >= L.wf && s0 < L.bf) {
             // fc1 tile (95 % of a net): wfq[ob][kq][l][0..3] = fc1.w[64 ob + l][4 kq .. 4 kq + 3], four consecutive
             // canonical indices = one Philox block; never BatchNorm, never padding
@@ -74,7 +100,7 @@ __global__ __launch_bounds__(256) void dqn_perturb_kernel(const float *parent_sl
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int64_t s = s0 + k;
-                const int64_t p = dqn_slab_to_flat(s, C, n_actions);
+                const int64_t p = dqn_slab_to_flat(s, C, n_actions, fc1_tiled);
                 live[k] = p >= 0;
                 const bool keep = p < 0 || ((flags & DQP_SKIP_BN) && dqn_slab_is_batchnorm(s, L));
                 if (keep) { out[k] = in[k]; continue; }
@@ -105,13 +131,13 @@ __global__ __launch_bounds__(256) void dqn_perturb_kernel(const float *parent_sl
     }
 }
 
-__global__ __launch_bounds__(256) void dqn_unpack_kernel(const float *slab, float *flat, int C, int n)
+__global__ __launch_bounds__(256) void dqn_unpack_kernel(const float *slab, float *flat, int C, int n, int fc1_tiled)
 {
     const DqnLayout L = dqn_layout(C, n);
     const int64_t P = dqn_param_count(C, n);
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= L.total) return;
-    const int64_t f = dqn_slab_to_flat(s, C, n);
+    const int64_t f = dqn_slab_to_flat(s, C, n, fc1_tiled);
     if (f >= 0) flat[(int64_t)blockIdx.y * P + f] = slab[(int64_t)blockIdx.y * L.stride + s];
 }
 
@@ -200,37 +226,44 @@ using namespace coevo;
 
 static bool dqn_shape_ok2(int C, int n) { return C >= 1 && C <= 6 && n >= 1 && n <= COEVO_DQN_LOGIT_STRIDE; }
 
-extern "C" int64_t coevo_dqn_perturb_blocks(int C, int n_actions)
+static int64_t dqn_perturb_grid(const DqnLayout &L, int tiled) { return (L.stride / 4 + (tiled ? dqn_perturb_shift(L) : 0) + 255) / 256; }
+static bool dqn_carg_ok(int c_arg, int n) { return !(c_arg & ~(0xff | COEVO_DQN_FC1_TILED)) && dqn_shape_ok2(dqn_channels(c_arg), n); }
+
+extern "C" int64_t coevo_dqn_perturb_blocks(int c_arg, int n_actions)
 {
-    return dqn_shape_ok2(C, n_actions) ? (dqn_layout(C, n_actions).stride / 4 + 255) / 256 : COEVO_ERR_ARG;
+    return dqn_carg_ok(c_arg, n_actions) ? dqn_perturb_grid(dqn_layout(dqn_channels(c_arg), n_actions), dqn_fc1_tiled(c_arg))
+                                        : COEVO_ERR_ARG;
 }
 
 extern "C" int coevo_dqn_perturb(const float *parent_slab, const int32_t *parent_idx, float *child_slab,
-                                 int child_first, int n_children, int C, int n_actions, const float *sigma_dev,
+                                 int child_first, int n_children, int c_arg, int n_actions, const float *sigma_dev,
                                  uint64_t seed, uint32_t stream_lo_first, uint32_t stream_hi, int flags, int E,
                                  const int32_t *gen_dev, int gen_bias, const float *dist_ref, double *dist_partial,
                                  void *stream)
 {
     if ((dist_ref == nullptr) != (dist_partial == nullptr)) return COEVO_ERR_ARG;
-    if (!parent_slab || !dqn_shape_ok2(C, n_actions) || flags < 0 || flags > 15) return COEVO_ERR_ARG;
+    if (!dqn_carg_ok(c_arg, n_actions)) return COEVO_ERR_ARG;
+    const int C = dqn_channels(c_arg), tiled = dqn_fc1_tiled(c_arg);
+    if (!parent_slab || flags < 0 || flags > 15) return COEVO_ERR_ARG;
     if (!child_slab && !dist_partial) return COEVO_ERR_ARG;
     if (!(flags & DQP_COPY) && !sigma_dev) return COEVO_ERR_ARG;
     if ((flags & DQP_FROM_ORDER) && (!parent_idx || E <= 0 || parent_slab == child_slab)) return COEVO_ERR_ARG;
     if (n_children < 0 || child_first < 0 || n_children > 65535) return COEVO_ERR_ARG;
     if (n_children == 0) return COEVO_OK;
-    const dim3 grid((unsigned)((dqn_layout(C, n_actions).stride / 4 + 255) / 256), (unsigned)n_children);
+    const dim3 grid((unsigned)dqn_perturb_grid(dqn_layout(C, n_actions), tiled), (unsigned)n_children);
     hipLaunchKernelGGL(dqn_perturb_kernel, grid, dim3(256), 0, (hipStream_t)stream, parent_slab, parent_idx, child_slab,
                        child_first, C, n_actions, sigma_dev, seed, stream_lo_first, stream_hi, flags, E, gen_dev, gen_bias,
-                       dist_ref, dist_partial);
+                       dist_ref, dist_partial, tiled);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }
 
-extern "C" int coevo_dqn_unpack(const float *slab, float *flat, int n, int C, int n_actions, void *stream)
+extern "C" int coevo_dqn_unpack(const float *slab, float *flat, int n, int c_arg, int n_actions, void *stream)
 {
-    if (!flat || !slab || n <= 0 || !dqn_shape_ok2(C, n_actions)) return COEVO_ERR_ARG;
+    if (!flat || !slab || n <= 0 || !dqn_carg_ok(c_arg, n_actions)) return COEVO_ERR_ARG;
+    const int C = dqn_channels(c_arg);
     const dim3 grid((unsigned)((dqn_layout(C, n_actions).total + 255) / 256), (unsigned)n);
-    hipLaunchKernelGGL(dqn_unpack_kernel, grid, dim3(256), 0, (hipStream_t)stream, slab, flat, C, n_actions);
+    hipLaunchKernelGGL(dqn_unpack_kernel, grid, dim3(256), 0, (hipStream_t)stream, slab, flat, C, n_actions, dqn_fc1_tiled(c_arg));
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

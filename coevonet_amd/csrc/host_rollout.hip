@@ -821,7 +821,7 @@ void frame_part(void *arg, int part, int parts)
     const coevo_frames_rollout_desc *d = j->d;
     const coevo_frame_cohort &c = *j->c;
     const int t = j->t, p = t & 1, q = (t - 1) & 1;
-    const int nbytes = 84 * 84 * d->C;
+    const int nbytes = 84 * 84 * (d->C & 0xff);
     const int lo = (int)((int64_t)c.n_games * part / parts), hi = (int)((int64_t)c.n_games * (part + 1) / parts);
     for (int i = lo; i < hi; ++i) {
         const int g = c.game_first + i;
@@ -853,11 +853,12 @@ extern "C" int coevo_dqn_host_frames_rollout(void *handle, const coevo_frames_ro
     auto *h = static_cast<HostRollout *>(handle);
     if (!h || !d || !d->slab || !d->status || !d->game_state || !d->acc || !d->game_ordinal0 || !d->limit || !d->cohorts)
         return COEVO_ERR_ARG;
-    if (d->n_games <= 0 || d->T < 0 || d->T > 65535 || d->C < 1 || d->C > 6 || d->n_actions < 1 || d->n_cohorts < 1 ||
-        d->n_cohorts > h->max_cohorts)
+    const int C = d->C & 0xff;   // (d->C may carry COEVO_DQN_FC1_TILED for the forward launches)
+    if (d->n_games <= 0 || d->T < 0 || d->T > 65535 || C < 1 || C > 6 || (d->C & ~(0xff | COEVO_DQN_FC1_TILED)) ||
+        d->n_actions < 1 || d->n_cohorts < 1 || d->n_cohorts > h->max_cohorts)
         return COEVO_ERR_ARG;
     const int K = d->n_cohorts;
-    const size_t nbytes = (size_t)84 * 84 * d->C;
+    const size_t nbytes = (size_t)84 * 84 * C;
     int covered = 0;
     for (int k = 0; k < K; ++k) {
         const coevo_frame_cohort &c = d->cohorts[k];

@@ -188,14 +188,16 @@ class DeepQN:
         return int(actions[0])
 
 
-def batched_actions(nets_flat, frames_per_net, C, n_actions, device="cuda"):
+def batched_actions(nets_flat, frames_per_net, C, n_actions, device="cuda", fc1_tiled=False):
     """nets_flat: list of flat parameter vectors; frames_per_net: list of uint8 arrays [r_i, 84, 84, C] (r_i <= 16).
-    -> (logits [sum r_i, n_actions] float32, actions [sum r_i] int32).  One task per net."""
+    -> (logits [sum r_i, n_actions] float32, actions [sum r_i] int32).  One task per net.  fc1_tiled: the slab keeps fc1 in
+    the layout of v_mfma_f32_16x16x4 (include/coevo.h COEVO_DQN_FC1_TILED; same results)"""
     n_nets = len(nets_flat)
+    Cw = C | (L.DQN_FC1_TILED if fc1_tiled else 0)
     stride = int(L.load().coevo_dqn_slab_stride(C, n_actions))
     flat = torch.from_numpy(np.ascontiguousarray(np.stack(nets_flat), dtype=np.float32)).to(device)
     slab = torch.zeros(n_nets, stride, dtype=torch.float32, device=device)
-    L.call("coevo_dqn_pack", L._p(flat), L._p(slab), n_nets, C, n_actions)
+    L.call("coevo_dqn_pack", L._p(flat), L._p(slab), n_nets, Cw, n_actions)
     tasks = np.zeros(n_nets, dtype=L.DQN_TASK_DTYPE)
     row = 0
     for i, fr in enumerate(frames_per_net):
@@ -209,7 +211,7 @@ def batched_actions(nets_flat, frames_per_net, C, n_actions, device="cuda"):
     status = torch.zeros(1, dtype=torch.int32, device=device)
     ws = torch.zeros(int(L.load().coevo_dqn_workspace_bytes(row)) // 4, dtype=torch.float32, device=device)
     L.call("coevo_dqn_forward_argmax", L._p(slab), L._p(d_tasks), n_nets, int(max(f.shape[0] for f in frames_per_net)),
-           row, C, n_actions, L._p(frames), L._p(actions), L._p(logits), L._p(status), L._p(ws))
+           row, Cw, n_actions, L._p(frames), L._p(actions), L._p(logits), L._p(status), L._p(ws))
     L.raise_on_status(status)
     return logits[:, :n_actions].cpu().numpy(), actions.cpu().numpy()
 

@@ -46,9 +46,10 @@ class SynthRollout:
     stream (HBM) instead of the whole chip alternating between the two.  Eager enqueue only (no graph capture)."""
 
     def __init__(self, game_nets, net_off, ordinal0, C, n_actions, slab, env_seed, ordinals_per_gen, device="cuda",
-                 bounds=None):
+                 bounds=None, fc1_tiled=False):
         self.n_games = n = int(len(game_nets))
         self.C, self.n_actions, self.slab, self.env_seed = C, n_actions, slab, int(env_seed)
+        self.Cw = C | (L.DQN_FC1_TILED if fc1_tiled else 0)   # channel argument of the forward launches: + the slab's fc1 layout
         self.ordinals_per_gen = int(ordinals_per_gen)
         self.device = device
         game_nets = np.asarray(game_nets, dtype=np.int64).reshape(n, 2)
@@ -188,7 +189,7 @@ class SynthRollout:
                     which = (t // self.timing_every) & 1
                     tc = self.timing_ctx[which]
                 L._check(lib.coevo_dqn_forward_hidden_timed(L._p(self.slab), L._p(ln["tasks"][p]), ln["n_tasks"][p],
-                                                            ln["max_rows"][p], m, self.C, self.n_actions,
+                                                            ln["max_rows"][p], m, self.Cw, self.n_actions,
                                                             L._p(ln["frames"]), L._p(ln["ws"]), tc, which, stream),
                          "coevo_dqn_forward_hidden_timed")
 
@@ -277,7 +278,7 @@ class HostFrameRollout(SynthRollout):
             cohorts=L.C.cast(self._cohorts, L.C.c_void_p),
             phase_us=(self.phase_us.ctypes.data if self.phase_us is not None else None), generation=gen,
             ordinals_per_gen=self.ordinals_per_gen, seed=self.env_seed, n_games=self.n_games, n_cohorts=len(self.lanes),
-            C=self.C, n_actions=self.n_actions, T=int(T), reserved=0)
+            C=self.Cw, n_actions=self.n_actions, T=int(T), reserved=0)
         L._check(L.load().coevo_dqn_host_frames_rollout(self.frame_ctx, L.C.byref(d), L._stream()),
                  "coevo_dqn_host_frames_rollout")
         self.acc.copy_(torch.from_numpy(self.h_acc))
@@ -331,12 +332,12 @@ class _SlabMixin:
 
     def upload(self, role, region, first, flat_np):
         flat = torch.from_numpy(np.ascontiguousarray(flat_np, dtype=np.float32)).to(self.device)
-        L.call("coevo_dqn_pack", L._p(flat), self._ptr(role, region, first), flat.shape[0], self.C, self.n_actions)
+        L.call("coevo_dqn_pack", L._p(flat), self._ptr(role, region, first), flat.shape[0], self.Cw, self.n_actions)
         torch.cuda.current_stream().synchronize()
 
     def download(self, role, region, first, n):
         out = torch.zeros(n, self.P, dtype=torch.float32, device=self.device)
-        L.call("coevo_dqn_unpack", self._ptr(role, region, first), L._p(out), n, self.C, self.n_actions)
+        L.call("coevo_dqn_unpack", self._ptr(role, region, first), L._p(out), n, self.Cw, self.n_actions)
         return out.cpu().numpy()
 
 
@@ -347,6 +348,11 @@ class DQNGAEngine(_SlabMixin):
         assert 1 <= elites <= pop and hof >= 1 and frames in ("device", "host")
         self.frames = frames
         self.pop, self.hof, self.E, self.C, self.n_actions = pop, hof, elites, C, n_actions
+        # the engine's slab keeps fc1 TILED for v_mfma_f32_16x16x4 (its tasks carry 10 / 16 frames; include/coevo.h
+        # COEVO_DQN_FC1_TILED; COEVO_DQN_FC1_LAYOUT=streamed keeps the Co-ES layout for A/B runs): every layout-dependent
+        # call takes self.Cw
+        self.fc1_tiled = os.environ.get("COEVO_DQN_FC1_LAYOUT", "tiled") != "streamed"
+        self.Cw = C | (L.DQN_FC1_TILED if self.fc1_tiled else 0)
         self.T_train, self.T_eval = int(T_train), int(T_eval)
         self.T = max(self.T_train, self.T_eval)
         self.device, self.philox_seed = device, int(philox_seed)
@@ -398,7 +404,8 @@ class DQNGAEngine(_SlabMixin):
         if frames == "host":   # env in host memory: the cohorts alternate between the host cores and the GPU
             bounds = even_bounds(len(games), int(os.environ.get("COEVO_FRAME_COHORTS", "3")))
         self.ro = (HostFrameRollout if frames == "host" else SynthRollout)(
-            games, net_off, ordinal0, C, n_actions, self.slab, env_seed, self.per_gen, device, bounds=bounds)
+            games, net_off, ordinal0, C, n_actions, self.slab, env_seed, self.per_gen, device, bounds=bounds,
+            fc1_tiled=self.fc1_tiled)
         self.cohorts = len(self.ro.lanes)
         # ---- device-resident loop state ------------------------------------------------------------------------
         f32 = dict(dtype=torch.float32, device=device)
@@ -417,7 +424,7 @@ class DQNGAEngine(_SlabMixin):
         self.order = [torch.zeros(pop, **i32) for _ in ROLES2]
         self.best_dist = [torch.zeros(1, **f32) for _ in ROLES2]
         self.last_reward = torch.zeros(2, pop, 3, dtype=torch.float64, device=device)
-        self.pblocks = int(lib.coevo_dqn_perturb_blocks(C, n_actions))
+        self.pblocks = int(lib.coevo_dqn_perturb_blocks(self.Cw, n_actions))
         self.dist_partial = torch.zeros(max(pop, 1) * self.pblocks, dtype=torch.float64, device=device)
         self.parent_idx = torch.tensor([c % elites for c in range(max(pop - 1, 1))], **i32)
         self.iota = torch.arange(max(pop, hof, elites, 2), **i32)
@@ -434,7 +441,7 @@ class DQNGAEngine(_SlabMixin):
             self.upload(r, "hof", 0, hof_flat[r])
             self.upload(r, "stale", 0, pop_flat[r][self.pop - 1:self.pop])   # Q3: the object left over from the init loop
         for ri, r in enumerate(ROLES2):  # distances of the initial population to the stale agent (later: fused into breeding)
-            L.call("coevo_dqn_perturb", self._ptr(r, "pop"), L._p(self.iota), None, 0, self.pop, self.C, self.n_actions,
+            L.call("coevo_dqn_perturb", self._ptr(r, "pop"), L._p(self.iota), None, 0, self.pop, self.Cw, self.n_actions,
                    None, 0, 0, 0, 8, 1, None, 0, self._ptr(r, "stale"), L._p(self.dist_partial))
             L.call("coevo_fc_distance_finalize", L._p(self.dist_partial), self.pblocks, self.pop,
                    self.dist_all[ri].data_ptr(), 0, None)
@@ -466,7 +473,7 @@ class DQNGAEngine(_SlabMixin):
                 L.call("coevo_net_gather", self._ptr(r, "elite"), L._p(self.iota), self._ptr(r, "elite_prev"), 0, self.E,
                        self.stride)
                 L.call("coevo_dqn_perturb", self._ptr(r, "elite_prev"), L._p(self.order[ri]), self._ptr(r, "elite"), 0,
-                       self.E, self.C, self.n_actions, self.sigma32_prev.data_ptr() + 4 * ri, self.philox_seed, 0, ri, 4,
+                       self.E, self.Cw, self.n_actions, self.sigma32_prev.data_ptr() + 4 * ri, self.philox_seed, 0, ri, 4,
                        self.E, g, -1, None, None)
             else:
                 L.call("coevo_net_gather", self._ptr(r, "pop"), L._p(self.order[ri]), self._ptr(r, "elite"), 0, self.E,
@@ -482,7 +489,7 @@ class DQNGAEngine(_SlabMixin):
                 L.call("coevo_net_gather", self._ptr(r, "elite"), L._p(self.iota), self._ptr(r, "pop"), 0, 1, self.stride)
             if c_hi > c_lo:
                 L.call("coevo_dqn_perturb", self._ptr(r, "elite"), self.parent_idx.data_ptr() + 4 * c_lo,
-                       self._ptr(r, "pop"), 1 + c_lo, c_hi - c_lo, self.C, self.n_actions,
+                       self._ptr(r, "pop"), 1 + c_lo, c_hi - c_lo, self.Cw, self.n_actions,
                        self.sigma32.data_ptr() + 4 * ri, self.philox_seed, c_lo, ri, 0, self.E, g, 0,
                        self._ptr(r, "stale"), L._p(self.dist_partial))
                 L.call("coevo_fc_distance_finalize", L._p(self.dist_partial), self.pblocks, c_hi - c_lo,
@@ -653,6 +660,7 @@ class DQNESEngine(_SlabMixin):
         assert frames in ("device", "host")
         self.frames = frames
         self.pop, self.C, self.n_actions, self.device = pop, C, n_actions, device
+        self.Cw = C   # the streamed fc1 layout (one frame per task: v_mfma_f32_4x4x1, lane = output)
         self.T_train, self.T_eval = int(T_train), int(T_eval)
         self.philox_seed = int(philox_seed)
         self.rank, self.world = shard

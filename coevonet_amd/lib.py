@@ -24,6 +24,7 @@ ST_NAMES = {1: "input contains inf or NaN", 2: "output contains inf or NaN after
             16: "no action selected (current_best_position = -1)"}
 
 DQN_LOGIT_STRIDE = 32
+DQN_FC1_TILED = 0x100   # COEVO_DQN_FC1_TILED: or-ed into the channel argument of the layout-dependent DeepQN entry points
 DQN_MAX_ROWS = 16
 DQN_TASK_DTYPE = np.dtype([("net_off", "<i8"), ("row_begin", "<i4"), ("n_rows", "<i4")])
 

@@ -515,6 +515,16 @@ int coevo_counter_add(int32_t *counter, int value, void *stream);   /* the devic
  * output.w output.b vbn1.w vbn1.b vbn2.w vbn2.b vbn3.w vbn3.b. */
 #define COEVO_DQN_LOGIT_STRIDE 32    /* floats per logits row; n_actions <= 32 (6 pong, 18 boxing) */
 #define COEVO_DQN_MAX_ROWS 16        /* frames one task (one weight set) may carry */
+/* The fc1 block (3136 -> 512, 95 % of a net: Atari/deepqn.py:46) of a slab has one of two layouts, an attribute of the engine
+ * that owns the slab; every entry point whose work depends on it - coevo_dqn_pack / _unpack / _perturb / _perturb_blocks and
+ * the coevo_dqn_forward_* family (also through coevo_frames_rollout_desc.C) - takes it or-ed into its channel argument:
+ *   C                        streamed: [out block of 64][k / 4][out % 64][k % 4] - v_mfma_f32_4x4x1, rows in groups of four
+ *                            (Co-ES: one frame per task)
+ *   C | COEVO_DQN_FC1_TILED  tiled for v_mfma_f32_16x16x4: [out block][k / 16][16-out tile][lane = 16 (k % 4) + out % 16][(k / 4) % 4]
+ *                            - sixteen matrix instructions per 16 k of a <= 16-row task without a vector instruction
+ *                            touching an operand (Co-GA: 10 / 16 frames per task)
+ * Results do not depend on the layout (same sequential-k chains); sizes (param_count, slab_stride) do not either. */
+#define COEVO_DQN_FC1_TILED 0x100
 int64_t coevo_dqn_param_count(int C, int n_actions);      /* 1 687 526 for C=4, n=6 */
 int64_t coevo_dqn_slab_stride(int C, int n_actions);
 int64_t coevo_dqn_workspace_bytes(int n_rows_total);      /* conv3 activations + fc1 outputs of every row */

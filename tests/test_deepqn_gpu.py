@@ -12,8 +12,11 @@ from tests.util import load_golden, sha
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("tiled", [False, True])
 @pytest.mark.parametrize("C,n_actions,rows", [(4, 6, [3, 1, 10]), (6, 18, [16, 2]), (3, 6, [2, 5]), (5, 18, [4])])
-def test_dqn_forward_bit_exact_vs_oracle(C, n_actions, rows):
+def test_dqn_forward_bit_exact_vs_oracle(C, n_actions, rows, tiled):
+    """both fc1 layouts of the slab (streamed: v_mfma_f32_4x4x1, lane = output; tiled: v_mfma_f32_16x16x4 without operand
+    moves - include/coevo.h COEVO_DQN_FC1_TILED): the same sequential-k chains, the oracle's bits"""
     torch.manual_seed(C * 10 + n_actions)
     nets = []
     for _ in rows:
@@ -22,7 +25,7 @@ def test_dqn_forward_bit_exact_vs_oracle(C, n_actions, rows):
     g = np.random.Generator(np.random.PCG64(7))
     frames = [g.integers(0, 256, size=(r, 84, 84, C), dtype=np.uint8) for r in rows]
     frames[0][0, :, :, :] = 0          # a constant frame: zero variance in conv1's BatchNorm statistics
-    logits, actions = dq.batched_actions(nets, frames, C, n_actions)
+    logits, actions = dq.batched_actions(nets, frames, C, n_actions, fc1_tiled=tiled)
     row = 0
     for net, fr in zip(nets, frames):
         for r in range(fr.shape[0]):

@@ -19,7 +19,7 @@ DEV = "cuda"
 
 
 def _slab(flats, C, n):
-    stride = int(L.load().coevo_dqn_slab_stride(C, n))
+    stride = int(L.load().coevo_dqn_slab_stride(C & 0xff, n))
     flat = torch.from_numpy(np.ascontiguousarray(np.stack(flats), dtype=np.float32)).to(DEV)
     slab = torch.zeros(len(flats), stride, dtype=torch.float32, device=DEV)
     L.call("coevo_dqn_pack", L._p(flat), L._p(slab), len(flats), C, n)
@@ -27,23 +27,27 @@ def _slab(flats, C, n):
 
 
 def _unpack(slab_ptr, k, C, n):
-    P = int(L.load().coevo_dqn_param_count(C, n))
+    P = int(L.load().coevo_dqn_param_count(C & 0xff, n))
     out = torch.zeros(k, P, dtype=torch.float32, device=DEV)
     L.call("coevo_dqn_unpack", slab_ptr, L._p(out), k, C, n)
     return out.cpu().numpy()
 
 
-@pytest.mark.parametrize("C,n", [(4, 6), (6, 18)])
-def test_dqn_perturb_bit_exact_vs_oracle(C, n):
+@pytest.mark.parametrize("tiled", [0, L.DQN_FC1_TILED])
+@pytest.mark.parametrize("Cp,n", [(4, 6), (6, 18)])
+def test_dqn_perturb_bit_exact_vs_oracle(Cp, n, tiled):
+    """offspring / elite rebuild / distances over both fc1 layouts of the slab (the noise is indexed by the CANONICAL parameter
+    position, so a child is the same net whatever the layout; the tiled block draws one Philox block per lane and transposes)"""
+    C = Cp | tiled   # the channel argument of every layout-dependent entry point (sizes ignore the flag)
     torch.manual_seed(3)
-    parents = [rp.dqn_init(C, n)[0] for _ in range(3)]
+    parents = [rp.dqn_init(Cp, n)[0] for _ in range(3)]
     slab, stride = _slab(parents, C, n)
     assert np.array_equal(_unpack(L._p(slab), 3, C, n), np.stack(parents))        # pack / unpack round trip
     P = len(parents[0])
     sigma = torch.tensor([0.05], dtype=torch.float32, device=DEV)
     seed, shi = 0xABCDEF0123, 9
     blocks = int(L.load().coevo_dqn_perturb_blocks(C, n))
-    bn = rp.dqn_bn_segments(C, n)
+    bn = rp.dqn_bn_segments(Cp, n)
     # GA (every parameter), ES (BatchNorm untouched), ES antithetic
     for flags, first in [(0, 100), (1, 100), (3, 10)]:
         k = 4

@@ -8,7 +8,7 @@ while [ "$1" != "--" ]; do sets+=("$1"); shift; done
 shift
 cd /tmp && export TMPDIR=/tmp
 # the profiler starts the HIP runtime before python runs: the package's own setdefault would come too late
-export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8} DEBUG_HIP_DYNAMIC_QUEUES=${DEBUG_HIP_DYNAMIC_QUEUES:-1}
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8} DEBUG_HIP_DYNAMIC_QUEUES=${DEBUG_HIP_DYNAMIC_QUEUES:-0}
 mkdir -p "$out"
 i=0
 for s in "${sets[@]}"; do

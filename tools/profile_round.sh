@@ -6,14 +6,16 @@
 # Separate passes: kernel trace + stats per workload; FETCH_SIZE and WRITE_SIZE (one counter per pass, never combined
 # with a trace domain other than --kernel-trace) for the headline.
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 PART=${2:-all}   # all | stats | pmc (a gpurun call is limited to 20 minutes: the two halves fit one call each)
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# the profiler starts the HIP runtime before python runs: the package's own setdefault would come too late
-export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8} DEBUG_HIP_DYNAMIC_QUEUES=${DEBUG_HIP_DYNAMIC_QUEUES:-1}
+# the profiler starts the HIP runtime before python runs: the package's own setdefault would come too late.  Static queues under the
+# profiler: with DEBUG_HIP_DYNAMIC_QUEUES=1 (the package default) rocprofv3 runs read 10-40 % low (headline 502, host env 277, cfg 5
+# 10.5 against 560 / 470 / 12.3 unprofiled); each workload is its own process here, so the static mapping has nothing to trip over
+export GPU_MAX_HW_QUEUES=${GPU_MAX_HW_QUEUES:-8} DEBUG_HIP_DYNAMIC_QUEUES=${DEBUG_HIP_DYNAMIC_QUEUES:-0}
 run() {  # name, bench args...
     local name=$1; shift
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -- python3 $ROOT/bench.py --no-extra --no-cpu-baseline "$@" \
@@ -30,8 +32,9 @@ run cfg4_dqn_ga --workload dqn-ga --steps 2 --warmup 1
 run cfg5_dqn_es --workload dqn-es --steps 2 --warmup 1
 run cfg4_dqn_ga_c6 --workload dqn-ga --channels 6 --steps 2 --warmup 1
 run cfg5_dqn_es_c6 --workload dqn-es --channels 6 --steps 2 --warmup 1
-run cfg2_host_env --env host --steps 20 --warmup 3
+run cfg2_host_env --env host --steps 40 --warmup 3
 run cfg2_shard_1_of_4 --shard-of 4 --steps 20 --warmup 3
+run cfg2_shard_1_of_8 --shard-of 8 --steps 20 --warmup 3
 run cfg3_host_env --workload es --env host --steps 5 --warmup 2
 run cfg4_host_frames --workload dqn-ga --frames host --steps 1 --warmup 1
 fi

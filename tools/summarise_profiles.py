@@ -132,10 +132,10 @@ def pmc(tag, src, dst):
 
 
 if __name__ == "__main__":
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
     src, dst = f"{REPO}/gpurun_out/prof_{tag}", f"{REPO}/profiles"
     for wl in ("headline", "cfg2_T200", "cfg2_host_env", "cfg3_es", "cfg3_es_ext", "cfg4_dqn_ga", "cfg5_dqn_es",
-               "cfg4_dqn_ga_c6", "cfg5_dqn_es_c6", "cfg2_shard_1_of_4", "cfg4_host_frames", "cfg3_host_env"):
+               "cfg4_dqn_ga_c6", "cfg5_dqn_es_c6", "cfg2_shard_1_of_4", "cfg2_shard_1_of_8", "cfg4_host_frames", "cfg3_host_env"):
         print(stats(tag, wl, src, dst))
     print(overlap(tag, src, dst))
     if glob.glob(f"{src}/pmc_*_FETCH_SIZE"):   # per-workload passes (round 3 on): tools/pmc_traffic_all.py
