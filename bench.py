@@ -407,15 +407,20 @@ def run_dqn(a, ctx, dev, algo, pop_per_gpu=None, T=None):
         gen_bytes = eng.ro.weight_bytes_per_round() * rounds
         wl = ("cfg4_dqn_ga" if ga else "cfg5_dqn_es") + ("" if a.channels == 4 else f"_c{a.channels}")
         conv_traffic, conv_src = pmc_traffic(wl, "dqn_conv_kernel")
-        fc1_traffic, fc1_src = pmc_traffic(wl, "dqn_fc1_kernel")
+        tiled = bool(getattr(eng, "fc1_tiled", False))
+        fc1_traffic, fc1_src = pmc_traffic(wl, "dqn_fc1_tiled_kernel" if tiled else "dqn_fc1_kernel")
+        if fc1_traffic is None:
+            fc1_traffic, fc1_src = pmc_traffic(wl, "dqn_fc1_kernel")
         conv_rl = {"bound": "mfma", "kernel": "dqn_conv_kernel (conv stack + per-sample BatchNorm of every frame of one "
                    "agent-step of one cohort on v_mfma_f32_16x16x4_f32; exact f32 = the reference's arithmetic)",
                    "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS,
                    "traffic": conv_traffic, "traffic_source": conv_src, "flops_per_launch": n_frames * 2 * mac,
                    "avg_launch_ms": c_avg,
                    "launches_timed": len(conv_ms)}
-        fc1_rl = {"bound": "hbm", "kernel": "dqn_fc1_kernel (every acting net's 6.4 MB fc1 matrix streamed once for its "
-                  "<= 16 frames per task, v_mfma_f32_4x4x1)", "achieved": fc1_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        fc1_rl = {"bound": "hbm", "kernel": ("dqn_fc1_tiled_kernel (every acting net's 6.4 MB fc1 matrix, kept tiled for "
+                  "v_mfma_f32_16x16x4, streamed once for its <= 16 frames per task)" if tiled else
+                  "dqn_fc1_kernel (every acting net's 6.4 MB fc1 matrix streamed once for its <= 16 frames per task, "
+                  "v_mfma_f32_4x4x1)"), "achieved": fc1_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": fc1_gbs / HBM_PEAK_GBS, "traffic": fc1_traffic, "traffic_source": fc1_src,
                   "algorithmic_bytes_per_launch": fc1_bytes,
                   "avg_launch_ms": f_avg, "launches_timed": len(fc1_ms)}

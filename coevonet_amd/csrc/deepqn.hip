@@ -924,6 +924,79 @@ __global__ __launch_bounds__(64) void dqn_fc1_narrow_kernel(const float *slab, c
             hid[(size_t)(task.row_begin + 4 * kk + i) * DQ_FC1_OUT + 64 * ob + col] = relu_keep_nan(acc[i]);
 }
 
+// dqn_fc1_narrow_kernel over the TILED fc1 block: the 16-byte piece of lane (c, kk) of tile (ob, Q, T) is the B operand of
+// k-quads 4 Q .. 4 Q + 3 as it is, and the A operands x[row c][16 Q + 4 j + kk] come as four dwords straight from memory (L2
+// hits): no cross-lane move at all.  The streamed form pays two 4x4 transposes (eight v_permlane swaps) per four matrix
+// instructions - ~20 of a lone wave's ~65 cycles per instruction on top of the 45-cycle dependent step; here the launch is
+// the chain: 784 x 45 cycles = 14.7 us (measured: profiles/r05_experiments.md).
+template <int NB>
+__global__ __launch_bounds__(64) void dqn_fc1_narrow_tiled_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int C,
+                                                                   int n_actions, const float *act, float *hid)
+{
+    constexpr int U = DQ_FC1_U;
+    const int ti = blockIdx.x;
+    const coevo_dqn_task task = tasks[ti];
+    const float *net = slab + task.net_off;
+    const DqnLayout L = dqn_layout(C, n_actions);
+    const int ob = blockIdx.y >> 2, T = blockIdx.y & 3, l = threadIdx.x, c = l & 15, kk = l >> 4, col = 16 * T + c;
+    const int nrows = task.n_rows;
+    f32x4_acc acc;
+    {
+        const float bb = net[L.bf + 64 * ob + col];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = bb;
+    }
+    constexpr int NSQ = 196, NCH = NSQ / U;
+    static_assert(NSQ % U == 0 && NCH % NB == 0, "whole rounds of the ring");
+    const float4 *wp = reinterpret_cast<const float4 *>(net + L.wf) + ((size_t)ob * NSQ * 4 + T) * 64 + l;
+    const float *xp = act + (size_t)(task.row_begin + min(c, nrows - 1)) * DQ_FC1_IN + kk;
+    float4 wv[NB][U];
+    float xv[NB][U][4];
+    auto issue = [&](float4 (&w)[U], float (&x)[U][4], int sq) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            w[u] = wp[(size_t)(sq + u) * 256];   // (plain loads: the same two nets every step)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[u][j] = xp[16 * (sq + u) + 4 * j];
+        }
+    };
+#pragma unroll
+    for (int b = 0; b < NB - 1; ++b) issue(wv[b], xv[b], b * U);
+    // The loads of chunk c + NB - 1 are issued BETWEEN the matrix instructions of chunk c, one or two behind each (the order
+    // pinned): a dependent v_mfma_f32_16x16x4 leaves ~45 cycles in which the wave issues nothing else, and a wave issues in
+    // order - as a block in front of the chunk's matrix instructions the 35 loads cost their own issue time on top of the
+    // chain (22.3 us per launch = 784 x 68 cycles; the chain alone is 784 x 45).
+#pragma nounroll
+    for (int c0 = 0; c0 < NCH; c0 += NB) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int nxt = min(c0 + b + NB - 1, NCH - 1) * U;   // (clamped, unconditional: straight-line code)
+            float4 (&wn)[U] = wv[(b + NB - 1) % NB];
+            float (&xn)[U][4] = xv[(b + NB - 1) % NB];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[b][u][0], wv[b][u].x, acc, 0, 0, 0);
+                wn[u] = wp[(size_t)(nxt + u) * 256];
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[b][u][1], wv[b][u].y, acc, 0, 0, 0);
+                xn[u][0] = xp[16 * (nxt + u)];
+                xn[u][1] = xp[16 * (nxt + u) + 4];
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[b][u][2], wv[b][u].z, acc, 0, 0, 0);
+                xn[u][2] = xp[16 * (nxt + u) + 8];
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[b][u][3], wv[b][u].w, acc, 0, 0, 0);
+                xn[u][3] = xp[16 * (nxt + u) + 12];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (4 * kk + i < nrows)
+            hid[(size_t)(task.row_begin + 4 * kk + i) * DQ_FC1_OUT + 64 * ob + col] = relu_keep_nan(acc[i]);
+}
+
 // output layer + first-max action: one 64-thread workgroup per (task, row) (dqn_out_row, dqn_common.hip.h).  The
 // population engine does not launch it: there the output layer rides in the env-step launch (coevo_dqn_out_synth_step).
 __global__ __launch_bounds__(64) void dqn_out_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int C,
@@ -1019,7 +1092,10 @@ static int dqn_forward_launch(const float *slab, const coevo_dqn_task *tasks, in
     if (timing_ctx && timed_kernel == 0 && coevo_timing_end(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     if (timing_ctx && timed_kernel == 1 && coevo_timing_begin(timing_ctx, stream) != COEVO_OK) return COEVO_ERR_HIP;
     const dim3 fg(8 * ((n_tasks + 7) / 8), 8);
-    if (tiled)   // the Co-GA engines' layout: every launch size through the 16x16x4 kernel
+    if (tiled && n_tasks <= DQ_FC1_NARROW_MAX_TASKS)   // the tiled layout: v_mfma_f32_16x16x4 without operand moves at every size
+        hipLaunchKernelGGL(dqn_fc1_narrow_tiled_kernel<DQ_FC1_NBN>, dim3(n_tasks, 32), dim3(64), 0, s, slab, tasks, n_tasks, C,
+                           n_actions, act, hid);
+    else if (tiled)
         hipLaunchKernelGGL(dqn_fc1_tiled_kernel<DQ_FC1_TNB>, fg, dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions, act, hid);
     else if (n_tasks <= DQ_FC1_NARROW_MAX_TASKS)
         hipLaunchKernelGGL(dqn_fc1_narrow_kernel<DQ_FC1_NBN>, dim3(n_tasks, 32), dim3(64), 0, s, slab, tasks, n_tasks, C, n_actions,

@@ -73,6 +73,14 @@ __host__ __device__ inline int64_t dqn_fc1_slab_to_flat(int64_t i, int tiled)   
     return (ob * 64 + l) * DQ_FC1_IN + kq * 4 + c;
 }
 
+// ... and back: fc1.w[out][k] -> position inside the block
+__host__ __device__ inline int64_t dqn_fc1_flat_to_slab(int64_t out, int64_t k, int tiled)
+{
+    const int64_t ob = out >> 6, o = out & 63;
+    if (tiled) return ((((ob * 196 + (k >> 4)) * 4 + (o >> 4)) * 64 + 16 * (k & 3) + (o & 15)) << 2) + ((k >> 2) & 3);
+    return (((ob * 784 + (k >> 2)) * 64 + o) << 2) + (k & 3);
+}
+
 // slab position -> canonical flat index (parameters() order: conv1.w conv1.b conv2.w conv2.b conv3.w conv3.b fc1.w
 // fc1.b output.w output.b vbn1.w vbn1.b vbn2.w vbn2.b vbn3.w vbn3.b); -1 for padding
 __host__ __device__ inline int64_t dqn_slab_to_flat(int64_t s, int C, int n, int fc1_tiled = 0)

@@ -141,6 +141,21 @@ __global__ __launch_bounds__(256) void dqn_unpack_kernel(const float *slab, floa
     if (f >= 0) flat[(int64_t)blockIdx.y * P + f] = slab[(int64_t)blockIdx.y * L.stride + s];
 }
 
+// dst (fc1 layout dst_tiled) := src (fc1 layout src_tiled): everything outside the fc1 block keeps its place
+__global__ __launch_bounds__(256) void dqn_relayout_kernel(const float *src, float *dst, int C, int n, int src_tiled, int dst_tiled)
+{
+    const DqnLayout L = dqn_layout(C, n);
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= L.stride) return;
+    const float *sn = src + (int64_t)blockIdx.y * L.stride;
+    int64_t from = s;
+    if (s >= L.wf && s < L.bf) {
+        const int64_t f = dqn_fc1_slab_to_flat(s - L.wf, dst_tiled);
+        from = L.wf + dqn_fc1_flat_to_slab(f / DQ_FC1_IN, f % DQ_FC1_IN, src_tiled);
+    }
+    dst[(int64_t)blockIdx.y * L.stride + s] = sn[from];
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Synthetic two-player env in the shape of pettingzoo.atari (agents first_0, second_0 alternate; uint8 84x84xC frames).
 // It has no game dynamics, but it IS sequential: the frame an agent observes at agent-step t is keyed by the game's
@@ -254,6 +269,23 @@ extern "C" int coevo_dqn_perturb(const float *parent_slab, const int32_t *parent
     hipLaunchKernelGGL(dqn_perturb_kernel, grid, dim3(256), 0, (hipStream_t)stream, parent_slab, parent_idx, child_slab,
                        child_first, C, n_actions, sigma_dev, seed, stream_lo_first, stream_hi, flags, E, gen_dev, gen_bias,
                        dist_ref, dist_partial, tiled);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
+}
+
+// n nets from one fc1 layout into the other (c_arg_src / c_arg_dst: the channel arguments of the two slabs; same channels).
+// A Co-ES engine keeps its nets streamed (one frame per task in the rollout) and plays the ten evaluation games of the updated
+// base nets (evolutionary_strategy.py:272) - one 10-frame task per agent-step - on tiled twins of them.
+extern "C" int coevo_dqn_relayout(const float *src_slab, float *dst_slab, int n, int c_arg_src, int c_arg_dst, int n_actions,
+                                  void *stream)
+{
+    if (!src_slab || !dst_slab || src_slab == dst_slab || n <= 0 || n > 65535 || !dqn_carg_ok(c_arg_src, n_actions) ||
+        !dqn_carg_ok(c_arg_dst, n_actions) || dqn_channels(c_arg_src) != dqn_channels(c_arg_dst))
+        return COEVO_ERR_ARG;
+    const int C = dqn_channels(c_arg_src);
+    const dim3 grid((unsigned)((dqn_layout(C, n_actions).stride + 255) / 256), (unsigned)n);
+    hipLaunchKernelGGL(dqn_relayout_kernel, grid, dim3(256), 0, (hipStream_t)stream, src_slab, dst_slab, C, n_actions,
+                       dqn_fc1_tiled(c_arg_src), dqn_fc1_tiled(c_arg_dst));
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }

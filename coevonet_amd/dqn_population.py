@@ -701,8 +701,15 @@ class DQNESEngine(_SlabMixin):
             bounds = [b - (b & 1) for b in bounds[:-1]] + [bounds[-1]]   # an individual's two games stay in one cohort
         self.ro = cls(games, net_off, ordinal0, C, n_actions, self.slab, env_seed, self.per_gen, device, bounds=bounds)
         self.ro.set_limits(np.full(self.n_main, self.T_train, dtype=np.int32))
-        self.eval_ro = cls([(0, 1)] * N_EVAL, net_off[:2], [first_ordinal + 2 * pop + j for j in range(N_EVAL)],
-                                    C, n_actions, self.slab, env_seed, self.per_gen, device)
+        # the ten evaluation games of the updated base nets (one 10-frame task per agent-step) play on TILED twins of the two
+        # base nets (fc1 laid out for v_mfma_f32_16x16x4: the narrow fc1 launch then has no cross-lane operand moves, 25 ->
+        # ~16 us of a 68 us evaluation step); the engine's own slab stays streamed for the one-frame tasks of the rollout.
+        # COEVO_DQN_EVAL_TILED=0: evaluate on the slab itself (A/B)
+        self.eval_tiled = os.environ.get("COEVO_DQN_EVAL_TILED", "1") != "0"
+        self.eval_slab = torch.zeros(2 * self.stride, dtype=torch.float32, device=device) if self.eval_tiled else self.slab
+        self.eval_ro = cls([(0, 1)] * N_EVAL, [0, self.stride] if self.eval_tiled else net_off[:2],
+                           [first_ordinal + 2 * pop + j for j in range(N_EVAL)], C, n_actions, self.eval_slab, env_seed,
+                           self.per_gen, device, fc1_tiled=self.eval_tiled)
         self.eval_ro.set_limits(np.full(N_EVAL, self.T_eval, dtype=np.int32))
         f32 = dict(dtype=torch.float32, device=device)
         self.gen_dev = torch.zeros(1, dtype=torch.int32, device=device)
@@ -767,6 +774,10 @@ class DQNESEngine(_SlabMixin):
             L.call("coevo_dqn_es_apply", self._ptr(r, "base"), self.partials.data_ptr() + 4 * self.part_off[r],
                    self.chunks, self.chunks_local, self.part_block, self.C, self.n_actions, self.pop,
                    self.sigma.data_ptr() + 4 * ri, L.C.c_float(lr))
+        if self.eval_tiled:   # the updated base nets -> their tiled twins (two 6.75 MB copies)
+            for ri, r in enumerate(ROLES2):
+                L.call("coevo_dqn_relayout", self._ptr(r, "base"), self.eval_slab.data_ptr() + 4 * ri * self.stride, 1, self.C,
+                       self.C | L.DQN_FC1_TILED, self.n_actions)
         # the ten evaluation games of the updated base nets: a chain of 3 x T_eval small dependent launches (29 % of a cfg 5
         # generation when enqueued one by one) - replayed as one hipGraph (the generation index is read from the device)
         if self.eval_graph:

@@ -207,6 +207,7 @@ _SIGS = {
     "coevo_timing_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "coevo_timing_end": (C.c_int, [C.c_void_p, C.c_void_p]),
     "coevo_dqn_unpack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "coevo_dqn_relayout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "coevo_dqn_perturb_blocks": (C.c_int64, [C.c_int, C.c_int]),
     "coevo_dqn_perturb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                     C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_int,

@@ -557,6 +557,8 @@ int coevo_dqn_forward_hidden_timed(const float *slab, const coevo_dqn_task *task
 int coevo_timing_begin(void *ctx, void *stream);
 int coevo_timing_end(void *ctx, void *stream);
 int coevo_dqn_unpack(const float *slab, float *flat, int n, int C, int n_actions, void *stream);
+/* n nets from a slab of one fc1 layout into a slab of the other (channel arguments of the two slabs; slab strides are equal) */
+int coevo_dqn_relayout(const float *src_slab, float *dst_slab, int n, int C_src, int C_dst, int n_actions, void *stream);
 
 /* ---------------------------------------------------------------- DeepQN population engine (cfg 4 / cfg 5) ---------- */
 /* Offspring of the DeepQN layout on the device: child = parent +- sigma * eps(seed, stream, p), p = canonical flat index

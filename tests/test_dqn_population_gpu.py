@@ -43,6 +43,11 @@ def test_dqn_perturb_bit_exact_vs_oracle(Cp, n, tiled):
     parents = [rp.dqn_init(Cp, n)[0] for _ in range(3)]
     slab, stride = _slab(parents, C, n)
     assert np.array_equal(_unpack(L._p(slab), 3, C, n), np.stack(parents))        # pack / unpack round trip
+    other = Cp | (0 if tiled else L.DQN_FC1_TILED)                                  # ... and through the other fc1 layout
+    twin = torch.zeros_like(slab)
+    L.call("coevo_dqn_relayout", L._p(slab), L._p(twin), 3, C, other, n)
+    assert np.array_equal(_unpack(L._p(twin), 3, other, n), np.stack(parents)) and not torch.equal(twin, slab)
+    assert L.load().coevo_dqn_relayout(L._p(slab), L._p(slab), 3, C, other, n, None) == -1   # in place: refused
     P = len(parents[0])
     sigma = torch.tensor([0.05], dtype=torch.float32, device=DEV)
     seed, shi = 0xABCDEF0123, 9
