@@ -925,10 +925,11 @@ __global__ __launch_bounds__(64) void dqn_fc1_narrow_kernel(const float *slab, c
 }
 
 // dqn_fc1_narrow_kernel over the TILED fc1 block: the 16-byte piece of lane (c, kk) of tile (ob, Q, T) is the B operand of
-// k-quads 4 Q .. 4 Q + 3 as it is, and the A operands x[row c][16 Q + 4 j + kk] come as four dwords straight from memory (L2
-// hits): no cross-lane move at all.  The streamed form pays two 4x4 transposes (eight v_permlane swaps) per four matrix
-// instructions - ~20 of a lone wave's ~65 cycles per instruction on top of the 45-cycle dependent step; here the launch is
-// the chain: 784 x 45 cycles = 14.7 us (measured: profiles/r05_experiments.md).
+// k-quads 4 Q .. 4 Q + 3 as it is; the A operands x[row c][16 Q + 4 j + kk] still come as ONE 16-byte load per lane and a 4x4
+// transpose (four v_permlane swaps per four matrix instructions, half of the streamed form's eight: they issue in the shadow of
+// the dependent matrix instructions).  Two loads per super-quad instead of the five of an all-dword form matter more than the
+// swaps: a wave can count 63 loads in flight, i.e. 31 super-quads = 2.3 us of chain ahead instead of 0.9 (measured: all-dword
+// 22.4 us per launch, interleaved or not; streamed 25.2; this form: profiles/r05_experiments.md).
 template <int NB>
 __global__ __launch_bounds__(64) void dqn_fc1_narrow_tiled_kernel(const float *slab, const coevo_dqn_task *tasks, int n_tasks, int C,
                                                                    int n_actions, const float *act, float *hid)
@@ -946,48 +947,66 @@ __global__ __launch_bounds__(64) void dqn_fc1_narrow_tiled_kernel(const float *s
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = bb;
     }
+    typedef unsigned u32x2_s __attribute__((ext_vector_type(2)));
     constexpr int NSQ = 196, NCH = NSQ / U;
     static_assert(NSQ % U == 0 && NCH % NB == 0, "whole rounds of the ring");
     const float4 *wp = reinterpret_cast<const float4 *>(net + L.wf) + ((size_t)ob * NSQ * 4 + T) * 64 + l;
-    const float *xp = act + (size_t)(task.row_begin + min(c, nrows - 1)) * DQ_FC1_IN + kk;
-    float4 wv[NB][U];
-    float xv[NB][U][4];
-    auto issue = [&](float4 (&w)[U], float (&x)[U][4], int sq) {
+    const float4 *xp = reinterpret_cast<const float4 *>(act + (size_t)(task.row_begin + min(c, nrows - 1)) * DQ_FC1_IN) + kk;
+    float4 wv[NB][U], xv[NB][U];
+    auto issue = [&](float4 (&w)[U], float4 (&x)[U], int sq) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             w[u] = wp[(size_t)(sq + u) * 256];   // (plain loads: the same two nets every step)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) x[u][j] = xp[16 * (sq + u) + 4 * j];
+            x[u] = xp[4 * (sq + u)];             // x[row c][16 (sq + u) + 4 kk .. + 3]
         }
     };
 #pragma unroll
     for (int b = 0; b < NB - 1; ++b) issue(wv[b], xv[b], b * U);
-    // The loads of chunk c + NB - 1 are issued BETWEEN the matrix instructions of chunk c, one or two behind each (the order
-    // pinned): a dependent v_mfma_f32_16x16x4 leaves ~45 cycles in which the wave issues nothing else, and a wave issues in
-    // order - as a block in front of the chunk's matrix instructions the 35 loads cost their own issue time on top of the
-    // chain (22.3 us per launch = 784 x 68 cycles; the chain alone is 784 x 45).
+    // The transpose of super-quad s + 1 is issued one swap behind each matrix instruction of super-quad s (the order pinned): a
+    // dependent v_mfma_f32_16x16x4 leaves ~45 cycles in which the in-order wave can issue an independent vector instruction
+    // for free; as four swaps in front of their own four matrix instructions they sat on the chain (63 cycles per step).
+    float a_cur[4], a_nxt[4];
+    auto tr_a = [&](const float4 &v, u32x2_s &s02, u32x2_s &s13) {
+        s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v.x), __float_as_uint(v.z), false, false);
+        s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v.y), __float_as_uint(v.w), false, false);
+    };
+    {
+        u32x2_s s02, s13;
+        tr_a(xv[0][0], s02, s13);
+        const u32x2_s y01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
+        const u32x2_s y23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
+        a_cur[0] = __uint_as_float(y01[0]); a_cur[1] = __uint_as_float(y01[1]);
+        a_cur[2] = __uint_as_float(y23[0]); a_cur[3] = __uint_as_float(y23[1]);
+    }
 #pragma nounroll
     for (int c0 = 0; c0 < NCH; c0 += NB) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const int nxt = min(c0 + b + NB - 1, NCH - 1) * U;   // (clamped, unconditional: straight-line code)
-            float4 (&wn)[U] = wv[(b + NB - 1) % NB];
-            float (&xn)[U][4] = xv[(b + NB - 1) % NB];
+            const int nxt = min(c0 + b + NB - 1, NCH - 1);   // (clamped, unconditional: straight-line code)
+            issue(wv[(b + NB - 1) % NB], xv[(b + NB - 1) % NB], nxt * U);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[b][u][0], wv[b][u].x, acc, 0, 0, 0);
-                wn[u] = wp[(size_t)(nxt + u) * 256];
+                // the super-quad after this one: the next of the chunk, or the first of the next chunk (the last one of all
+                // transposes a piece nobody uses)
+                const float4 &vn = (u + 1 < U) ? xv[b][u + 1] : xv[(b + 1) % NB][0];
+                u32x2_s s02, s13;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[0], wv[b][u].x, acc, 0, 0, 0);
+                s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(vn.x), __float_as_uint(vn.z), false, false);
                 __builtin_amdgcn_sched_barrier(0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[b][u][1], wv[b][u].y, acc, 0, 0, 0);
-                xn[u][0] = xp[16 * (nxt + u)];
-                xn[u][1] = xp[16 * (nxt + u) + 4];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[1], wv[b][u].y, acc, 0, 0, 0);
+                s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(vn.y), __float_as_uint(vn.w), false, false);
                 __builtin_amdgcn_sched_barrier(0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[b][u][2], wv[b][u].z, acc, 0, 0, 0);
-                xn[u][2] = xp[16 * (nxt + u) + 8];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[2], wv[b][u].z, acc, 0, 0, 0);
+                const u32x2_s y01 = __builtin_amdgcn_permlane16_swap(s02[0], s13[0], false, false);
                 __builtin_amdgcn_sched_barrier(0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[b][u][3], wv[b][u].w, acc, 0, 0, 0);
-                xn[u][3] = xp[16 * (nxt + u) + 12];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[3], wv[b][u].w, acc, 0, 0, 0);
+                const u32x2_s y23 = __builtin_amdgcn_permlane16_swap(s02[1], s13[1], false, false);
                 __builtin_amdgcn_sched_barrier(0);
+                a_nxt[0] = __uint_as_float(y01[0]); a_nxt[1] = __uint_as_float(y01[1]);
+                a_nxt[2] = __uint_as_float(y23[0]); a_nxt[3] = __uint_as_float(y23[1]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a_cur[j] = a_nxt[j];
             }
         }
     }
