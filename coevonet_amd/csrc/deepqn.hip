@@ -692,7 +692,7 @@ __global__ __launch_bounds__(64, (HALF || NB <= DQ_FC1_NB_MANY) ? 2 : 1) void dq
     const DqnLayout L = dqn_layout(C, n_actions);
     const int ob = blockIdx.y, l = threadIdx.x;
 #ifdef COEVO_PHASE_STAMPS
-    // diagnostic build only (tools/dqn_fc1_clock.py): shader-clock and 100 MHz stamps of wave (task ti, block 0) -> the clock
+    // diagnostic build only (round 4: tools/dqn_fc1_clock.py, retired - profiles/r04_experiments.md): shader-clock and 100 MHz stamps of wave (task ti, block 0) -> the clock
     // the chip holds during this launch
     if (ob == 0 && l == 0 && ti < 1024) {
         g_dqn_stamps[ti * 16 + 10] = __builtin_amdgcn_s_memrealtime();

@@ -12,7 +12,7 @@
 //                              4 rows, one k per instruction); the A operands of a row group are one ds_read_b128
 //   out  W3[5][256]            staged through LDS once
 // Arithmetic per weight byte is tiny (R FMAs per 4 bytes), but as VALU FMAs fed by LDS broadcasts it still cost a lone
-// workgroup 27 us per net against ~5 us of HBM time (tools/stream_probe.hip): the matrix pipe, otherwise idle here,
+// workgroup 27 us per net against ~5 us of HBM time (round 1 probe; the stream rate of one CU: tools/stream_waves_probe.hip): the matrix pipe, otherwise idle here,
 // does the same sequential-k fma chains (tools/mfma4_chain_probe.hip: bit-identical) in far fewer issue slots and LDS
 // reads.  (v_mfma_f32_16x16x4_f32, tools/mfma16_chain_probe.hip, is exact as well but spends 16 tile rows on <= 8.)
 // All fp32 math follows the canonical order in coevo_common.hip.h, so logits equal the oracle's bit for bit.
@@ -105,7 +105,7 @@ __device__ inline void stamp_end(unsigned long long *stamps)
 }
 
 #ifdef COEVO_PHASE_STAMPS
-// diagnostic build only (tools/phase_stamps.py): per-workgroup shader-clock stamps at the phase boundaries of the
+// diagnostic build only (tools/merged_wg_times.py): per-workgroup shader-clock stamps at the phase boundaries of the
 // streaming kernel, written to a buffer nothing else reads
 __device__ unsigned long long g_phase_stamps[4096 * 16];
 #define COEVO_STAMP(i)                                                                          \

@@ -143,7 +143,7 @@ struct HostRollout {
     // ... and the other direction: a cohort's NEXT launch is queued while the core still steps the games, behind a stream
     // wait on a word of the same page (hipStreamWaitValue32, >=), and released by a plain store when the observations stand
     // - no runtime call between the last observation and the launch's start (release -> completion of an empty kernel 6 us,
-    // against 16 us for launching it then: tools/wait_value_probe.hip).  COEVO_HOST_PREQUEUE=0 for A/B.
+    // against 16 us for launching it then: round 4 probe, profiles/r04_experiments.md).  COEVO_HOST_PREQUEUE=0 for A/B.
     volatile uint32_t *gates = nullptr;   // one per cohort, 64 bytes apart (second half of the page)
     uint32_t gate_issued[COEVO_MAX_COHORTS] = {0, 0, 0, 0, 0, 0, 0, 0};     // target of the newest queued wait
     uint32_t gate_released[COEVO_MAX_COHORTS] = {0, 0, 0, 0, 0, 0, 0, 0};   // value last stored

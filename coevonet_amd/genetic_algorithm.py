@@ -190,7 +190,7 @@ class GAEngine:
         # (env on the host cores: the cohorts alternate between the cores and the GPU - COEVO_HOST_COHORTS, default 4: the
         # chain launch -> actions -> host step -> next launch of ONE cohort is ~90 us of latency however many cores step it;
         # four chains in flight hide most of it, six or more share hardware queues and serialise - profiles/r04_experiments.md)
-        # ... a small batch fewer: ~700 games per cohort (550 games: one cohort 792 generations/s, four 671: tools/host_soak.py)
+        # ... a small batch fewer: ~700 games per cohort (550 games: one cohort 792 generations/s, four 671: profiles/r04_experiments.md)
         host_k = int(os.environ.get("COEVO_HOST_COHORTS", "0")) or max(1, min(4, len(games) // 700))
         self.K = max(1, min(int(cohorts) if env == "device" else host_k, self.n_local))
         row_order = "class" if env == "device" else "cohort"
