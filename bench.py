@@ -684,18 +684,19 @@ def run_ga(a, ctx, dev):
                              "rollout_span_ms": span_ms, "launches": K * eng.ro._span_cycles,
                              "note": "algorithmic bytes of every policy launch of one rollout / (first workgroup start "
                                      ".. last workgroup end of the rollout)"}
-            # which instantiation the C side picks (coevo_mpe_policy_cycle_merged): row-count template, lean 16-row
-            # tiles when both cohorts' workgroups fit four per CU, else 32-row tiles (two nets per streaming workgroup
-            # when one per workgroup would not fit two per CU)
+            # which instantiation the C side picks (coevo_mpe_policy_cycle_merged -> coevo_mpe_cycle_kernel_form): row-count
+            # template; the small-launch kernel when no CU holds more than one workgroup, lean 16-row tiles when both
+            # cohorts' workgroups fit four per CU, else 32-row tiles (two nets per streaming workgroup when one per
+            # workgroup would not fit two per CU)
             Kc = max(eng.ro.n_cohorts, 1)
             R = next(r for r in (1, 2, 5, 8, 32) if eng.plan.light_max <= r)
-            cus = torch.cuda.get_device_properties(dev).multi_processor_count
-            per_launch = (len(eng.plan.heavy_np) + len(eng.plan.light_np)) / Kc
-            lean = merged and eng.plan.heavy_max <= 16 and per_launch * Kc <= 4 * cus
-            if lean:
-                kernel_id = f"fc_cycle16_kernel<{R}, 2>"   # <rows per streaming task, MODE_FUSED>
-            elif merged:
-                kernel_id = f"fc_cycle_kernel<{R}, {2 if per_launch * Kc > 2 * cus else 1}>"
+            if merged:
+                hb, lb = eng.plan.heavy_begin_np, eng.plan.light_begin_np
+                form = L.load().coevo_mpe_cycle_kernel_form(int(hb[1] - hb[0]), int(lb[1] - lb[0]), eng.plan.heavy_max,
+                                                            eng.plan.light_max, Kc)
+                Rs = next(r for r in (1, 2, 5, 8) if max(eng.plan.light_max, min(eng.plan.heavy_max, 8)) <= r)
+                kernel_id = {0: f"fc_cycle_kernel<{R}, 1>", 1: f"fc_cycle_kernel<{R}, 2>", 2: f"fc_cycle16_kernel<{R}, 2>",
+                             3: f"fc_cycle_small_kernel<{Rs}, 2>"}[form]
             else:
                 kernel_id = f"fc_policy_kernel<{R}, 2>"
             traffic, traffic_note = None, None

@@ -302,7 +302,7 @@ int coevo_mpe_policy_cycle_fused(const float *slab, const coevo_fc_task *tasks, 
  * `concurrent_launches` such launches (cohorts running side by side, else 1) exceed those slots, a streaming workgroup
  * carries two nets so that everything is resident in one round.  heavy_max_rows <= 16 selects the lean kernel (four
  * workgroups per CU, 16-row shared-opponent tiles) when everything then fits at one net per workgroup; heavy_max_rows <= 8
- * with at most two workgroups per CU in flight selects the small-launch kernel (every task through the per-individual body,
+ * with no more workgroups in flight than the device has CUs selects the small-launch kernel (every task through the per-individual body,
  * fc2 on the vector ALU: a rank of a population sharded over several GPUs, genetic_algorithm.py:125-217 split by index). */
 #define COEVO_CYCLE_FORM_TILE32 0         /* 32-row shared-opponent tiles, one net per streaming workgroup, two per CU */
 #define COEVO_CYCLE_FORM_TILE32_PAIRED 1  /* ... two nets per streaming workgroup */
