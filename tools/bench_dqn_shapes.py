@@ -20,6 +20,7 @@ ap.add_argument("--shape", default="cfg4")
 ap.add_argument("--C", type=int, default=4)
 ap.add_argument("--reps", type=int, default=40)
 ap.add_argument("--interleave", action="store_true", help="cfg4: HoF nets spread among the population nets in the task table")
+ap.add_argument("--fc1", default="streamed", choices=("streamed", "tiled"), help="fc1 layout of the slab (COEVO_DQN_FC1_TILED)")
 ap.add_argument("--task-rows", type=int, default=L.DQN_MAX_ROWS, help="rows per task of a net that acts in many games")
 a = ap.parse_args()
 dev = "cuda"
@@ -72,10 +73,11 @@ status = torch.zeros(1, dtype=torch.int32, device=dev)
 ws = torch.zeros(int(lib.coevo_dqn_workspace_bytes(row)) // 4, dtype=torch.float32, device=dev)
 tc = [lib.coevo_rollout_ctx_create(a.reps + 8) for _ in range(2)]
 stream = torch.cuda.current_stream().cuda_stream
+c_arg = a.C | (L.DQN_FC1_TILED if a.fc1 == "tiled" else 0)
 
 
 def run(which=None):
-    L._check(lib.coevo_dqn_forward_argmax_timed(L._p(slab), L._p(d_tasks), len(layout), a.task_rows, row, a.C, n_act, L._p(frames),
+    L._check(lib.coevo_dqn_forward_argmax_timed(L._p(slab), L._p(d_tasks), len(layout), a.task_rows, row, c_arg, n_act, L._p(frames),
                                                 L._p(actions), None, L._p(status), L._p(ws),
                                                 tc[which] if which is not None else None, which or 0, stream), "fwd")
 
@@ -103,7 +105,7 @@ conv, fc1 = times(tc[0]), times(tc[1])
 mac = 3276800 + 2654208 + 1806336 + (a.C - 4) * 64 * 32 * 400
 tf = row * 2 * mac / (conv.mean() * 1e-6) / 1e12
 fc1_bytes = n_nets * 512 * 3136 * 4 + row * (3136 + 512) * 4
-print(f"{a.shape} C={a.C} lib={os.path.basename(L.LIB_PATH)} flags='{(lib.coevo_build_flags() or b'').decode()}': "
+print(f"{a.shape} C={a.C} fc1={a.fc1} lib={os.path.basename(L.LIB_PATH)} flags='{(lib.coevo_build_flags() or b'').decode()}': "
       f"{row} rows, {len(layout)} tasks, {n_nets} nets | conv {conv.mean():.1f} us (min {conv.min():.1f}) = {tf:.1f} TF/s "
       f"= {tf / 157.3:.3f} | fc1 {fc1.mean():.1f} us (min {fc1.min():.1f}) = {fc1_bytes / fc1.mean() / 1e6:.2f} TB/s "
       f"= {fc1_bytes / fc1.mean() / 1e6 / 8:.3f} | step (3 launches) {step:.1f} us")
