@@ -697,6 +697,15 @@ def run_ga(a, ctx, dev):
                 Rs = next(r for r in (1, 2, 5, 8) if max(eng.plan.light_max, min(eng.plan.heavy_max, 8)) <= r)
                 kernel_id = {0: f"fc_cycle_kernel<{R}, 1>", 1: f"fc_cycle_kernel<{R}, 2>", 2: f"fc_cycle16_kernel<{R}, 2>",
                              3: f"fc_cycle_small_kernel<{Rs}, 2>"}[form]
+                persistent = (form == 3 and getattr(eng.ro, "sync_words", None) is not None
+                              and os.environ.get("COEVO_PERSISTENT", "1") != "0")
+                if persistent and aggregate:
+                    # ONE launch plays the whole rollout (coevo_mpe_rollout_persistent): a "launch" of the roofline block is
+                    # one env-cycle of it = the rollout's span / its cycles (the per-cycle stamps - earliest start after the
+                    # wait .. latest action posted - overlap from cycle to cycle and would overstate it)
+                    kernel_id = f"fc_rollout_small_kernel<{Rs}>"
+                    avg_ms = aggregate["rollout_span_ms"] / max(eng.ro._span_cycles, 1)
+                    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
             else:
                 kernel_id = f"fc_policy_kernel<{R}, 2>"
             traffic, traffic_note = None, None
@@ -711,12 +720,17 @@ def run_ga(a, ctx, dev):
                     if kernel_id in j.get("dominant_kernel", ""):
                         traffic = j["dominant_kernel_hbm_bytes_per_launch"]
                         traffic_note = "profiles/r02_pmc_hbm_traffic.json (rocprofv3 --pmc passes of this command)"
-            kname = (kernel_id +
+            kname = (kernel_id + " (one env-cycle of the persistent whole-rollout launch: every task's weight set streamed "
+                     "once per cycle, fused env step, rows exchange tagged action words)"
+                     if kernel_id.startswith("fc_rollout_small") else
+                     kernel_id +
                      " (one env-cycle of one cohort: per-individual weight sets streamed once + shared-opponent tasks "
                      "on the matrix cores, fused env step)" if merged else
                      kernel_id + " (per-individual weight sets, fused env step)")
             out["roofline"] = {"bound": "hbm", "kernel": kname,
-                               "timing": ("HIP events around each launch on its stream" if a.no_graph else
+                               "timing": ("in-kernel 100 MHz clock stamps: span of the rollout (first cycle's earliest start .. last "
+                                          "cycle's latest action) / cycles" if kernel_id.startswith("fc_rollout_small") else
+                                          "HIP events around each launch on its stream" if a.no_graph else
                                           "in-kernel 100 MHz clock stamps, first workgroup start to last workgroup "
                                           "end (HIP events cannot be read back from replayed hipGraphs; "
                                           "--no-graph uses events)"),

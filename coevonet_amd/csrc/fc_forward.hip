@@ -1548,6 +1548,382 @@ __global__ __launch_bounds__(256, 2) void fc_cycle_small_kernel(FcArgs a)
     stamp_end(a.stamps);
 }
 
+// ---- The PERSISTENT form of the small launch: a whole rollout (n_cycles env-cycles) in ONE launch ---------------------------
+// ("device-side env step fused with the forward into a persistent whole-rollout kernel".)  A launch that the small
+// kernel serves has no more workgroups than the device has CUs, so all of them are resident at once (<= 256 registers, < 80 KiB
+// of LDS: two fit a CU, i.e. even two such launches side by side are resident together) and a workgroup can keep its task for the
+// whole rollout: W1t / the LayerNorm(512) affine / W3 stay in LDS, the small parameters in registers, every row's game (fp64
+// state + the reward books) in LDS - no state buffer is read or written between the reset and the last cycle.  What the rows of
+// a game owe each other per cycle is three small integers: a row posts its action as ONE 32-bit word (cycle + 1) << 8 | action
+// (agent-scope atomic store, double buffered by cycle parity: a row can be at most one cycle ahead of the rows it plays with),
+// and the rows of cycle c spin on the three words of their game until all carry the tag c (agent-scope atomic loads; bounded: a
+// workgroup that waits too long - a third such launch squeezed its partners off the chip - raises COEVO_ST_SYNC_TIMEOUT and
+// the abort word, which every waiter also watches, so the grid drains).  The data IS the flag: nothing else crosses between
+// workgroups, so no fence and no cache maintenance is needed.
+// The arithmetic is fc_policy_body_c<R, MODE_FUSED, FC2_DPP>'s and mpe_fused_observe's, operation for operation; the last cycle
+// leaves the state buffer and the plain action words exactly as the per-cycle launches do, for coevo_mpe_final_step.
+template <int R>
+struct FcSmemP {
+    static constexpr int NG = (R + 3) / 4;
+    float par[13 * H1];                      // resident: W1t [D][512], fc1.bias, ln1.weight, ln1.bias
+    float h1r[R][H1];                        // fc2's activations, row-major (FC2_DPP)
+    float h2[R][260];
+    float w3s[NACT][260];                    // resident
+    float xs0[4 * NG][COEVO_OBS_STRIDE];
+    float red[4][16], red2[4][16];
+    float logit[R][COEVO_LOGIT_STRIDE];
+    double gs[8][24];                        // per row: its game (MpeGame, 18 doubles) + the books [18..21]
+    float p2[3][H2];                         // resident: fc2.bias, ln2.weight, ln2.bias (read where used: registers are short)
+    float pb3[8];                            // output.bias
+    int rowinfo[8][4];                       // per row: game, env slot, agent-step limit
+    int ctl[4];                              // [0]: leave the cycle loop (a wait timed out somewhere)
+};
+
+#ifndef COEVO_SYNC_SPINS
+#define COEVO_SYNC_SPINS (1 << 21)   // polls of ~0.5-1 us each before a waiting row gives up (seconds, not microseconds)
+#endif
+
+struct PersistArgs {
+    int n_cycles;
+    int32_t *sync;        // [4 + 2 * 3 * n_games]: [0] abort word, tagged actions [parity][game][slot] from [4]; zeroed before the launch
+    double *state_alt;    // the second state buffer (buffer 1); a.state is buffer 0 (the reset state)
+    int32_t *act_plain;   // actions_by_game [2][n_games][3]: only the last cycle's plain actions are written
+};
+
+template <int R>
+__global__ __launch_bounds__(256, 2) void fc_rollout_small_kernel(FcArgs a, PersistArgs pa)
+{
+    __shared__ __attribute__((aligned(16))) FcSmemP<R> sm;
+    static_assert(sizeof(FcSmemP<R>) <= 80 * 1024, "two workgroups per CU");
+    constexpr int NG = FcSmemP<R>::NG;
+    constexpr int US = COEVO_SMALL_U;
+    typedef float f32x4_acc __attribute__((ext_vector_type(4)));
+    const int t = threadIdx.x, w = t >> 6, l = t & 63;
+    const bool heavy = (int)blockIdx.x < a.n_heavy;   // workgroup-uniform
+    const coevo_fc_task task = heavy ? a.tasks[blockIdx.x] : a.light_tasks[(int)blockIdx.x - a.n_heavy];
+    const int D = task.D, nrows = task.n_rows, row0 = task.row_begin;
+    const float *net = a.slab + task.net_off;
+    const size_t N = (size_t)a.n_games;
+    int st = 0;
+
+    // ---- once: parameters into LDS / registers, every row's game into LDS ---------------------------------------------------
+    const int n_pieces = (D + 3) * (H1 / 4);
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+        if (64 * w + 256 * j < n_pieces)   // wave-uniform
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(net + 4 * (t + 256 * j)),
+                                             (__attribute__((address_space(3))) void *)(&sm.par[4 * (64 * w + 256 * j)]),
+                                             16, 0, 0);
+    {
+        const float *W3 = net + fc_off_w3(D);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) sm.w3s[(t + 256 * j) >> 8][(t + 256 * j) & 255] = W3[t + 256 * j];
+    }
+    {
+        const float *b2p = net + fc_off_b2(D);
+        sm.p2[0][t] = b2p[t]; sm.p2[1][t] = b2p[H2 + t]; sm.p2[2][t] = b2p[2 * H2 + t];
+        if (t < NACT) sm.pb3[t] = net[fc_off_b3(D) + t];
+    }
+    const float4 *wps = reinterpret_cast<const float4 *>(net + fc_off_w2(D)) + (size_t)w * 128 * 64 + l;
+    float4 sbufA[US], sbufB[US];
+    if (w == 0 && l < nrows) {
+        const int g = a.row_game[row0 + l];
+        sm.rowinfo[l][0] = g;
+        sm.rowinfo[l][1] = a.row_slot[row0 + l];
+        sm.rowinfo[l][2] = a.game_limit ? a.game_limit[g] : 0x7fffffff;
+#pragma unroll
+        for (int f = 0; f < 22; ++f) sm.gs[l][f] = a.state[(size_t)f * N + g];
+    }
+    if (t == 0) sm.ctl[0] = 0;
+    int32_t *const tags = pa.sync + 4;
+
+    for (int c = 0; c < pa.n_cycles; ++c) {
+        // (an opaque zero in the once-per-cycle global addresses of wave 0: left alone, the compiler computes all of them in
+        // front of the loop and spills them across it)
+        int zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+        // ---- env step + observation: one lane per row (wave 0); cycle c > 0 first waits for the three actions of cycle c - 1 --
+        // (the first two buffers of this cycle's fc2 stream are requested by waves 1-3 as soon as they get here - under wave 0's
+        // output chain of the previous cycle, its wait and its env step - and by wave 0 behind its env step, whose fp64 state is the
+        // kernel's register peak: held across it they spilled)
+        auto prefetch = [&]() {
+#pragma unroll
+            for (int uu = 0; uu < US; ++uu) sbufA[uu] = wps[(size_t)uu * 64];
+#pragma unroll
+            for (int uu = 0; uu < US; ++uu) sbufB[uu] = wps[(size_t)(US + uu) * 64];
+        };
+        if (w != 0) {
+            prefetch();
+        } else {
+        if (l < 4 * NG) {
+            float o[COEVO_OBS_STRIDE];
+#pragma unroll
+            for (int k = 0; k < COEVO_OBS_STRIDE; ++k) o[k] = 0.0f;
+            if (l < nrows) {
+                const int g = sm.rowinfo[l][0], slot = sm.rowinfo[l][1], limit = sm.rowinfo[l][2];
+                MpeGame s;
+                s.ax = sm.gs[l][0]; s.ay = sm.gs[l][1]; s.bx = sm.gs[l][2]; s.by = sm.gs[l][3]; s.cx = sm.gs[l][4]; s.cy = sm.gs[l][5];
+                s.avx = sm.gs[l][6]; s.avy = sm.gs[l][7]; s.bvx = sm.gs[l][8]; s.bvy = sm.gs[l][9]; s.cvx = sm.gs[l][10];
+                s.cvy = sm.gs[l][11]; s.l0x = sm.gs[l][12]; s.l0y = sm.gs[l][13]; s.l1x = sm.gs[l][14]; s.l1y = sm.gs[l][15];
+                s.gx = sm.gs[l][16]; s.gy = sm.gs[l][17];
+                if (c > 0) {
+                    const int32_t *tp = tags + (size_t)((c - 1) & 1) * 3 * N + 3 * (size_t)(g + zero);
+                    int w0 = 0, w1 = 0, w2 = 0;
+                    bool ok = false;
+                    for (int it = 0; it < COEVO_SYNC_SPINS; ++it) {
+                        w0 = __hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        w1 = __hip_atomic_load(tp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        w2 = __hip_atomic_load(tp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const int ab = __hip_atomic_load(pa.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = (w0 >> 8) == c && (w1 >> 8) == c && (w2 >> 8) == c;
+                        if (ok || ab) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (!ok) {   // timed out, or somebody else did: everybody leaves
+                        st |= COEVO_ST_SYNC_TIMEOUT;
+                        __hip_atomic_store(pa.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sm.ctl[0] = 1;
+                    } else {
+                        // mpe_fused_observe's step of cycle c from the state of cycle c - 1 (same operations, same order)
+                        const int t0 = 3 * (c - 1);
+                        const bool stepped = t0 + 2 < limit;
+                        double r_good = 0.0, r_adv = 0.0;
+                        if (stepped) {
+                            const int a0 = w0 & 0xff, a1 = w1 & 0xff, a2 = w2 & 0xff;
+                            if (slot == COEVO_SLOT_ADVERSARY) mpe_world_step(s, a0, a1, a2, a.pos_first, r_good, r_adv);
+                            else mpe_world_move(s, a0, a1, a2, a.pos_first);
+                        }
+                        if (slot == COEVO_SLOT_ADVERSARY) {   // the game's owner row keeps the books
+                            double rg_prev = sm.gs[l][18], a_adv = sm.gs[l][19], a_a0 = sm.gs[l][20], a_a1 = sm.gs[l][21];
+                            if (t0 < limit) a_adv = a_adv + rg_prev;
+                            if (t0 + 1 < limit) a_a0 = a_a0 + rg_prev;
+                            if (stepped) { a_a1 = a_a1 + r_adv; rg_prev = r_good; }
+                            sm.gs[l][18] = rg_prev; sm.gs[l][19] = a_adv; sm.gs[l][20] = a_a0; sm.gs[l][21] = a_a1;
+                        }
+                        sm.gs[l][0] = s.ax; sm.gs[l][1] = s.ay; sm.gs[l][2] = s.bx; sm.gs[l][3] = s.by; sm.gs[l][4] = s.cx;
+                        sm.gs[l][5] = s.cy; sm.gs[l][6] = s.avx; sm.gs[l][7] = s.avy; sm.gs[l][8] = s.bvx; sm.gs[l][9] = s.bvy;
+                        sm.gs[l][10] = s.cvx; sm.gs[l][11] = s.cvy;
+                    }
+                }
+                mpe_obs_from_game(s, slot, o);
+#pragma unroll
+                for (int k = 0; k < 10; ++k)
+                    if (!__builtin_isfinite(o[k])) st |= COEVO_ST_BAD_INPUT;
+            }
+#pragma unroll
+            for (int k = 0; k < COEVO_OBS_STRIDE; ++k) sm.xs0[l][k] = o[k];
+        }
+        prefetch();
+        }
+        if (a.stamps && t == 0)
+            atomicMin(&a.stamps[2 * (COEVO_STAMP_SLOTS * (size_t)c + blockIdx.x % COEVO_STAMP_SLOTS)],
+                      (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        __syncthreads();   // (cycle 0: waits for the LDS-DMA too)
+        if (sm.ctl[0]) break;   // workgroup-uniform
+
+        // ---- fc1 (v_mfma_f32_4x4x1, rows in groups of four) ---------------------------------------------------------------
+        const float *b1s = sm.par + D * H1;
+        f32x4_acc c0[NG], c1[NG];
+        {
+            const float bia = b1s[t], bib = b1s[t + 256];
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { c0[gq][i] = bia; c1[gq][i] = bib; }
+            float4 xk[NG][3];
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) xk[gq][j] = *reinterpret_cast<const float4 *>(&sm.xs0[4 * gq + (l & 3)][4 * j]);
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                if (k < D) {   // wave-uniform
+                    const float wa = sm.par[k * H1 + t], wb = sm.par[k * H1 + 256 + t];
+#pragma unroll
+                    for (int gq = 0; gq < NG; ++gq) {
+                        const float4 xv = xk[gq][k >> 2];
+                        const float x = (k & 3) == 0 ? xv.x : (k & 3) == 1 ? xv.y : (k & 3) == 2 ? xv.z : xv.w;
+                        c0[gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(x, wa, c0[gq], 0, 0, 0);
+                        c1[gq] = __builtin_amdgcn_mfma_f32_4x4x1f32(x, wb, c1[gq], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        const float p_g1a = b1s[H1 + t], p_g1b = b1s[H1 + t + 256], p_be1a = b1s[2 * H1 + t], p_be1b = b1s[2 * H1 + t + 256];
+        // ---- LayerNorm(512) + ReLU ------------------------------------------------------------------------------------------
+        float v[2 * R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { v[2 * r] = c0[r >> 2][r & 3]; v[2 * r + 1] = c1[r >> 2][r & 3]; }
+        {
+            const float s = packed_totals<2 * R>(v, l);
+            if (l < 2 * R) sm.red[w][l] = s;
+        }
+        __syncthreads();
+        const int lr = l < R ? l : R - 1;
+        {
+            float tot = sm.red[0][2 * lr];
+#pragma unroll
+            for (int b = 1; b < 8; ++b) tot = tot + sm.red[b & 3][2 * lr + (b >> 2)];
+            const float meanv = tot * (1.0f / H1);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(meanv), r));
+                v[2 * r] = v[2 * r] - m;
+                v[2 * r + 1] = v[2 * r + 1] - m;
+            }
+        }
+        {
+            float sq[2 * R];
+#pragma unroll
+            for (int j = 0; j < 2 * R; ++j) sq[j] = v[j] * v[j];
+            const float s = packed_totals<2 * R>(sq, l);
+            if (l < 2 * R) sm.red2[w][l] = s;
+        }
+        __syncthreads();
+        {
+            float tot = sm.red2[0][2 * lr];
+#pragma unroll
+            for (int b = 1; b < 8; ++b) tot = tot + sm.red2[b & 3][2 * lr + (b >> 2)];
+            const float rstdv = 1.0f / __builtin_sqrtf(tot * (1.0f / H1) + LN_EPS);
+            bool bad = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float rstd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rstdv), r));
+                const float y0 = __builtin_fmaf(v[2 * r] * rstd, p_g1a, p_be1a);
+                const float y1 = __builtin_fmaf(v[2 * r + 1] * rstd, p_g1b, p_be1b);
+                if (r < nrows) bad = bad || bad_post_relu(y0) || bad_post_relu(y1);
+                sm.h1r[r][t] = relu_keep_nan(y0);
+                sm.h1r[r][t + 256] = relu_keep_nan(y1);
+            }
+            if (bad) st |= COEVO_ST_BAD_FC1;
+        }
+        asm volatile("" : "+v"(st));
+        __syncthreads();
+
+        // ---- fc2 on the vector ALU (FC2_DPP) ----------------------------------------------------------------------------------
+        float u[R];
+        {
+            const float p_b2 = sm.p2[0][t];
+#pragma unroll
+            for (int r = 0; r < R; ++r) u[r] = p_b2;
+        }
+        {
+            const float *xrow = &sm.h1r[0][l & 15];
+            auto issue_s = [&](float4 (&buf)[US], int kq) {
+#pragma unroll
+                for (int uu = 0; uu < US; ++uu) buf[uu] = wps[(size_t)(kq + uu) * 64];
+            };
+            auto consume_s = [&](const float4 (&buf)[US], int kq) {
+#pragma unroll
+                for (int b = 0; b < US / 4; ++b) {
+                    float xv[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) xv[r] = xrow[r * H1 + 4 * (kq + 4 * b)];
+                    fmac_block16<R>(u, xv, buf[4 * b], buf[4 * b + 1], buf[4 * b + 2], buf[4 * b + 3]);
+                }
+            };
+#pragma nounroll
+            for (int kq = 0; kq < 128; kq += 2 * US) {
+                consume_s(sbufA, kq);
+                if (kq + 2 * US < 128) issue_s(sbufA, kq + 2 * US);   // wave-uniform
+                __builtin_amdgcn_sched_barrier(0);
+                consume_s(sbufB, kq + US);
+                if (kq + 3 * US < 128) issue_s(sbufB, kq + 3 * US);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- LayerNorm(256) + ReLU ------------------------------------------------------------------------------------------
+        {
+            const float s = packed_totals<R>(u, l);
+            if (l < R) sm.red[w][l] = s;
+        }
+        __syncthreads();
+        {
+            const float tot = ((sm.red[0][lr] + sm.red[1][lr]) + sm.red[2][lr]) + sm.red[3][lr];
+            const float meanv = tot * (1.0f / H2);
+#pragma unroll
+            for (int r = 0; r < R; ++r) u[r] = u[r] - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(meanv), r));
+            float sq[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) sq[r] = u[r] * u[r];
+            const float s = packed_totals<R>(sq, l);
+            if (l < R) sm.red2[w][l] = s;
+        }
+        __syncthreads();
+        {
+            const float tot = ((sm.red2[0][lr] + sm.red2[1][lr]) + sm.red2[2][lr]) + sm.red2[3][lr];
+            const float rstdv = 1.0f / __builtin_sqrtf(tot * (1.0f / H2) + LN_EPS);
+            const float p_g2 = sm.p2[1][t], p_be2 = sm.p2[2][t];
+            bool bad = false;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float rstd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rstdv), r));
+                const float y = __builtin_fmaf(u[r] * rstd, p_g2, p_be2);
+                if (r < nrows) bad = bad || bad_post_relu(y);
+                sm.h2[r][t] = relu_keep_nan(y);
+            }
+            if (bad) st |= COEVO_ST_BAD_FC2;
+        }
+        asm volatile("" : "+v"(st));
+        __syncthreads();
+
+        // ---- output layer + first-max action: wave 0; the action is posted as the tagged word -------------------------------
+        if (w == 0) {
+            if (l < R * NACT) {
+                const int r = l / NACT, o = l % NACT;
+                float y = sm.pb3[o];
+                const float4 *wr = reinterpret_cast<const float4 *>(&sm.w3s[o][0]);
+                const float4 *xr = reinterpret_cast<const float4 *>(&sm.h2[r][0]);
+#pragma unroll 8
+                for (int k = 0; k < H2 / 4; ++k) {
+                    const float4 wv = wr[k], xv = xr[k];
+                    y = __builtin_fmaf(wv.x, xv.x, y);
+                    y = __builtin_fmaf(wv.y, xv.y, y);
+                    y = __builtin_fmaf(wv.z, xv.z, y);
+                    y = __builtin_fmaf(wv.w, xv.w, y);
+                }
+                sm.logit[r][o] = y;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (l < nrows) {   // strict '>' scan from -inf
+                int best = -1;
+                float cur = -__builtin_inff();
+#pragma unroll
+                for (int o = 0; o < NACT; ++o) {
+                    const float vv = sm.logit[l][o];
+                    if (!__builtin_isfinite(vv)) st |= COEVO_ST_BAD_OUT;
+                    if (vv > cur) { cur = vv; best = o; }
+                }
+                if (best < 0) { st |= COEVO_ST_NO_ACTION; best = 0; }
+                const int g = sm.rowinfo[l][0], slot = sm.rowinfo[l][1];
+                __hip_atomic_store(tags + (size_t)(c & 1) * 3 * N + 3 * (size_t)(g + zero) + slot, ((c + 1) << 8) | best, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                if (c == pa.n_cycles - 1) pa.act_plain[(size_t)(c & 1) * 3 * N + 3 * (size_t)(g + zero) + slot] = best;
+                if (a.logits) {
+                    int r0 = row0;
+                    asm volatile("" : "+s"(r0));   // (not an address to carry through the loop)
+#pragma unroll
+                    for (int o = 0; o < NACT; ++o) a.logits[(size_t)(r0 + l) * COEVO_LOGIT_STRIDE + o] = sm.logit[l][o];
+                }
+            }
+        }
+        if (a.stamps && t == 0)
+            atomicMax(&a.stamps[2 * (COEVO_STAMP_SLOTS * (size_t)c + blockIdx.x % COEVO_STAMP_SLOTS) + 1],
+                      (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    }
+    // what the last per-cycle launch leaves for coevo_mpe_final_step: the state of cycle n_cycles - 1 + the books, in that
+    // cycle's buffer, written by each game's owner row (cycle 0 writes nothing: its state is the reset state in buffer 0)
+    if (w == 0 && l < nrows && sm.rowinfo[l][1] == COEVO_SLOT_ADVERSARY && pa.n_cycles > 1 && !sm.ctl[0]) {
+        const int g = sm.rowinfo[l][0];
+        double *sn = ((pa.n_cycles - 1) & 1) ? pa.state_alt : const_cast<double *>(a.state);
+#pragma unroll
+        for (int f = 0; f < 22; ++f) sn[(size_t)f * N + g] = sm.gs[l][f];
+    }
+    if (st) atomicOr(a.status, st);
+}
+
 // One launch = one env-cycle of one cohort of games (fused env step): the shared-opponent tasks first (lowest block
 // indices: they are dispatched first and are the longer workgroups), then the per-individual tasks.  Both kinds of
 // workgroup get the MFMA path's footprint (<= 256 registers, ~73 KiB LDS: two workgroups per CU), so a launch of a
@@ -1682,6 +2058,38 @@ extern "C" int coevo_mpe_cycle_kernel_form(int n_heavy, int n_light, int heavy_m
     // If one net per streaming workgroup does not fit the slots in a single round, pair the nets: the second round would
     // otherwise wait for the slots of the (long) shared-opponent workgroups.
     return wgs > slots ? COEVO_CYCLE_FORM_TILE32_PAIRED : COEVO_CYCLE_FORM_TILE32;
+}
+
+extern "C" int coevo_mpe_persistent_sync_words(int n_games) { return n_games > 0 ? 4 + 6 * n_games : COEVO_ERR_ARG; }
+
+extern "C" int coevo_mpe_rollout_persistent(const float *slab, const coevo_fc_task *heavy_tasks, int n_heavy,
+                                            const coevo_fc_task *light_tasks, int n_light, int light_max_rows, int heavy_max_rows,
+                                            double *state, double *state_alt, int n_games, const int32_t *row_game,
+                                            const int32_t *row_slot, int32_t *actions_by_game, const int32_t *game_limit,
+                                            int n_cycles, int pos_first, int32_t *status, uint64_t *stamps, int32_t *sync_words,
+                                            int concurrent_launches, void *stream)
+{
+    if (!slab || !heavy_tasks || !light_tasks || !state || !state_alt || state == state_alt || !row_game || !row_slot ||
+        !actions_by_game || !status || !sync_words || n_games <= 0 || n_cycles < 1 || n_cycles > (1 << 22))
+        return COEVO_ERR_ARG;
+    const int form = coevo_mpe_cycle_kernel_form(n_heavy, n_light, heavy_max_rows, light_max_rows, concurrent_launches);
+    if (form < 0) return form;
+    if (form != COEVO_CYCLE_FORM_SMALL) return COEVO_ERR_UNSUPPORTED;   // not all resident at once: the per-cycle launches
+    hipStream_t s = (hipStream_t)stream;
+    COEVO_HIP_CHECK(hipMemsetAsync(sync_words, 0, sizeof(int32_t) * (size_t)(4 + 6 * (size_t)n_games), s));
+    coevo::FcArgs a{};
+    a.slab = slab; a.tasks = heavy_tasks; a.state = state; a.row_game = row_game; a.row_slot = row_slot; a.n_games = n_games;
+    a.status = status; a.stamps = reinterpret_cast<unsigned long long *>(stamps); a.game_limit = game_limit;
+    a.pos_first = pos_first; a.light_tasks = light_tasks; a.n_heavy = n_heavy; a.n_light = n_light;
+    const coevo::PersistArgs pa{n_cycles, sync_words, state_alt, actions_by_game};
+    const int rows = heavy_max_rows > light_max_rows ? heavy_max_rows : light_max_rows;
+    const dim3 grid(n_heavy + n_light), block(256);
+    if (rows <= 1) hipLaunchKernelGGL((coevo::fc_rollout_small_kernel<1>), grid, block, 0, s, a, pa);
+    else if (rows <= 2) hipLaunchKernelGGL((coevo::fc_rollout_small_kernel<2>), grid, block, 0, s, a, pa);
+    else if (rows <= 5) hipLaunchKernelGGL((coevo::fc_rollout_small_kernel<5>), grid, block, 0, s, a, pa);
+    else hipLaunchKernelGGL((coevo::fc_rollout_small_kernel<8>), grid, block, 0, s, a, pa);
+    COEVO_HIP_CHECK(hipGetLastError());
+    return COEVO_OK;
 }
 
 extern "C" int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_task *heavy_tasks, int n_heavy,

@@ -6,11 +6,12 @@
 // own streams (cohort 0: the caller's).  With d->merged == 0 the older two-launch form is used instead: [side stream]
 // the shared-opponent launch || [main stream] the per-individual launch, joined by an event.  Nothing here synchronises
 // with the host; a single-cohort sequence can also be captured into a hipGraph by the caller.
+#include <cstdlib>
 #include <vector>
 
 #include "coevo_common.hip.h"
 
-static_assert(sizeof(coevo_rollout_desc) == 176, "layout mirrored by coevonet_amd/lib.py RolloutDesc");
+static_assert(sizeof(coevo_rollout_desc) == 184, "layout mirrored by coevonet_amd/lib.py RolloutDesc");
 
 __global__ void stamps_init_kernel(uint64_t *stamps, int n)
 {
@@ -153,6 +154,7 @@ extern "C" int coevo_mpe_rollout(const coevo_rollout_desc *d, void *ctx, int tim
         COEVO_HIP_CHECK(hipGetLastError());
     }
     const bool fused = d->state_alt != nullptr && d->actions_by_game != nullptr;
+    static const bool persistent_ok = !(getenv("COEVO_PERSISTENT") && getenv("COEVO_PERSISTENT")[0] == '0');   // A/B
     const size_t act_stride = 3 * (size_t)d->n_games;
     const int K = d->n_cohorts > 1 ? d->n_cohorts : 1;
     if (K > 1) {
@@ -177,6 +179,17 @@ extern "C" int coevo_mpe_rollout(const coevo_rollout_desc *d, void *ctx, int tim
     auto chain = [&](int k, const coevo_fc_task *heavy, int n_heavy, const coevo_fc_task *light, int n_light,
                      hipStream_t ls, hipStream_t hs, hipEvent_t fork, hipEvent_t join) -> int {
         const bool two = c && hs != ls && n_heavy > 0 && n_light > 0;
+        // a cohort whose launches all fit the chip at once (COEVO_CYCLE_FORM_SMALL): its n_cycles as ONE persistent launch
+        if (persistent_ok && fused && d->merged && d->sync_words && n_heavy > 0 && n_light > 0 && d->light_max_rows <= 8 &&
+            d->n_cycles > 0) {
+            const int conc = d->concurrent_hint > K ? d->concurrent_hint : K;
+            if (coevo_mpe_cycle_kernel_form(n_heavy, n_light, d->heavy_max_rows, d->light_max_rows, conc) == COEVO_CYCLE_FORM_SMALL)
+                return coevo_mpe_rollout_persistent(
+                    d->slab, heavy, n_heavy, light, n_light, d->light_max_rows, d->heavy_max_rows, d->state, d->state_alt,
+                    d->n_games, d->row_game, d->row_slot, d->actions_by_game, d->game_limit, d->n_cycles, d->pos_first, d->status,
+                    d->light_stamps ? d->light_stamps + 2 * COEVO_STAMP_SLOTS * ((size_t)k * d->n_cycles) : nullptr,
+                    d->sync_words + (size_t)k * (size_t)(4 + 6 * (size_t)d->n_games), conc, ls);
+        }
         for (int cyc = 0; cyc < d->n_cycles; ++cyc) {
             int rc;
             // fused env step: cycle c reads the state of cycle c-1 (buffer (c-1)&1; buffer 0 holds the reset state)

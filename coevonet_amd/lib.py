@@ -21,7 +21,8 @@ MPE_STATE_DOUBLES = 24
 STAMP_SLOTS = 32
 ST_NAMES = {1: "input contains inf or NaN", 2: "output contains inf or NaN after fc1",
             4: "output contains inf or NaN after fc2", 8: "output contains inf or NaN",
-            16: "no action selected (current_best_position = -1)"}
+            16: "no action selected (current_best_position = -1)",
+            32: "persistent rollout: a workgroup timed out waiting for the other rows of its games (COEVO_ST_SYNC_TIMEOUT)"}
 
 DQN_LOGIT_STRIDE = 32
 DQN_FC1_TILED = 0x100   # COEVO_DQN_FC1_TILED: or-ed into the channel argument of the layout-dependent DeepQN entry points
@@ -68,7 +69,8 @@ class RolloutDesc(C.Structure):
                 ("rewards", C.c_void_p), ("pos_first", C.c_int32), ("n_cohorts", C.c_int32),
                 ("state_alt", C.c_void_p), ("actions_by_game", C.c_void_p), ("light_stamps", C.c_void_p),
                 ("heavy_begin", C.c_void_p), ("light_begin", C.c_void_p),
-                ("merged", C.c_int32), ("concurrent_hint", C.c_int32), ("stamps_armed", C.c_int32), ("reserved", C.c_int32)]
+                ("merged", C.c_int32), ("concurrent_hint", C.c_int32), ("stamps_armed", C.c_int32), ("reserved", C.c_int32),
+                ("sync_words", C.c_void_p)]
 
 
 class HostCohort(C.Structure):        # coevo_host_cohort
@@ -171,6 +173,10 @@ _SIGS = {
     "coevo_mpe_policy_cycle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "coevo_mpe_cycle_kernel_form": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "coevo_mpe_persistent_sync_words": (C.c_int, [C.c_int]),
+    "coevo_mpe_rollout_persistent": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                               C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "coevo_rollout_ctx_create": (C.c_void_p, [C.c_int]),
     "coevo_rollout_ctx_destroy": (None, [C.c_void_p]),
     "coevo_ga_select": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -252,6 +252,13 @@ class DeviceRollout:
         self.stamp_cycles = 256
         self.stamps = torch.zeros(self.n_cohorts * self.stamp_cycles, L.STAMP_SLOTS, 2, dtype=torch.int64,
                                   device=dev)  # per (cohort, cycle), per slot
+        # scratch of the persistent whole-rollout launch (coevo_mpe_rollout_persistent: a cohort whose workgroups all fit the
+        # chip at once plays its n_cycles in ONE launch; the C side decides per cohort): tagged action words, per cohort
+        self.sync_words_per_cohort = int(L.load().coevo_mpe_persistent_sync_words(n))
+        self.sync_words = None
+        if fused_step and merged:
+            self.sync_words = torch.zeros(self.n_cohorts * self.sync_words_per_cohort, dtype=torch.int32, device=dev)
+            self.desc.sync_words = L._p(self.sync_words)
 
     def __del__(self):
         try:
@@ -348,6 +355,8 @@ class DeviceRollout:
         d.rewards = None
         d.light_stamps = (self.stamps.data_ptr() + 16 * L.STAMP_SLOTS * k * int(n_cycles)) if self.time_light else None
         d.stamps_armed = 1 if (armed and self.time_light) else 0
+        if self.sync_words is not None:   # this cohort's own scratch (the launch zeroes it)
+            d.sync_words = self.sync_words.data_ptr() + 4 * k * self.sync_words_per_cohort
         L._check(L.load().coevo_mpe_rollout(L.C.byref(d), self.ctx, 0, stream.cuda_stream), "coevo_mpe_rollout")
         if self.time_light:
             self._pending_stamps = int(n_cycles)

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define COEVO_VERSION 102   /* 102: host-cores placement (coevo_host_placement_choose, coevo_host_rollout_placement / _alloc),
+#define COEVO_VERSION 103   /* 103: coevo_mpe_rollout_persistent, coevo_rollout_desc.sync_words (184 bytes); 102: host-cores placement (coevo_host_placement_choose, coevo_host_rollout_placement / _alloc),
                              * wide small-shard cycle kernel; 101: offspring noise = Philox4x32-7 (100: -10; other numbers for the same seed), host-cores
                              * rollout entry points, coevo_noise_rounds */
 
@@ -41,6 +41,8 @@ extern "C" {
 #define COEVO_ST_BAD_FC2 4
 #define COEVO_ST_BAD_OUT 8
 #define COEVO_ST_NO_ACTION 16
+#define COEVO_ST_SYNC_TIMEOUT 32 /* coevo_mpe_rollout_persistent: a workgroup waited too long for the other rows of its games (no
+                                  * reference counterpart: more such launches side by side than the device holds at once) */
 
 /* FCNetwork geometry (MPE/fcnetwork.py:14-22) */
 #define COEVO_FC_H1 512
@@ -269,6 +271,9 @@ typedef struct {
     int32_t stamps_armed;        /* != 0: the caller has re-armed light_stamps to {UINT64_MAX, 0} itself (coevo_mpe_reset_multi_arm,
                                     in the reset launch that precedes the rollout anyway): no launch of its own for it */
     int32_t reserved;
+    int32_t *sync_words;         /* device int32 [n_cohorts][coevo_mpe_persistent_sync_words(n_games)] or NULL.  Given: a cohort
+                                    whose launches are of COEVO_CYCLE_FORM_SMALL runs its n_cycles as ONE persistent launch
+                                    (coevo_mpe_rollout_persistent) */
 } coevo_rollout_desc;
 #define COEVO_MAX_COHORTS 8
 void *coevo_rollout_ctx_create(int n_timing_pairs);
@@ -317,6 +322,25 @@ int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_task *heavy_
                                   int32_t *act_cur, const int32_t *game_limit, int cycle, int pos_first,
                                   int32_t *status, uint64_t *stamps, int concurrent_launches, int heavy_max_rows,
                                   void *stream);
+/* n_cycles env-cycles of one cohort in ONE launch (the env step and the forward fused into a persistent
+ * whole-rollout kernel; replaces n_cycles coevo_mpe_policy_cycle_merged launches of COEVO_CYCLE_FORM_SMALL, i.e. the whole
+ * per-step loop of utils/game_logic_functions.py:138-212 for every game of the cohort).  Only for launch shapes of that form
+ * (every task <= 8 rows, no more workgroups than CUs: all resident at once; anything else: COEVO_ERR_UNSUPPORTED): a workgroup
+ * keeps its net's small layers in LDS and its rows' games in LDS for the whole rollout; per cycle a row posts its action as one
+ * tagged 32-bit word and waits for the two other rows of its game (bounded: COEVO_ST_SYNC_TIMEOUT in the status word).
+ * state = buffer 0 (the reset state), state_alt = buffer 1; on return they and actions_by_game [2][n_games][3] hold exactly
+ * what the last of the per-cycle launches leaves for coevo_mpe_final_step(state of cycle n_cycles - 1, cycle n_cycles - 1).
+ * sync_words: device int32 [coevo_mpe_persistent_sync_words(n_games)], scratch of this call (zeroed by it on `stream`).
+ * stamps: [n_cycles][COEVO_STAMP_SLOTS][2] or NULL, per cycle {earliest start after the wait, latest action posted}.
+ * Every task's games must have all three of their rows among the tasks of this call.  COEVO_PERSISTENT=0 in the environment
+ * makes coevo_mpe_rollout keep the per-cycle launches (A/B). */
+int coevo_mpe_persistent_sync_words(int n_games);
+int coevo_mpe_rollout_persistent(const float *slab, const coevo_fc_task *heavy_tasks, int n_heavy,
+                                 const coevo_fc_task *light_tasks, int n_light, int light_max_rows, int heavy_max_rows,
+                                 double *state, double *state_alt, int n_games, const int32_t *row_game,
+                                 const int32_t *row_slot, int32_t *actions_by_game, const int32_t *game_limit, int n_cycles,
+                                 int pos_first, int32_t *status, uint64_t *stamps, int32_t *sync_words,
+                                 int concurrent_launches, void *stream);
 int coevo_mpe_final_step(const double *state, int n_games, const int32_t *actions_by_game, int cycle,
                          const int32_t *game_limit, int pos_first, double *rewards, void *stream);
 /* ... + this rank's record of the fitness all-gather in the same launch (a population-sharded run; genetic_algorithm.py:

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_layout_constants():
     dll = L.load()
-    assert dll.coevo_version() == 102
+    assert dll.coevo_version() == 103
     # parameter counts of the reference's FCNetwork (139 781 good / 138 757 adversary)
     assert L.fc_param_count(10) == 139781 and L.fc_param_count(8) == 138757
     assert L.fc_slab_stride(10) % 64 == 0 and L.fc_slab_stride(10) >= 139781

@@ -320,13 +320,77 @@ def test_rollout_variants_match_oracle(mode, nh, heavy_rows):
         assert list(r[g]) == want["rewards"], (mode, g, r[g], want["rewards"])
 
 
+def _small_launch_setup(npop, nh, heavy_rows, cohorts):
+    from coevonet_amd.rollout import RolloutPlan
+    nets10 = make_nets(npop + nh, 10, seed=191, mutate=False)
+    nets8 = make_nets(nh, 8, seed=192, mutate=False)
+    s10, s8 = L.fc_slab_stride(10), L.fc_slab_stride(8)
+    slab = torch.cat([to_slab(nets10, 10).reshape(-1), to_slab(nets8, 8).reshape(-1)]).contiguous()
+    off = [i * s10 for i in range(npop + nh)] + [(npop + nh) * s10 + k * s8 for k in range(nh)]
+    D = [10] * (npop + nh) + [8] * nh
+    games = [(npop + nh + k, i, npop + k) for i in range(npop) for k in range(nh)]   # (adversary, agent_0, agent_1)
+    plan = RolloutPlan(np.array(games), off, D, device=DEV, n_cohorts=cohorts, heavy_rows=heavy_rows)
+    return plan, slab, games, nets10, nets8
+
+
+@pytest.mark.parametrize("limit", [40, 1, 4, 75])
+def test_persistent_rollout_leaves_what_the_per_cycle_launches_leave(limit):
+    """coevo_mpe_rollout_persistent (ONE launch for the n_cycles of a small cohort: rows keep their games in LDS and hand each
+    other tagged action words) against the chain of fc_cycle_small_kernel launches: the same rewards, and the same state buffer
+    / plain action words for coevo_mpe_final_step - bit for bit; 1 cycle (nothing to wait for), 2 cycles, an odd and an even
+    last cycle"""
+    from coevonet_amd.rollout import DeviceRollout
+    plan, slab, games, _, _ = _small_launch_setup(25, 5, 5, 1)
+    got = []
+    for persistent in (True, False):
+        ro = DeviceRollout(plan, slab, merged=True)
+        if not persistent:
+            ro.sync_words, ro.desc.sync_words = None, None
+        ro.use_graph = False
+        T = min(limit, 75)
+        ro.set_limits(np.full(plan.n_games, T))
+        ro.reset(0, plan.n_games, 11)
+        n_cycles = (T + 2) // 3
+        ro.run(n_cycles)
+        torch.cuda.synchronize()
+        ro.check_status()
+        last = n_cycles - 1
+        st = (ro.state2[0] if last <= 0 or (last & 1) == 0 else ro.state2[1])[:22].cpu().numpy()
+        act = ro.actions_by_game[(last if last > 0 else 0) & 1].cpu().numpy()
+        got.append((ro.rewards.cpu().numpy(), st, act))
+    for a, b in zip(*got):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def test_persistent_rollout_times_out_instead_of_hanging():
+    """a task list that lacks one seat of some games: their other rows wait, give up after COEVO_SYNC_SPINS polls, raise the
+    abort word, every workgroup leaves and the status word carries COEVO_ST_SYNC_TIMEOUT (no reference counterpart)"""
+    from coevonet_amd.rollout import DeviceRollout
+    plan, slab, games, _, _ = _small_launch_setup(25, 5, 5, 1)
+    ro = DeviceRollout(plan, slab, merged=True)
+    ro.set_limits(np.full(plan.n_games, 40))
+    ro.reset(0, plan.n_games, 3)
+    lib = L.load()
+    rc = lib.coevo_mpe_rollout_persistent(
+        L._p(slab), L._p(plan.heavy), len(plan.heavy_np), L._p(plan.light), len(plan.light_np) - 1, plan.light_max, plan.heavy_max,
+        L._p(ro.state2[0]), L._p(ro.state2[1]), plan.n_games, L._p(plan.row_game), L._p(plan.row_slot), L._p(ro.actions_by_game),
+        L._p(ro.limits), 3, ro.pos_first, L._p(ro.status), None, L._p(ro.sync_words), 1, L._stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert int(ro.status.item()) & 32
+    with pytest.raises(ValueError, match="SYNC_TIMEOUT"):
+        ro.check_status()
+
+
+@pytest.mark.parametrize("persistent", [True, False])
 @pytest.mark.parametrize("npop,nh,heavy_rows,cohorts", [(25, 5, 5, 1), (50, 5, 8, 1), (20, 8, 8, 1), (20, 2, 5, 1), (23, 1, 7, 1),
                                                         (26, 5, 5, 2)])
-def test_small_launch_kernel_matches_oracle(npop, nh, heavy_rows, cohorts):
+def test_small_launch_kernel_matches_oracle(npop, nh, heavy_rows, cohorts, persistent):
     """fc_cycle_small_kernel (every task <= 8 rows through the per-individual body, fc2 as v_fmac_f32 with DPP row_newbcast
     activations - the launch shape of ONE RANK of a sharded population, genetic_algorithm.py:125-217 split by index: 25 / 50
     individuals per role, shared opponents cut into hof- or 8-row chunks) == the oracle's play_game, bit for bit: every row-count
-    instantiation (1, 2, 5, 8), ragged last chunks, two cohorts side by side"""
+    instantiation (1, 2, 5, 8), ragged last chunks, two cohorts side by side; as one launch per env-cycle and as ONE persistent
+    launch per cohort (fc_rollout_small_kernel)"""
     from coevonet_amd.rollout import RolloutPlan, DeviceRollout
     limit, max_cycles = 40, 25
     nets10 = make_nets(npop + nh, 10, seed=191, mutate=False)
@@ -343,6 +407,8 @@ def test_small_launch_kernel_matches_oracle(npop, nh, heavy_rows, cohorts):
         n_l = int(plan.light_begin_np[k + 1] - plan.light_begin_np[k])
         assert L.load().coevo_mpe_cycle_kernel_form(n_h, n_l, plan.heavy_max, plan.light_max, cohorts) == 3   # COEVO_CYCLE_FORM_SMALL
     ro = DeviceRollout(plan, slab, merged=True)
+    if not persistent:
+        ro.sync_words, ro.desc.sync_words = None, None
     T = min(limit, 3 * max_cycles)
     ro.set_limits(np.full(plan.n_games, T))
     first = 3
