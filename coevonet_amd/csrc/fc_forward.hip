@@ -2060,6 +2060,21 @@ extern "C" int coevo_mpe_cycle_kernel_form(int n_heavy, int n_light, int heavy_m
     return wgs > slots ? COEVO_CYCLE_FORM_TILE32_PAIRED : COEVO_CYCLE_FORM_TILE32;
 }
 
+// The persistent launch needs every workgroup resident at once: <= 256 registers and < 80 KiB of LDS, so two fit a CU.  (With
+// more than one per CU the rollout is bound by what ONE CU streams - ~47 GB/s, tools/stream_waves_probe.hip: two 0.56 MB nets
+// per cycle = 20 us - and still ahead of the per-cycle launches of the lean kernel: a rank of 4, 450 workgroups, 20.2 against
+// 23.3 us per cycle.)
+extern "C" int coevo_mpe_persistent_fits(int n_heavy, int n_light, int heavy_max_rows, int light_max_rows, int concurrent_launches)
+{
+    if (n_heavy <= 0 || n_light <= 0 || light_max_rows < 1 || light_max_rows > 8) return COEVO_ERR_ARG;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return COEVO_ERR_HIP;
+    const int conc = concurrent_launches > 1 ? concurrent_launches : 1;
+    return heavy_max_rows >= 1 && heavy_max_rows <= 8 && (n_heavy + n_light) * conc <= 2 * cus ? 1 : 0;
+}
+
 extern "C" int coevo_mpe_persistent_sync_words(int n_games) { return n_games > 0 ? 4 + 6 * n_games : COEVO_ERR_ARG; }
 
 extern "C" int coevo_mpe_rollout_persistent(const float *slab, const coevo_fc_task *heavy_tasks, int n_heavy,
@@ -2072,9 +2087,9 @@ extern "C" int coevo_mpe_rollout_persistent(const float *slab, const coevo_fc_ta
     if (!slab || !heavy_tasks || !light_tasks || !state || !state_alt || state == state_alt || !row_game || !row_slot ||
         !actions_by_game || !status || !sync_words || n_games <= 0 || n_cycles < 1 || n_cycles > (1 << 22))
         return COEVO_ERR_ARG;
-    const int form = coevo_mpe_cycle_kernel_form(n_heavy, n_light, heavy_max_rows, light_max_rows, concurrent_launches);
-    if (form < 0) return form;
-    if (form != COEVO_CYCLE_FORM_SMALL) return COEVO_ERR_UNSUPPORTED;   // not all resident at once: the per-cycle launches
+    const int fits = coevo_mpe_persistent_fits(n_heavy, n_light, heavy_max_rows, light_max_rows, concurrent_launches);
+    if (fits < 0) return fits;
+    if (!fits) return COEVO_ERR_UNSUPPORTED;   // not all resident at once: the per-cycle launches
     hipStream_t s = (hipStream_t)stream;
     COEVO_HIP_CHECK(hipMemsetAsync(sync_words, 0, sizeof(int32_t) * (size_t)(4 + 6 * (size_t)n_games), s));
     coevo::FcArgs a{};

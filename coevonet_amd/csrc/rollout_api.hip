@@ -179,11 +179,11 @@ extern "C" int coevo_mpe_rollout(const coevo_rollout_desc *d, void *ctx, int tim
     auto chain = [&](int k, const coevo_fc_task *heavy, int n_heavy, const coevo_fc_task *light, int n_light,
                      hipStream_t ls, hipStream_t hs, hipEvent_t fork, hipEvent_t join) -> int {
         const bool two = c && hs != ls && n_heavy > 0 && n_light > 0;
-        // a cohort whose launches all fit the chip at once (COEVO_CYCLE_FORM_SMALL): its n_cycles as ONE persistent launch
+        // a cohort whose workgroups are all resident at once (coevo_mpe_persistent_fits): its n_cycles as ONE persistent launch
         if (persistent_ok && fused && d->merged && d->sync_words && n_heavy > 0 && n_light > 0 && d->light_max_rows <= 8 &&
             d->n_cycles > 0) {
             const int conc = d->concurrent_hint > K ? d->concurrent_hint : K;
-            if (coevo_mpe_cycle_kernel_form(n_heavy, n_light, d->heavy_max_rows, d->light_max_rows, conc) == COEVO_CYCLE_FORM_SMALL)
+            if (coevo_mpe_persistent_fits(n_heavy, n_light, d->heavy_max_rows, d->light_max_rows, conc) == 1)
                 return coevo_mpe_rollout_persistent(
                     d->slab, heavy, n_heavy, light, n_light, d->light_max_rows, d->heavy_max_rows, d->state, d->state_alt,
                     d->n_games, d->row_game, d->row_slot, d->actions_by_game, d->game_limit, d->n_cycles, d->pos_first, d->status,

@@ -90,14 +90,17 @@ def adapt_mutation_power(args, gen, hist):
 
 
 def small_shard_rows(n_local, hof, cus, pop):
-    """Rows per shared-opponent task of a rank that holds n_local individuals per role.  A launch of one env-cycle is 3 n_local
+    """Rows per shared-opponent task of a rank that holds n_local individuals per role.  One env-cycle of it is 3 n_local
     per-individual workgroups + 6 hof ceil(n_local / rows) shared-opponent ones (3 phases x hof games x 2 opponent seats, each
-    opponent against all of the rank's individuals).  While they fit ONE per CU (a rank of pop 200 over 8 GPUs: 75 + 150) the
-    launch lasts as long as one workgroup, and tasks are cut to hof rows (25 = 5 x 5: no padding) for the small-launch kernel
-    (<= 8 rows, vector-ALU fc2: csrc/fc_forward.hip fc_cycle_small_kernel); else the 16-row tiles of the lean kernel."""
+    opponent against all of the rank's individuals).  While they are all resident at once - two per CU: a rank of pop 200 over 8
+    GPUs, 75 + 150, or over 4, 150 + 300 - tasks are cut to hof rows (25 = 5 x 5: no padding) and the rollout is ONE persistent
+    launch of the small-launch body (<= 8 rows, vector-ALU fc2: csrc/fc_forward.hip fc_rollout_small_kernel,
+    coevo_mpe_persistent_fits); else the 16-row tiles of the lean kernel.  COEVO_PERSISTENT=0 (per-cycle launches, A/B): hof rows
+    only while every workgroup has a CU to itself (two small-launch workgroups per CU lose against the lean kernel)."""
     if n_local >= pop or not 1 <= hof <= 8:   # the whole population on this GPU: the full launch
         return 16
-    if 3 * n_local + 6 * hof * -(-n_local // hof) <= cus:
+    per_cu = 2 if os.environ.get("COEVO_PERSISTENT", "1") != "0" else 1
+    if 3 * n_local + 6 * hof * -(-n_local // hof) <= per_cu * cus:
         return hof
     return 16
 

@@ -174,6 +174,7 @@ _SIGS = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "coevo_mpe_cycle_kernel_form": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "coevo_mpe_persistent_sync_words": (C.c_int, [C.c_int]),
+    "coevo_mpe_persistent_fits": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "coevo_mpe_rollout_persistent": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

@@ -272,7 +272,7 @@ typedef struct {
                                     in the reset launch that precedes the rollout anyway): no launch of its own for it */
     int32_t reserved;
     int32_t *sync_words;         /* device int32 [n_cohorts][coevo_mpe_persistent_sync_words(n_games)] or NULL.  Given: a cohort
-                                    whose launches are of COEVO_CYCLE_FORM_SMALL runs its n_cycles as ONE persistent launch
+                                    whose workgroups are all resident at once (coevo_mpe_persistent_fits) runs its n_cycles as ONE persistent launch
                                     (coevo_mpe_rollout_persistent) */
 } coevo_rollout_desc;
 #define COEVO_MAX_COHORTS 8
@@ -323,9 +323,10 @@ int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_task *heavy_
                                   int32_t *status, uint64_t *stamps, int concurrent_launches, int heavy_max_rows,
                                   void *stream);
 /* n_cycles env-cycles of one cohort in ONE launch (the env step and the forward fused into a persistent
- * whole-rollout kernel; replaces n_cycles coevo_mpe_policy_cycle_merged launches of COEVO_CYCLE_FORM_SMALL, i.e. the whole
- * per-step loop of utils/game_logic_functions.py:138-212 for every game of the cohort).  Only for launch shapes of that form
- * (every task <= 8 rows, no more workgroups than CUs: all resident at once; anything else: COEVO_ERR_UNSUPPORTED): a workgroup
+ * whole-rollout kernel; replaces n_cycles coevo_mpe_policy_cycle_merged launches, i.e. the whole per-step loop of
+ * utils/game_logic_functions.py:138-212 for every game of the cohort).  Only for launch shapes whose workgroups are all
+ * resident at once (coevo_mpe_persistent_fits: every task <= 8 rows, at most two workgroups per CU counting
+ * `concurrent_launches` such launches side by side; anything else: COEVO_ERR_UNSUPPORTED): a workgroup
  * keeps its net's small layers in LDS and its rows' games in LDS for the whole rollout; per cycle a row posts its action as one
  * tagged 32-bit word and waits for the two other rows of its game (bounded: COEVO_ST_SYNC_TIMEOUT in the status word).
  * state = buffer 0 (the reset state), state_alt = buffer 1; on return they and actions_by_game [2][n_games][3] hold exactly
@@ -335,6 +336,7 @@ int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_task *heavy_
  * Every task's games must have all three of their rows among the tasks of this call.  COEVO_PERSISTENT=0 in the environment
  * makes coevo_mpe_rollout keep the per-cycle launches (A/B). */
 int coevo_mpe_persistent_sync_words(int n_games);
+int coevo_mpe_persistent_fits(int n_heavy, int n_light, int heavy_max_rows, int light_max_rows, int concurrent_launches);
 int coevo_mpe_rollout_persistent(const float *slab, const coevo_fc_task *heavy_tasks, int n_heavy,
                                  const coevo_fc_task *light_tasks, int n_light, int light_max_rows, int heavy_max_rows,
                                  double *state, double *state_alt, int n_games, const int32_t *row_game,

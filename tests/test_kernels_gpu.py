@@ -384,7 +384,7 @@ def test_persistent_rollout_times_out_instead_of_hanging():
 
 @pytest.mark.parametrize("persistent", [True, False])
 @pytest.mark.parametrize("npop,nh,heavy_rows,cohorts", [(25, 5, 5, 1), (50, 5, 8, 1), (20, 8, 8, 1), (20, 2, 5, 1), (23, 1, 7, 1),
-                                                        (26, 5, 5, 2)])
+                                                        (26, 5, 5, 2), (90, 5, 5, 1)])
 def test_small_launch_kernel_matches_oracle(npop, nh, heavy_rows, cohorts, persistent):
     """fc_cycle_small_kernel (every task <= 8 rows through the per-individual body, fc2 as v_fmac_f32 with DPP row_newbcast
     activations - the launch shape of ONE RANK of a sharded population, genetic_algorithm.py:125-217 split by index: 25 / 50
@@ -405,7 +405,10 @@ def test_small_launch_kernel_matches_oracle(npop, nh, heavy_rows, cohorts, persi
     for k in range(cohorts):
         n_h = int(plan.heavy_begin_np[k + 1] - plan.heavy_begin_np[k])
         n_l = int(plan.light_begin_np[k + 1] - plan.light_begin_np[k])
-        assert L.load().coevo_mpe_cycle_kernel_form(n_h, n_l, plan.heavy_max, plan.light_max, cohorts) == 3   # COEVO_CYCLE_FORM_SMALL
+        assert L.load().coevo_mpe_persistent_fits(n_h, n_l, plan.heavy_max, plan.light_max, cohorts) == 1
+        # (90 individuals: 270 workgroups, two per CU on some - persistent only; per cycle that shape runs the lean kernel)
+        form = L.load().coevo_mpe_cycle_kernel_form(n_h, n_l, plan.heavy_max, plan.light_max, cohorts)
+        assert form == (3 if npop < 90 else 2)   # COEVO_CYCLE_FORM_SMALL / _LEAN16
     ro = DeviceRollout(plan, slab, merged=True)
     if not persistent:
         ro.sync_words, ro.desc.sync_words = None, None

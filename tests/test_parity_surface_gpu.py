@@ -344,9 +344,9 @@ def test_cfg2_full_size_host_cores_equal_device(monkeypatch):
 @pytest.mark.parametrize("world,rank", [(8, 0), (8, 5), (4, 3)])
 def test_cfg2_one_rank_of_the_split_vs_oracle(world, rank):
     """BASELINE's own split (pop 200 over 4 / 8 GPUs: `--gpus N`, genetic_algorithm.py:125-217 by individual index): the
-    launches ONE rank runs - a rank of 8: 25 individuals per role, shared opponents in hof-row chunks, every task through the
-    small-launch kernel (fc2 on the vector ALU, one workgroup per CU); a rank of 4: 50 per role on the lean kernel with 16-row
-    tiles - against the oracle: all of the rank's deciding games of generation 0, a
+    launches ONE rank runs - 25 / 50 individuals per role, shared opponents in hof-row chunks, every task through the
+    small-launch body (fc2 on the vector ALU) and the whole rollout as ONE persistent launch (a rank of 8: a workgroup per CU,
+    of 4: two) - against the oracle: all of the rank's deciding games of generation 0, a
     sample of the others, and generation 1's games of bred children (the rank's own children; the elites are whatever
     dist.ShardRehearsal's made-up gather selected, read back from the engine)"""
     from coevonet_amd.dist import ShardRehearsal
@@ -358,10 +358,10 @@ def test_cfg2_one_rank_of_the_split_vs_oracle(world, rank):
     args, env, res = _ga(cfg, "device_philox", dist_ctx=ShardRehearsal(rank, world))
     eng = res.engine
     assert (eng.lo, eng.hi, eng.K) == (lo, lo + n_local, 1) and eng.plan.light_max == hof
-    assert eng.plan.heavy_max == (hof if world == 8 else 16)
-    form = L.load().coevo_mpe_cycle_kernel_form(len(eng.plan.heavy_np), len(eng.plan.light_np), eng.plan.heavy_max,
-                                                eng.plan.light_max, 1)
-    assert form == (3 if world == 8 else 2)   # COEVO_CYCLE_FORM_SMALL / _LEAN16
+    assert eng.plan.heavy_max == hof and eng.ro.sync_words is not None
+    shape = (len(eng.plan.heavy_np), len(eng.plan.light_np), eng.plan.heavy_max, eng.plan.light_max, 1)
+    assert L.load().coevo_mpe_persistent_fits(*shape) == 1
+    assert L.load().coevo_mpe_cycle_kernel_form(*shape) == (3 if world == 8 else 2)   # what COEVO_PERSISTENT=0 would launch
     _seed(0)
     hofs, popu = rp.ga_initial(pop, hof)
     M = 3 * pop * hof
