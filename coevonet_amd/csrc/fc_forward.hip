@@ -1590,6 +1590,12 @@ struct PersistArgs {
     int32_t *act_plain;   // actions_by_game [2][n_games][3]: only the last cycle's plain actions are written
 };
 
+__global__ void sync_clear_kernel(int32_t *w, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) w[i] = 0;
+}
+
 template <int R>
 __global__ __launch_bounds__(256, 2) void fc_rollout_small_kernel(FcArgs a, PersistArgs pa)
 {
@@ -2066,13 +2072,15 @@ extern "C" int coevo_mpe_cycle_kernel_form(int n_heavy, int n_light, int heavy_m
 // 23.3 us per cycle.)
 extern "C" int coevo_mpe_persistent_fits(int n_heavy, int n_light, int heavy_max_rows, int light_max_rows, int concurrent_launches)
 {
-    if (n_heavy <= 0 || n_light <= 0 || light_max_rows < 1 || light_max_rows > 8) return COEVO_ERR_ARG;
+    // (either list may be empty: the ten evaluation games of Co-ES are six per-individual tasks and nothing else)
+    if (n_heavy < 0 || n_light < 0 || n_heavy + n_light <= 0) return COEVO_ERR_ARG;
+    if ((n_light > 0 && (light_max_rows < 1 || light_max_rows > 8)) || (n_heavy > 0 && heavy_max_rows < 1)) return COEVO_ERR_ARG;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
         return COEVO_ERR_HIP;
     const int conc = concurrent_launches > 1 ? concurrent_launches : 1;
-    return heavy_max_rows >= 1 && heavy_max_rows <= 8 && (n_heavy + n_light) * conc <= 2 * cus ? 1 : 0;
+    return (n_heavy == 0 || heavy_max_rows <= 8) && (n_heavy + n_light) * conc <= 2 * cus ? 1 : 0;
 }
 
 extern "C" int coevo_mpe_persistent_sync_words(int n_games) { return n_games > 0 ? 4 + 6 * n_games : COEVO_ERR_ARG; }
@@ -2084,20 +2092,24 @@ extern "C" int coevo_mpe_rollout_persistent(const float *slab, const coevo_fc_ta
                                             int n_cycles, int pos_first, int32_t *status, uint64_t *stamps, int32_t *sync_words,
                                             int concurrent_launches, void *stream)
 {
-    if (!slab || !heavy_tasks || !light_tasks || !state || !state_alt || state == state_alt || !row_game || !row_slot ||
-        !actions_by_game || !status || !sync_words || n_games <= 0 || n_cycles < 1 || n_cycles > (1 << 22))
+    if (!slab || (n_heavy > 0 && !heavy_tasks) || (n_light > 0 && !light_tasks) || !state || !state_alt || state == state_alt ||
+        !row_game || !row_slot || !actions_by_game || !status || !sync_words || n_games <= 0 || n_cycles < 1 || n_cycles > (1 << 22))
         return COEVO_ERR_ARG;
     const int fits = coevo_mpe_persistent_fits(n_heavy, n_light, heavy_max_rows, light_max_rows, concurrent_launches);
     if (fits < 0) return fits;
     if (!fits) return COEVO_ERR_UNSUPPORTED;   // not all resident at once: the per-cycle launches
     hipStream_t s = (hipStream_t)stream;
-    COEVO_HIP_CHECK(hipMemsetAsync(sync_words, 0, sizeof(int32_t) * (size_t)(4 + 6 * (size_t)n_games), s));
+    // (a kernel, not hipMemsetAsync: captured into a hipGraph and replayed after other work had run, the memset node of this
+    // runtime left device pointers in the buffer - the Co-ES evaluation rollout timed out on them)
+    hipLaunchKernelGGL(coevo::sync_clear_kernel, dim3((4 + 6 * n_games + 255) / 256), dim3(256), 0, s, sync_words, 4 + 6 * n_games);
+    COEVO_HIP_CHECK(hipGetLastError());
     coevo::FcArgs a{};
     a.slab = slab; a.tasks = heavy_tasks; a.state = state; a.row_game = row_game; a.row_slot = row_slot; a.n_games = n_games;
     a.status = status; a.stamps = reinterpret_cast<unsigned long long *>(stamps); a.game_limit = game_limit;
     a.pos_first = pos_first; a.light_tasks = light_tasks; a.n_heavy = n_heavy; a.n_light = n_light;
     const coevo::PersistArgs pa{n_cycles, sync_words, state_alt, actions_by_game};
-    const int rows = heavy_max_rows > light_max_rows ? heavy_max_rows : light_max_rows;
+    const int hr = n_heavy > 0 ? heavy_max_rows : 0, lr = n_light > 0 ? light_max_rows : 0;
+    const int rows = hr > lr ? hr : lr;
     const dim3 grid(n_heavy + n_light), block(256);
     if (rows <= 1) hipLaunchKernelGGL((coevo::fc_rollout_small_kernel<1>), grid, block, 0, s, a, pa);
     else if (rows <= 2) hipLaunchKernelGGL((coevo::fc_rollout_small_kernel<2>), grid, block, 0, s, a, pa);

@@ -180,8 +180,7 @@ extern "C" int coevo_mpe_rollout(const coevo_rollout_desc *d, void *ctx, int tim
                      hipStream_t ls, hipStream_t hs, hipEvent_t fork, hipEvent_t join) -> int {
         const bool two = c && hs != ls && n_heavy > 0 && n_light > 0;
         // a cohort whose workgroups are all resident at once (coevo_mpe_persistent_fits): its n_cycles as ONE persistent launch
-        if (persistent_ok && fused && d->merged && d->sync_words && n_heavy > 0 && n_light > 0 && d->light_max_rows <= 8 &&
-            d->n_cycles > 0) {
+        if (persistent_ok && fused && d->merged && d->sync_words && n_heavy + n_light > 0 && d->n_cycles > 0) {
             const int conc = d->concurrent_hint > K ? d->concurrent_hint : K;
             if (coevo_mpe_persistent_fits(n_heavy, n_light, d->heavy_max_rows, d->light_max_rows, conc) == 1)
                 return coevo_mpe_rollout_persistent(
