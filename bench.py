@@ -697,8 +697,10 @@ def run_ga(a, ctx, dev):
                 Rs = next(r for r in (1, 2, 5, 8) if max(eng.plan.light_max, min(eng.plan.heavy_max, 8)) <= r)
                 kernel_id = {0: f"fc_cycle_kernel<{R}, 1>", 1: f"fc_cycle_kernel<{R}, 2>", 2: f"fc_cycle16_kernel<{R}, 2>",
                              3: f"fc_cycle_small_kernel<{Rs}, 2>"}[form]
-                persistent = (form == 3 and getattr(eng.ro, "sync_words", None) is not None
-                              and os.environ.get("COEVO_PERSISTENT", "1") != "0")
+                persistent = (getattr(eng.ro, "sync_words", None) is not None
+                              and os.environ.get("COEVO_PERSISTENT", "1") != "0"
+                              and L.load().coevo_mpe_persistent_fits(int(hb[1] - hb[0]), int(lb[1] - lb[0]), eng.plan.heavy_max,
+                                                                     eng.plan.light_max, Kc) == 1)
                 if persistent and aggregate:
                     # ONE launch plays the whole rollout (coevo_mpe_rollout_persistent): a "launch" of the roofline block is
                     # one env-cycle of it = the rollout's span / its cycles (the per-cycle stamps - earliest start after the

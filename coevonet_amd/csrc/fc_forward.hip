@@ -1680,9 +1680,11 @@ __global__ __launch_bounds__(256, 2) void fc_rollout_small_kernel(FcArgs a, Pers
                         w0 = __hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         w1 = __hip_atomic_load(tp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         w2 = __hip_atomic_load(tp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const int ab = __hip_atomic_load(pa.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         ok = (w0 >> 8) == c && (w1 >> 8) == c && (w2 >> 8) == c;
-                        if (ok || ab) break;
+                        if (ok) break;
+                        // (the abort word is ONE word for everybody - agent-scope loads are served by memory, and a thousand
+                        // lanes on one line queue up: looked at every 16th poll only)
+                        if ((it & 15) == 15 && __hip_atomic_load(pa.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
                         __builtin_amdgcn_s_sleep(1);
                     }
                     if (!ok) {   // timed out, or somebody else did: everybody leaves
