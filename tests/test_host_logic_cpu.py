@@ -182,6 +182,22 @@ def test_cohort_partition_is_one_consistent_partition(n_local, K):
         assert np.array_equal(np.nonzero(of == k)[0], np.arange(bounds[k], bounds[k + 1]))
 
 
+def test_small_shard_rows_follow_what_is_resident_at_once(monkeypatch):
+    """rows per shared-opponent task of a rank (genetic_algorithm.py:125-217 split by index): hof rows while the rank's
+    workgroups - 3 n_local + 6 hof ceil(n_local / hof) - are all resident, two per CU, for the persistent whole-rollout launch;
+    with COEVO_PERSISTENT=0 only while each has a CU to itself; the whole population, or hof > 8: the lean kernel's 16-row tiles"""
+    from coevonet_amd.genetic_algorithm import small_shard_rows
+    monkeypatch.delenv("COEVO_PERSISTENT", raising=False)
+    assert small_shard_rows(25, 5, 256, 200) == 5      # a rank of 8: 75 + 150 workgroups
+    assert small_shard_rows(50, 5, 256, 200) == 5      # a rank of 4: 150 + 300 <= 512
+    assert small_shard_rows(100, 5, 256, 200) == 16    # a rank of 2: 300 + 600
+    assert small_shard_rows(200, 5, 256, 200) == 16    # everything on this GPU
+    assert small_shard_rows(25, 10, 256, 200) == 16    # tasks of more than 8 rows are not the small body's
+    assert small_shard_rows(26, 5, 256, 200) == 5      # ragged last chunk: 78 + 180
+    monkeypatch.setenv("COEVO_PERSISTENT", "0")
+    assert small_shard_rows(25, 5, 256, 200) == 5 and small_shard_rows(50, 5, 256, 200) == 16
+
+
 def test_unequal_shards_are_rejected():
     from coevonet_amd.genetic_algorithm import GAEngine
     with pytest.raises(ValueError, match="not divisible"):
