@@ -144,6 +144,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--settle-ms", type=float, default=120.0, help="after the W warm-up steps keep stepping (untimed) until the "
+                    "device has been under this workload for this long in total: a generation of the headline is 1.7 ms, and "
+                    "the part needs ~100 ms of load before its clocks settle (W = 5: 573-590 generations/s, W = 60 or more: "
+                    "600-605 on the same box; profiles/r05_experiments.md section 7).  0 = exactly W steps.  The line "
+                    "carries settle_steps")
     ap.add_argument("--scaling", choices=["strong", "weak"], default=None, help="ga / es under --gpus N: strong (default) = "
                     "BASELINE's metric, ONE population (--pop, 200) sharded over the N ranks; weak = --pop-per-gpu "
                     "individuals on every GPU.  (dqn-ga / dqn-es are the per-GPU shards of configs[3] / [4]: always weak)")
@@ -233,7 +238,8 @@ def main():
     scaling = a.scaling if a.workload in ("ga", "es") else "weak"
     rehearsal = bool(getattr(ctx, "rehearsal", False))
     real_world = 1 if rehearsal else ctx.world
-    out.update({"n_gpus": real_world, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": scaling,
+    out.update({"n_gpus": real_world, "steps": a.steps, "warmup": a.warmup, "settle_steps": getattr(a, "settle_steps", 0),
+                "settle_ms": a.settle_ms, "higher_is_better": True, "scaling": scaling,
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "noise": f"philox4x32-{L.load().coevo_noise_rounds()}", "coevo_version": L.load().coevo_version(),
                 "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
@@ -265,10 +271,37 @@ def main():
     ctx.shutdown()
 
 
-def _timed_steps(step, a, ctx, dev, before_timed=None):
-    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize; max over ranks"""
+MAX_SETTLE_STEPS = 256
+
+
+def _warm_up(step, a, ctx, dev):
+    """the W untimed warm-up steps, then - untimed as well - as many more as it takes until the device has been under this
+    workload for --settle-ms in total (every rank runs the same number: it comes from times reduced over the ranks).
+    -> the number of extra steps"""
+    t0 = time.perf_counter()
     for _ in range(a.warmup):
         step()
+    extra = 0
+    want = getattr(a, "settle_ms", 0.0) * 1e-3
+    if want > 0 and a.warmup > 0:
+        for _ in range(4):   # (the warm-up steps hold graph captures: their mean overestimates a step)
+            torch.cuda.synchronize()
+            done = ctx.max_over_ranks(time.perf_counter() - t0, dev)
+            if done >= want or extra >= MAX_SETTLE_STEPS:
+                break
+            per = done / (a.warmup + extra)
+            n = int(min(MAX_SETTLE_STEPS - extra, max(1, np.ceil((want - done) / per))))
+            for _ in range(n):
+                step()
+            extra += n
+    a.settle_steps = extra
+    return extra
+
+
+def _timed_steps(step, a, ctx, dev, before_timed=None):
+    """W untimed warm-up steps (+ the settling steps, _warm_up), then exactly K steps bracketed by barrier + synchronize;
+    max over ranks"""
+    _warm_up(step, a, ctx, dev)
     if before_timed:
         before_timed()
     if ctx.world > 1:
@@ -348,7 +381,7 @@ def run_dqn(a, ctx, dev, algo, pop_per_gpu=None, T=None):
     args.game = "pong_v3" if ga else "boxing_v2"
     args.coevo_channels = a.channels
     args.fitness_sharing = ga          # the GA always computes its diversity (Q3); ES without, as cfg 3
-    args.generations = a.steps + a.warmup
+    args.generations = a.steps + a.warmup + MAX_SETTLE_STEPS
     args.coevo_graph = False           # eager enqueue: HIP events bracket sampled launches of the dominant kernel
     args.coevo_frames = a.frames
     env = initialize_env(args)
@@ -561,7 +594,7 @@ def run_ga(a, ctx, dev):
         ppg = a.pop_per_gpu or 200
         pop = ppg * ctx.world
     args = make_args(pop, a.hof, a.elites, a.limit)
-    args.generations = a.steps + a.warmup  # sizes the device-resident evaluation / sigma histories
+    args.generations = a.steps + a.warmup + MAX_SETTLE_STEPS  # sizes the device-resident evaluation / sigma histories
     if a.cohorts is not None:
         args.coevo_cohorts = a.cohorts
     if a.no_device_loop:
@@ -578,8 +611,7 @@ def run_ga(a, ctx, dev):
         eng.ro.use_graph = not a.no_graph
         eng.ro.overlap = not a.no_overlap
         eng.ro.time_light = True  # before the warm-up, so the (timed) graph is captured outside the timed region
-    for i in range(a.warmup):
-        tr.step()
+    _warm_up(tr.step, a, ctx, dev)
     if timed:  # duration of every launch of the dominant kernel in the timed region from here on
         torch.cuda.synchronize()
         eng.ro.collect_stamps()
