@@ -2077,12 +2077,28 @@ extern "C" int coevo_mpe_persistent_fits(int n_heavy, int n_light, int heavy_max
     // (either list may be empty: the ten evaluation games of Co-ES are six per-individual tasks and nothing else)
     if (n_heavy < 0 || n_light < 0 || n_heavy + n_light <= 0) return COEVO_ERR_ARG;
     if ((n_light > 0 && (light_max_rows < 1 || light_max_rows > 8)) || (n_heavy > 0 && heavy_max_rows < 1)) return COEVO_ERR_ARG;
+    if (n_heavy > 0 && heavy_max_rows > 8) return 0;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
         return COEVO_ERR_HIP;
+    // what the runtime says the instantiation's residency is (two per CU as built; asked, not assumed: a launch that is not
+    // all resident would wait for itself)
+    const int hr = n_heavy > 0 ? heavy_max_rows : 0, lr = n_light > 0 ? light_max_rows : 0, rows = hr > lr ? hr : lr;
+    static int per_cu[4] = {-1, -1, -1, -1};
+    const int slot = rows <= 1 ? 0 : rows <= 2 ? 1 : rows <= 5 ? 2 : 3;
+    if (per_cu[slot] < 0) {
+        int n = 0;
+        const hipError_t e =
+            slot == 0   ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, coevo::fc_rollout_small_kernel<1>, 256, 0)
+            : slot == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, coevo::fc_rollout_small_kernel<2>, 256, 0)
+            : slot == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, coevo::fc_rollout_small_kernel<5>, 256, 0)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, coevo::fc_rollout_small_kernel<8>, 256, 0);
+        if (e != hipSuccess) return COEVO_ERR_HIP;
+        per_cu[slot] = n > 2 ? 2 : n;   // (never more than the two the kernel was sized for)
+    }
     const int conc = concurrent_launches > 1 ? concurrent_launches : 1;
-    return (n_heavy == 0 || heavy_max_rows <= 8) && (n_heavy + n_light) * conc <= 2 * cus ? 1 : 0;
+    return (n_heavy + n_light) * conc <= per_cu[slot] * cus ? 1 : 0;
 }
 
 extern "C" int coevo_mpe_persistent_sync_words(int n_games) { return n_games > 0 ? 4 + 6 * n_games : COEVO_ERR_ARG; }

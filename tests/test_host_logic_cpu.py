@@ -558,6 +558,40 @@ def test_bench_scaling_arguments():
     assert 1 <= hc["usable"] <= hc["affinity"]
 
 
+def test_bench_settling_steps_are_untimed_and_the_same_on_every_rank(monkeypatch):
+    """bench.py's warm-up: W steps, then - still untimed - steps until the device has been under the workload for --settle-ms
+    (the number comes from times reduced over the ranks, so every rank takes the same number: collectives stay matched);
+    --settle-ms 0 = exactly W; the count is capped"""
+    import sys
+    import time
+    import types
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import bench
+    monkeypatch.setattr(bench.torch.cuda, "synchronize", lambda *a, **k: None)
+    calls = []
+
+    def step():
+        calls.append(1)
+        time.sleep(0.002)
+
+    class Ctx:
+        world = 1
+
+        def max_over_ranks(self, s, dev):
+            return s
+
+    a = types.SimpleNamespace(warmup=3, settle_ms=0.0)
+    assert bench._warm_up(step, a, Ctx(), None) == 0 and len(calls) == 3 and a.settle_steps == 0
+    calls.clear()
+    a = types.SimpleNamespace(warmup=3, settle_ms=40.0)
+    n = bench._warm_up(step, a, Ctx(), None)
+    assert n == a.settle_steps and 5 <= n <= 30 and len(calls) == 3 + n   # ~20 steps of 2 ms make up 40 ms
+    calls.clear()
+    a = types.SimpleNamespace(warmup=1, settle_ms=1e6)
+    assert bench._warm_up(lambda: calls.append(1), a, Ctx(), None) == bench.MAX_SETTLE_STEPS
+
+
 def test_host_rollout_entry_points_refuse_bad_descriptors():
     """argument errors of the host-side rollouts are COEVO_ERR_ARG before any GPU call (the error convention of the boundary:
     return codes, no exceptions, nothing dereferenced that was not checked)"""
