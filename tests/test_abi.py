@@ -34,6 +34,16 @@ def test_version_and_layout_constants():
     assert L.fc_param_count(9) < 0  # unsupported width is an argument error, not a crash
 
 
+def test_graft_entry_build_runs():
+    """the driver's "does it build" check (__graft_entry__.build): compiles what is stale, builds the oracle's C restatement,
+    binds every symbol and compares the library's version with the header's (a hard-coded number there went stale in round 5)"""
+    import importlib
+    import sys
+    sys.path.insert(0, REPO)
+    g = importlib.import_module("__graft_entry__")
+    g.build()
+
+
 def test_header_is_plain_c(tmp_path):
     """include/coevo.h is the drop-in boundary: it must compile as C99 (what a cgo / JNI / ctypes-gen binding includes)"""
     import os
