@@ -654,6 +654,8 @@ def run_ga(a, ctx, dev):
                   f"simple_adversary_v3 pop={pop} HoF={a.hof}",
         "value": gens_per_s * steps_per_gen, "unit": "env-steps/s", "gens_per_sec": gens_per_s,
         "ms_per_step": 1e3 * dt / a.steps,
+        # host time of a step (enqueue only: the loop never waits for the device): well below ms_per_step = the host runs ahead
+        "host_enqueue_ms_per_step": 1e3 * float(np.mean(tr.res.seconds[-a.steps:])) if getattr(tr, "res", None) and tr.res.seconds else None,
         "config": {"workload": f"Co-GA simple_adversary_v3 pop={pop} ({ppg}/GPU) HoF={a.hof} "
                                f"elites={a.elites} T={a.limit} (env max_cycles={a.max_cycles} caps a game at "
                                f"{3 * a.max_cycles} agent-steps" + (", as in the reference" if a.max_cycles == 25 else

@@ -333,7 +333,7 @@ def _small_launch_setup(npop, nh, heavy_rows, cohorts):
     return plan, slab, games, nets10, nets8
 
 
-@pytest.mark.parametrize("limit", [40, 1, 4, 75])
+@pytest.mark.parametrize("limit", [40, 1, 4, 75, 200])
 def test_persistent_rollout_leaves_what_the_per_cycle_launches_leave(limit):
     """coevo_mpe_rollout_persistent (ONE launch for the n_cycles of a small cohort: rows keep their games in LDS and hand each
     other tagged action words) against the chain of fc_cycle_small_kernel launches: the same rewards, and the same state buffer
@@ -347,7 +347,7 @@ def test_persistent_rollout_leaves_what_the_per_cycle_launches_leave(limit):
         if not persistent:
             ro.sync_words, ro.desc.sync_words = None, None
         ro.use_graph = False
-        T = min(limit, 75)
+        T = limit   # (200: the T = 200 variant's 67 cycles, SURVEY 8d cfg 2-T200)
         ro.set_limits(np.full(plan.n_games, T))
         ro.reset(0, plan.n_games, 11)
         n_cycles = (T + 2) // 3
