@@ -274,15 +274,27 @@ def main():
 MAX_SETTLE_STEPS = 256
 
 
-def _warm_up(step, a, ctx, dev):
+def _warm_up(step, a, ctx, dev, cold_probe=False):
     """the W untimed warm-up steps, then - untimed as well - as many more as it takes until the device has been under this
     workload for --settle-ms in total (every rank runs the same number: it comes from times reduced over the ranks).
-    -> the number of extra steps"""
+    -> the number of extra steps.  cold_probe: the first K of them are timed on the side, bracketed like the real region
+    (a.cold_gens_per_sec = what `--settle-ms 0` would have reported, for the record; they count as settling steps)"""
     t0 = time.perf_counter()
     for _ in range(a.warmup):
         step()
     extra = 0
     want = getattr(a, "settle_ms", 0.0) * 1e-3
+    a.cold_gens_per_sec = None
+    if cold_probe and want > 0 and a.warmup > 0:
+        ctx.barrier()
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize()
+        ctx.barrier()
+        a.cold_gens_per_sec = a.steps / ctx.max_over_ranks(time.perf_counter() - tc, dev)
+        extra = a.steps
     if want > 0 and a.warmup > 0:
         for _ in range(4):   # (the warm-up steps hold graph captures: their mean overestimates a step)
             torch.cuda.synchronize()
@@ -594,7 +606,7 @@ def run_ga(a, ctx, dev):
         ppg = a.pop_per_gpu or 200
         pop = ppg * ctx.world
     args = make_args(pop, a.hof, a.elites, a.limit)
-    args.generations = a.steps + a.warmup + MAX_SETTLE_STEPS  # sizes the device-resident evaluation / sigma histories
+    args.generations = 2 * a.steps + a.warmup + MAX_SETTLE_STEPS  # sizes the device-resident evaluation / sigma histories
     if a.cohorts is not None:
         args.coevo_cohorts = a.cohorts
     if a.no_device_loop:
@@ -611,7 +623,7 @@ def run_ga(a, ctx, dev):
         eng.ro.use_graph = not a.no_graph
         eng.ro.overlap = not a.no_overlap
         eng.ro.time_light = True  # before the warm-up, so the (timed) graph is captured outside the timed region
-    _warm_up(tr.step, a, ctx, dev)
+    _warm_up(tr.step, a, ctx, dev, cold_probe=True)
     if timed:  # duration of every launch of the dominant kernel in the timed region from here on
         torch.cuda.synchronize()
         eng.ro.collect_stamps()
@@ -655,6 +667,8 @@ def run_ga(a, ctx, dev):
         "value": gens_per_s * steps_per_gen, "unit": "env-steps/s", "gens_per_sec": gens_per_s,
         "ms_per_step": 1e3 * dt / a.steps,
         # host time of a step (enqueue only: the loop never waits for the device): well below ms_per_step = the host runs ahead
+        # the same K steps timed straight after the W warm-up steps, before the settling steps (what --settle-ms 0 reports)
+        "cold_gens_per_sec": getattr(a, "cold_gens_per_sec", None),
         "host_enqueue_ms_per_step": 1e3 * float(np.mean(tr.res.seconds[-a.steps:])) if getattr(tr, "res", None) and tr.res.seconds else None,
         "config": {"workload": f"Co-GA simple_adversary_v3 pop={pop} ({ppg}/GPU) HoF={a.hof} "
                                f"elites={a.elites} T={a.limit} (env max_cycles={a.max_cycles} caps a game at "
