@@ -770,6 +770,11 @@ def run_ga(a, ctx, dev):
                     if kernel_id in j.get("dominant_kernel", ""):
                         traffic = j["dominant_kernel_hbm_bytes_per_launch"]
                         traffic_note = "profiles/r02_pmc_hbm_traffic.json (rocprofv3 --pmc passes of this command)"
+            if a.shard_of and kernel_id.startswith("fc_rollout_small") and pop == 200 and a.hof == 5 and a.max_cycles == 25:
+                # the persistent launch plays the whole rollout: its PMC bytes / its cycles = one env-cycle, like avg_launch_ms
+                t_all, note = pmc_traffic(f"cfg2_shard_1_of_{a.shard_of}", "fc_rollout_small_kernel")
+                if t_all:
+                    traffic, traffic_note = t_all / max(eng.ro._span_cycles, 1), note + " / the launch's env-cycles"
             kname = (kernel_id + " (one env-cycle of the persistent whole-rollout launch: every task's weight set streamed "
                      "once per cycle, fused env step, rows exchange tagged action words)"
                      if kernel_id.startswith("fc_rollout_small") else

@@ -2,7 +2,7 @@
 pmc_<workload>_FETCH_SIZE / pmc_<workload>_WRITE_SIZE) into profiles/<tag>_pmc_hbm_traffic.json, which bench.py reads for
 `roofline.traffic`.
 
-usage: python tools/pmc_traffic_all.py gpurun_out/prof_<tag> profiles/<tag>_pmc_hbm_traffic.json
+usage: python tools/pmc_traffic_all.py gpurun_out/prof_<tag> profiles/<tag>_pmc_hbm_traffic.json [--merge]
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half of a wide coalesced 16 B/lane stream
 (MI355X_MICROARCH.md, HBM section): bytes = 2 * 1024 * FETCH_SIZE; WRITE_SIZE * 1024 is exact."""
 import collections
@@ -24,6 +24,8 @@ def load(d, counter):
 
 def main():
     root, out_path = sys.argv[1], sys.argv[2]
+    merge = len(sys.argv) > 3 and sys.argv[3] == "--merge"   # keep the workloads already in out_path that root does not hold
+    old = json.load(open(out_path)) if merge and os.path.exists(out_path) else None
     out = {"source": "rocprofv3 --kernel-trace --pmc <counter> (one counter per pass) -- python3 bench.py --workload ... "
                      "--no-extra --no-cpu-baseline (tools/profile_round.sh), MI355X",
            "correction": "FETCH_SIZE is in KiB and on gfx950 counts half of a wide coalesced 16 B/lane stream "
@@ -47,6 +49,9 @@ def main():
         bj = os.path.join(root, f"pmc_{wl}_FETCH_SIZE.bench.json")
         if os.path.exists(bj) and os.path.getsize(bj):
             out["workloads"][wl]["bench_line_of_the_profiled_run"] = json.load(open(bj))
+    if old:
+        for wl, e in old.get("workloads", {}).items():
+            out["workloads"].setdefault(wl, e)
     json.dump(out, open(out_path, "w"), indent=1)
     for wl, e in out["workloads"].items():
         for k, v in e["kernels"].items():

@@ -7,7 +7,7 @@
 # with a trace domain other than --kernel-trace) for the headline.
 set -o pipefail
 TAG=${1:-r05}
-PART=${2:-all}   # all | stats | pmc (a gpurun call is limited to 20 minutes: the two halves fit one call each)
+PART=${2:-all}   # all | stats | pmc | pmc_shards (a gpurun call is limited to 20 minutes: the two halves fit one call each)
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -23,7 +23,7 @@ run() {  # name, bench args...
     grep -h '^{' $OUT/$name.log | tail -1 > $OUT/$name.bench.json
     echo "done $name"
 }
-if [ "$PART" != "pmc" ]; then
+if [ "$PART" != "pmc" ] && [ "$PART" != "pmc_shards" ]; then
 run headline --steps 20 --warmup 3
 run cfg2_T200 --steps 10 --warmup 3 --max-cycles 67
 run cfg3_es --workload es --steps 10 --warmup 3
@@ -47,11 +47,15 @@ pmc() {  # workload name, bench args...: one pass per counter (never combined wi
         echo "done pmc $name $ctr"
     done
 }
-if [ "$PART" != "stats" ]; then
+if [ "$PART" != "stats" ] && [ "$PART" != "pmc_shards" ]; then
 pmc headline --steps 5 --warmup 2
 pmc cfg3_es --workload es --steps 3 --warmup 1
 pmc cfg4_dqn_ga --workload dqn-ga --steps 1 --warmup 1
 pmc cfg5_dqn_es --workload dqn-es --steps 1 --warmup 1
 pmc cfg4_dqn_ga_c6 --workload dqn-ga --channels 6 --steps 1 --warmup 1
 pmc cfg5_dqn_es_c6 --workload dqn-es --channels 6 --steps 1 --warmup 1
+fi
+if [ "$PART" = "pmc_shards" ] || [ "$PART" = "all" ]; then   # the persistent rollout launches of a rank of 4 / 8
+pmc cfg2_shard_1_of_4 --shard-of 4 --steps 5 --warmup 2
+pmc cfg2_shard_1_of_8 --shard-of 8 --steps 5 --warmup 2
 fi
