@@ -362,6 +362,36 @@ def test_persistent_rollout_leaves_what_the_per_cycle_launches_leave(limit):
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
 
 
+@pytest.mark.parametrize("npop,nh,heavy_rows,cohorts,limit", [(7, 1, 1, 1, 9), (13, 2, 2, 1, 30), (31, 3, 8, 1, 75), (40, 8, 8, 2, 21),
+                                                              (64, 4, 3, 1, 48), (17, 5, 5, 2, 75), (100, 1, 8, 1, 12), (9, 7, 7, 1, 5)])
+def test_persistent_rollout_equals_per_cycle_launches_over_shapes(npop, nh, heavy_rows, cohorts, limit):
+    """every row-count instantiation (1, 2, 5, 8), ragged chunks, one and two cohorts, odd and even cycle counts: ONE persistent
+    launch per cohort == the chain of launches per env-cycle - rewards, final state buffer, plain action words, bit for bit"""
+    from coevonet_amd.rollout import DeviceRollout
+    plan, slab, games, _, _ = _small_launch_setup(npop, nh, heavy_rows, cohorts)
+    for k in range(plan.n_cohorts):
+        n_h = int(plan.heavy_begin_np[k + 1] - plan.heavy_begin_np[k])
+        n_l = int(plan.light_begin_np[k + 1] - plan.light_begin_np[k])
+        assert L.load().coevo_mpe_persistent_fits(n_h, n_l, plan.heavy_max, plan.light_max, plan.n_cohorts) == 1
+    got = []
+    for persistent in (True, False):
+        ro = DeviceRollout(plan, slab, merged=True)
+        if not persistent:
+            ro.sync_words, ro.desc.sync_words = None, None
+        ro.set_limits(np.full(plan.n_games, limit))
+        ro.reset(0, plan.n_games, 5)
+        n_cycles = (limit + 2) // 3
+        ro.run(n_cycles)
+        torch.cuda.synchronize()
+        ro.check_status()
+        last = n_cycles - 1
+        st = (ro.state2[0] if last <= 0 or (last & 1) == 0 else ro.state2[1])[:22].cpu().numpy()
+        act = ro.actions_by_game[(last if last > 0 else 0) & 1].cpu().numpy()
+        got.append((ro.rewards.cpu().numpy(), st, act))
+    for a, b in zip(*got):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
 def test_persistent_rollout_times_out_instead_of_hanging():
     """a task list that lacks one seat of some games: their other rows wait, give up after COEVO_SYNC_SPINS polls, raise the
     abort word, every workgroup leaves and the status word carries COEVO_ST_SYNC_TIMEOUT (no reference counterpart)"""
