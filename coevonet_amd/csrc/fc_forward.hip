@@ -1588,6 +1588,8 @@ struct PersistArgs {
     int32_t *sync;        // [4 + 2 * 3 * n_games]: [0] abort word, tagged actions [parity][game][slot] from [4]; zeroed before the launch
     double *state_alt;    // the second state buffer (buffer 1); a.state is buffer 0 (the reset state)
     int32_t *act_plain;   // actions_by_game [2][n_games][3]: only the last cycle's plain actions are written
+    double *rewards;      // [n_games][3] or NULL: each game's owner row closes the books itself (mpe_final_step_kernel's arithmetic)
+    coevo_final_pack pack;   // .out != NULL: ... and writes this rank's all-gather record (mpe_final_step_kernel's)
 };
 
 __global__ void sync_clear_kernel(int32_t *w, int n)
@@ -1929,6 +1931,55 @@ __global__ __launch_bounds__(256, 2) void fc_rollout_small_kernel(FcArgs a, Pers
 #pragma unroll
         for (int f = 0; f < 22; ++f) sn[(size_t)f * N + g] = sm.gs[l][f];
     }
+    // ... and, asked to, the closing step itself (mpe_final_step_kernel, operation for operation): the owner row waits for the
+    // last cycle's three actions, credits the last rewards and writes the game's return triple (+ the all-gather record)
+    if (pa.rewards && w == 0 && l < nrows && sm.rowinfo[l][1] == COEVO_SLOT_ADVERSARY && !sm.ctl[0]) {
+        const int g = sm.rowinfo[l][0], limit = sm.rowinfo[l][2], cyc = pa.n_cycles - 1;
+        const int32_t *tp = tags + (size_t)(cyc & 1) * 3 * N + 3 * (size_t)g;
+        int w0 = 0, w1 = 0, w2 = 0;
+        bool ok = false;
+        for (int it = 0; it < COEVO_SYNC_SPINS; ++it) {
+            w0 = __hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w1 = __hip_atomic_load(tp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w2 = __hip_atomic_load(tp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = (w0 >> 8) == cyc + 1 && (w1 >> 8) == cyc + 1 && (w2 >> 8) == cyc + 1;
+            if (ok) break;
+            if ((it & 15) == 15 && __hip_atomic_load(pa.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) {
+            st |= COEVO_ST_SYNC_TIMEOUT;
+            __hip_atomic_store(pa.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            double a_adv = sm.gs[l][19], a_a0 = sm.gs[l][20], a_a1 = sm.gs[l][21];
+            const int t0 = 3 * cyc;
+            const double rg_prev = sm.gs[l][18];
+            if (t0 < limit) a_adv = a_adv + rg_prev;
+            if (t0 + 1 < limit) a_a0 = a_a0 + rg_prev;
+            if (t0 + 2 < limit) {
+                MpeGame s;
+                s.ax = sm.gs[l][0]; s.ay = sm.gs[l][1]; s.bx = sm.gs[l][2]; s.by = sm.gs[l][3]; s.cx = sm.gs[l][4]; s.cy = sm.gs[l][5];
+                s.avx = sm.gs[l][6]; s.avy = sm.gs[l][7]; s.bvx = sm.gs[l][8]; s.bvy = sm.gs[l][9]; s.cvx = sm.gs[l][10];
+                s.cvy = sm.gs[l][11]; s.l0x = sm.gs[l][12]; s.l0y = sm.gs[l][13]; s.l1x = sm.gs[l][14]; s.l1y = sm.gs[l][15];
+                s.gx = sm.gs[l][16]; s.gy = sm.gs[l][17];
+                double r_good, r_adv;
+                mpe_world_step(s, w0 & 0xff, w1 & 0xff, w2 & 0xff, a.pos_first, r_good, r_adv);
+                a_a1 = a_a1 + r_adv;
+            }
+            pa.rewards[3 * (size_t)g + 0] = a_a0;
+            pa.rewards[3 * (size_t)g + 1] = a_a1;
+            pa.rewards[3 * (size_t)g + 2] = a_adv;
+            const coevo_final_pack &pk = pa.pack;
+            if (pk.out && g < pk.n_roles * pk.n_local * pk.hof && g % pk.hof == pk.hof - 1) {
+                const int ij = g / pk.hof, role = ij / pk.n_local, j = ij % pk.n_local;
+                double *o = pk.out + 4 * (size_t)ij;
+                o[0] = a_a0;
+                o[1] = a_a1;
+                o[2] = a_adv;
+                o[3] = (double)pk.dist[(size_t)role * pk.dist_pitch + pk.dist_first + j];
+            }
+        }
+    }
     if (st) atomicOr(a.status, st);
 }
 
@@ -2108,7 +2159,8 @@ extern "C" int coevo_mpe_rollout_persistent(const float *slab, const coevo_fc_ta
                                             double *state, double *state_alt, int n_games, const int32_t *row_game,
                                             const int32_t *row_slot, int32_t *actions_by_game, const int32_t *game_limit,
                                             int n_cycles, int pos_first, int32_t *status, uint64_t *stamps, int32_t *sync_words,
-                                            int concurrent_launches, void *stream)
+                                            int concurrent_launches, double *rewards, const coevo_final_pack *pack,
+                                            int sync_cleared, void *stream)
 {
     if (!slab || (n_heavy > 0 && !heavy_tasks) || (n_light > 0 && !light_tasks) || !state || !state_alt || state == state_alt ||
         !row_game || !row_slot || !actions_by_game || !status || !sync_words || n_games <= 0 || n_cycles < 1 || n_cycles > (1 << 22))
@@ -2119,13 +2171,19 @@ extern "C" int coevo_mpe_rollout_persistent(const float *slab, const coevo_fc_ta
     hipStream_t s = (hipStream_t)stream;
     // (a kernel, not hipMemsetAsync: captured into a hipGraph and replayed after other work had run, the memset node of this
     // runtime left device pointers in the buffer - the Co-ES evaluation rollout timed out on them)
-    hipLaunchKernelGGL(coevo::sync_clear_kernel, dim3((4 + 6 * n_games + 255) / 256), dim3(256), 0, s, sync_words, 4 + 6 * n_games);
-    COEVO_HIP_CHECK(hipGetLastError());
+    if (!sync_cleared) {
+        hipLaunchKernelGGL(coevo::sync_clear_kernel, dim3((4 + 6 * n_games + 255) / 256), dim3(256), 0, s, sync_words, 4 + 6 * n_games);
+        COEVO_HIP_CHECK(hipGetLastError());
+    }
     coevo::FcArgs a{};
     a.slab = slab; a.tasks = heavy_tasks; a.state = state; a.row_game = row_game; a.row_slot = row_slot; a.n_games = n_games;
     a.status = status; a.stamps = reinterpret_cast<unsigned long long *>(stamps); a.game_limit = game_limit;
     a.pos_first = pos_first; a.light_tasks = light_tasks; a.n_heavy = n_heavy; a.n_light = n_light;
-    const coevo::PersistArgs pa{n_cycles, sync_words, state_alt, actions_by_game};
+    if (pack && (!rewards || !pack->out || !pack->dist || pack->n_roles < 1 || pack->n_local < 1 || pack->hof < 1 ||
+                 (int64_t)pack->n_roles * pack->n_local * pack->hof > n_games || pack->dist_first < 0 ||
+                 pack->dist_first + pack->n_local > pack->dist_pitch))
+        return COEVO_ERR_ARG;
+    const coevo::PersistArgs pa{n_cycles, sync_words, state_alt, actions_by_game, rewards, pack ? *pack : coevo_final_pack{}};
     const int hr = n_heavy > 0 ? heavy_max_rows : 0, lr = n_light > 0 ? light_max_rows : 0;
     const int rows = hr > lr ? hr : lr;
     const dim3 grid(n_heavy + n_light), block(256);

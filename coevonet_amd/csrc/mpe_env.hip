@@ -66,10 +66,14 @@ __global__ void mpe_reset_kernel(double *st, int n, int game_first, int count, c
 
 static_assert(sizeof(coevo_reset_seg) == 16, "layout mirrored by coevonet_amd/lib.py ResetSeg");
 struct ResetSegs { coevo_reset_seg s[COEVO_MAX_JOBS]; };
-__global__ void mpe_reset_multi_kernel(double *st, int n, ResetSegs segs, coevo_pcg64 rng, uint64_t *stamps, int n_stamps)
+__global__ void mpe_reset_multi_kernel(double *st, int n, ResetSegs segs, coevo_pcg64 rng, uint64_t *stamps, int n_stamps,
+                                       int32_t *zero_words, int n_zero)
 {
     const coevo_reset_seg &sg = segs.s[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // ... and the sync words of the persistent rollout that follows (what sync_clear_kernel did in a launch of its own)
+    if (zero_words && blockIdx.y == gridDim.y - 1)
+        for (int j = i; j < n_zero; j += gridDim.x * blockDim.x) zero_words[j] = 0;
     // the clock-stamp slot pairs of the rollout that follows, re-armed to {UINT64_MAX, 0} (what stamps_init_kernel did in a
     // launch of its own in front of every timed rollout)
     if (stamps && blockIdx.y == 0)
@@ -194,11 +198,8 @@ __global__ void mpe_step_kernel(double *st, int n, const int32_t *game_rows, con
 // pack (a population-sharded run, coevo_mpe_final_step_pack): the games are laid out [role][local individual][hof game]; the
 // thread that closes the LAST HoF game of an individual (the one that counts, quirk Q2) also writes that individual's record
 // of the fitness all-gather: pack[role][j] = {its play_game triple, the individual's distance to the stale agent}
-struct FinalPack {
-    double *out;            // [n_roles][n_local][4], or NULL
-    const float *dist;      // [n_roles][dist_pitch], this rank's individuals start at dist_first
-    int n_roles, n_local, hof, dist_pitch, dist_first;
-};
+typedef coevo_final_pack FinalPack;   // {out [n_roles][n_local][4] or NULL, dist [n_roles][dist_pitch], n_roles, n_local, hof, dist_pitch, dist_first}
+static_assert(sizeof(coevo_final_pack) == 40, "layout mirrored by coevonet_amd/lib.py FinalPack");
 
 __global__ void mpe_final_step_kernel(const double *st, int n, const int32_t *act, int cycle,
                                       const int32_t *game_limit, int pos_first, double *rewards, FinalPack pk)
@@ -259,12 +260,12 @@ extern "C" int coevo_mpe_reset_gen(double *state, int n_games, int game_first, i
 }
 
 static int reset_multi_launch(double *state, int n_games, const coevo_reset_seg *segs, int n_segs, coevo_pcg64 rng,
-                              uint64_t *stamps, int n_stamps, void *stream);
+                              uint64_t *stamps, int n_stamps, int32_t *zero_words, int n_zero, void *stream);
 
 extern "C" int coevo_mpe_reset_multi(double *state, int n_games, const coevo_reset_seg *segs, int n_segs, coevo_pcg64 rng,
                                      void *stream)
 {
-    return reset_multi_launch(state, n_games, segs, n_segs, rng, nullptr, 0, stream);
+    return reset_multi_launch(state, n_games, segs, n_segs, rng, nullptr, 0, nullptr, 0, stream);
 }
 
 // ... that also re-arms n_stamps {start, end} clock-stamp slot pairs for the timed rollout that follows (coevo_rollout_desc.
@@ -273,11 +274,19 @@ extern "C" int coevo_mpe_reset_multi_arm(double *state, int n_games, const coevo
                                          uint64_t *stamps, int n_stamps, void *stream)
 {
     if (!stamps || n_stamps <= 0) return COEVO_ERR_ARG;
-    return reset_multi_launch(state, n_games, segs, n_segs, rng, stamps, n_stamps, stream);
+    return reset_multi_launch(state, n_games, segs, n_segs, rng, stamps, n_stamps, nullptr, 0, stream);
+}
+
+extern "C" int coevo_mpe_reset_multi_prep(double *state, int n_games, const coevo_reset_seg *segs, int n_segs, coevo_pcg64 rng,
+                                          uint64_t *stamps, int n_stamps, int32_t *zero_words, int n_zero, void *stream)
+{
+    if ((stamps && n_stamps <= 0) || (zero_words && n_zero <= 0)) return COEVO_ERR_ARG;
+    return reset_multi_launch(state, n_games, segs, n_segs, rng, stamps, stamps ? n_stamps : 0, zero_words, zero_words ? n_zero : 0,
+                              stream);
 }
 
 static int reset_multi_launch(double *state, int n_games, const coevo_reset_seg *segs, int n_segs, coevo_pcg64 rng,
-                              uint64_t *stamps, int n_stamps, void *stream)
+                              uint64_t *stamps, int n_stamps, int32_t *zero_words, int n_zero, void *stream)
 {
     if (!state || n_games <= 0 || !segs || n_segs < 1 || n_segs > COEVO_MAX_JOBS) return COEVO_ERR_ARG;
     coevo::ResetSegs rs{};
@@ -287,9 +296,9 @@ static int reset_multi_launch(double *state, int n_games, const coevo_reset_seg 
         rs.s[i] = segs[i];
         cmax = segs[i].count > cmax ? segs[i].count : cmax;
     }
-    if (cmax == 0 && !stamps) return COEVO_OK;
+    if (cmax == 0 && !stamps && !zero_words) return COEVO_OK;
     hipLaunchKernelGGL(coevo::mpe_reset_multi_kernel, dim3((cmax > 0 ? cmax + 127 : 128) / 128, n_segs), dim3(128), 0,
-                       (hipStream_t)stream, state, n_games, rs, rng, stamps, n_stamps);
+                       (hipStream_t)stream, state, n_games, rs, rng, stamps, n_stamps, zero_words, n_zero);
     COEVO_HIP_CHECK(hipGetLastError());
     return COEVO_OK;
 }
@@ -476,7 +485,7 @@ extern "C" int coevo_mpe_final_step_pack(const double *state, int n_games, const
     if (!pack || !dist || n_roles < 1 || n_local < 1 || hof < 1 || (int64_t)n_roles * n_local * hof > n_games ||
         dist_first < 0 || dist_first + n_local > dist_pitch)
         return COEVO_ERR_ARG;
-    const coevo::FinalPack pk{pack, dist, n_roles, n_local, hof, dist_pitch, dist_first};
+    const coevo::FinalPack pk{pack, dist, n_roles, n_local, hof, dist_pitch, dist_first, 0};
     hipLaunchKernelGGL(coevo::mpe_final_step_kernel, dim3((n_games + 127) / 128), dim3(128), 0, (hipStream_t)stream,
                        state, n_games, actions_by_game, cycle, game_limit, pos_first, rewards, pk);
     COEVO_HIP_CHECK(hipGetLastError());

@@ -11,7 +11,7 @@
 
 #include "coevo_common.hip.h"
 
-static_assert(sizeof(coevo_rollout_desc) == 184, "layout mirrored by coevonet_amd/lib.py RolloutDesc");
+static_assert(sizeof(coevo_rollout_desc) == 192, "layout mirrored by coevonet_amd/lib.py RolloutDesc");
 
 __global__ void stamps_init_kernel(uint64_t *stamps, int n)
 {
@@ -174,6 +174,7 @@ extern "C" int coevo_mpe_rollout(const coevo_rollout_desc *d, void *ctx, int tim
         // matrix-core work with weight streaming now comes from the other cohorts' launches.
         for (int k = 1; k < K; ++k) COEVO_HIP_CHECK(hipStreamWaitEvent(c->lanes[k - 1].s, c->start, 0));
     }
+    bool closed_in_launch = false;
     // one cohort's chain of cycles: per cycle the shared-opponent launch on `hs` || the per-individual launch on `ls`
     // (hs == ls: back to back)
     auto chain = [&](int k, const coevo_fc_task *heavy, int n_heavy, const coevo_fc_task *light, int n_light,
@@ -182,12 +183,17 @@ extern "C" int coevo_mpe_rollout(const coevo_rollout_desc *d, void *ctx, int tim
         // a cohort whose workgroups are all resident at once (coevo_mpe_persistent_fits): its n_cycles as ONE persistent launch
         if (persistent_ok && fused && d->merged && d->sync_words && n_heavy + n_light > 0 && d->n_cycles > 0) {
             const int conc = d->concurrent_hint > K ? d->concurrent_hint : K;
-            if (coevo_mpe_persistent_fits(n_heavy, n_light, d->heavy_max_rows, d->light_max_rows, conc) == 1)
+            if (coevo_mpe_persistent_fits(n_heavy, n_light, d->heavy_max_rows, d->light_max_rows, conc) == 1) {
+                // one cohort = every game of the call: its launch closes the books too (no closing launch below)
+                const bool closes = K == 1 && d->rewards != nullptr;
+                closed_in_launch = closes;
                 return coevo_mpe_rollout_persistent(
                     d->slab, heavy, n_heavy, light, n_light, d->light_max_rows, d->heavy_max_rows, d->state, d->state_alt,
                     d->n_games, d->row_game, d->row_slot, d->actions_by_game, d->game_limit, d->n_cycles, d->pos_first, d->status,
                     d->light_stamps ? d->light_stamps + 2 * COEVO_STAMP_SLOTS * ((size_t)k * d->n_cycles) : nullptr,
-                    d->sync_words + (size_t)k * (size_t)(4 + 6 * (size_t)d->n_games), conc, ls);
+                    d->sync_words + (size_t)k * (size_t)(4 + 6 * (size_t)d->n_games), conc, closes ? d->rewards : nullptr,
+                    closes ? d->pack : nullptr, d->sync_cleared, ls);
+            }
         }
         for (int cyc = 0; cyc < d->n_cycles; ++cyc) {
             int rc;
@@ -266,10 +272,15 @@ extern "C" int coevo_mpe_rollout(const coevo_rollout_desc *d, void *ctx, int tim
     if (fused) {
         if (!d->rewards) return COEVO_OK;  // the caller closes the rollout itself (coevo_mpe_final_step), e.g. after
                                             // several per-cohort calls on different streams
+        if (closed_in_launch) return COEVO_OK;   // (the persistent launch did)
         const int last = d->n_cycles - 1;  // -1: no cycle ran, the books are the reset state's zeros
         const double *st_last = (last <= 0) ? d->state : ((last & 1) ? d->state_alt : d->state);
-        return coevo_mpe_final_step(st_last, d->n_games, d->actions_by_game + (size_t)((last < 0 ? 0 : last) & 1) * act_stride,
-                                    last, d->game_limit, d->pos_first, d->rewards, main_s);
+        const int32_t *act_last = d->actions_by_game + (size_t)((last < 0 ? 0 : last) & 1) * act_stride;
+        if (d->pack)
+            return coevo_mpe_final_step_pack(st_last, d->n_games, act_last, last, d->game_limit, d->pos_first, d->rewards,
+                                             d->pack->out, d->pack->dist, d->pack->n_roles, d->pack->n_local, d->pack->hof,
+                                             d->pack->dist_pitch, d->pack->dist_first, main_s);
+        return coevo_mpe_final_step(st_last, d->n_games, act_last, last, d->game_limit, d->pos_first, d->rewards, main_s);
     }
     if (d->rewards) return coevo_mpe_rewards(d->state, d->n_games, d->rewards, main_s);
     return COEVO_OK;

@@ -728,9 +728,8 @@ class GAEngine:
         if gen > 0:
             segs.append((self.n_main, N_EVAL, self._ordinal_base(gen - 1) + M))
         ro.reset_segments(segs, arm=(0, self.n_cycles))   # one launch (three phases + the evaluation games + clock stamps)
-        if self._packed_exchange():
-            ro.enqueue(self.n_cycles, final=False, armed=True)
-            ro.enqueue_final_step(self.n_cycles, pack=self._pack_args())
+        if self._packed_exchange():   # (the closing step + this rank's all-gather record: in the persistent launch, if it is one)
+            ro.enqueue(self.n_cycles, armed=True, pack=self._pack_args())
         else:
             ro.enqueue(self.n_cycles, armed=True)
         self._sharded_tail(gen, breed=True)

@@ -60,6 +60,11 @@ class ResetSeg(C.Structure):     # coevo_reset_seg
     _fields_ = [("game_first", C.c_int32), ("count", C.c_int32), ("first_ordinal", C.c_uint64)]
 
 
+class FinalPack(C.Structure):    # coevo_final_pack
+    _fields_ = [("out", C.c_void_p), ("dist", C.c_void_p), ("n_roles", C.c_int32), ("n_local", C.c_int32), ("hof", C.c_int32),
+                ("dist_pitch", C.c_int32), ("dist_first", C.c_int32), ("reserved", C.c_int32)]
+
+
 class RolloutDesc(C.Structure):
     _fields_ = [("slab", C.c_void_p), ("heavy", C.c_void_p), ("n_heavy", C.c_int32), ("heavy_max_rows", C.c_int32),
                 ("light", C.c_void_p), ("n_light", C.c_int32), ("light_max_rows", C.c_int32),
@@ -69,8 +74,8 @@ class RolloutDesc(C.Structure):
                 ("rewards", C.c_void_p), ("pos_first", C.c_int32), ("n_cohorts", C.c_int32),
                 ("state_alt", C.c_void_p), ("actions_by_game", C.c_void_p), ("light_stamps", C.c_void_p),
                 ("heavy_begin", C.c_void_p), ("light_begin", C.c_void_p),
-                ("merged", C.c_int32), ("concurrent_hint", C.c_int32), ("stamps_armed", C.c_int32), ("reserved", C.c_int32),
-                ("sync_words", C.c_void_p)]
+                ("merged", C.c_int32), ("concurrent_hint", C.c_int32), ("stamps_armed", C.c_int32), ("sync_cleared", C.c_int32),
+                ("sync_words", C.c_void_p), ("pack", C.c_void_p)]
 
 
 class HostCohort(C.Structure):        # coevo_host_cohort
@@ -140,6 +145,8 @@ _SIGS = {
     "coevo_mpe_reset_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, PCG64State, C.c_void_p]),
     "coevo_mpe_reset_multi_arm": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, PCG64State, C.c_void_p, C.c_int,
                                             C.c_void_p]),
+    "coevo_mpe_reset_multi_prep": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, PCG64State, C.c_void_p, C.c_int,
+                                             C.c_void_p, C.c_int, C.c_void_p]),
     "coevo_ga_select_adapt": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_void_p]),
     "coevo_ga_promote_tick": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -177,7 +184,8 @@ _SIGS = {
     "coevo_mpe_persistent_fits": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "coevo_mpe_rollout_persistent": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+                                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                               C.c_int, C.c_void_p]),
     "coevo_rollout_ctx_create": (C.c_void_p, [C.c_int]),
     "coevo_rollout_ctx_destroy": (None, [C.c_void_p]),
     "coevo_ga_select": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

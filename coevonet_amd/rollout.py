@@ -278,13 +278,19 @@ class DeviceRollout:
 
     def reset_segments(self, segs, arm=None):
         """several (game_first, n_games, first_ordinal) resets in ONE launch (<= 4 segments).  arm = (cohort k, n_cycles):
-        the launch also re-arms the clock stamps of that cohort's timed chain (time_light), which then needs no launch of
-        its own for it - the caller passes armed=True to the enqueue that follows"""
+        the launch also re-arms the clock stamps of that cohort's timed chain (time_light) and zeroes the sync words of its
+        persistent rollout launch, which then need no launch of their own - the caller passes armed=True to the enqueue that
+        follows"""
         arr = (L.ResetSeg * len(segs))(*[L.ResetSeg(int(a), int(b), int(c)) for a, b, c in segs])
-        if arm is not None and self.time_light:
+        if arm is not None and (self.time_light or self.sync_words is not None):
+            # ... and, in the same launch, zeroes the sync words of that cohort's persistent rollout launch (which then needs no
+            # clearing launch of its own either: desc.sync_cleared, set by the enqueue that is passed armed=True)
             k, n_cycles = arm
-            L.call("coevo_mpe_reset_multi_arm", L._p(self.state), self.plan.n_games, _ct.cast(arr, _ct.c_void_p), len(segs),
-                   self.rng, self.stamps.data_ptr() + 16 * L.STAMP_SLOTS * int(k) * int(n_cycles), int(n_cycles) * L.STAMP_SLOTS)
+            stamps = (self.stamps.data_ptr() + 16 * L.STAMP_SLOTS * int(k) * int(n_cycles)) if self.time_light else None
+            sync = (self.sync_words.data_ptr() + 4 * int(k) * self.sync_words_per_cohort) if self.sync_words is not None else None
+            L.call("coevo_mpe_reset_multi_prep", L._p(self.state), self.plan.n_games, _ct.cast(arr, _ct.c_void_p), len(segs),
+                   self.rng, stamps, int(n_cycles) * L.STAMP_SLOTS if stamps else 0, sync,
+                   self.sync_words_per_cohort if sync else 0)
             return
         L.call("coevo_mpe_reset_multi", L._p(self.state), self.plan.n_games, _ct.cast(arr, _ct.c_void_p), len(segs), self.rng)
 
@@ -316,22 +322,32 @@ class DeviceRollout:
         self.desc.n_cycles = n_cycles
         L.call("coevo_mpe_rollout", L.C.byref(self.desc), ctx, 1 if timed else 0)
 
-    def enqueue(self, n_cycles, final=True, armed=False):
+    def enqueue(self, n_cycles, final=True, armed=False, pack=None):
         """plain enqueue on the current stream (no graph of its own): for callers that capture a larger graph.
-        final=False: without the closing step (the caller runs enqueue_final_step itself, e.g. with its all-gather pack);
+        final=False: without the closing step (the caller runs enqueue_final_step itself);
+        pack (with final=True; see enqueue_final_step): the closing step also writes this rank's all-gather record - inside the
+        persistent launch when the rollout is one (coevo_rollout_desc.pack);
         armed: the reset launch in front of it re-armed the clock stamps (reset_segments(arm=...))"""
         self.desc.light_stamps = L._p(self.stamps) if self.time_light else None
         self.desc.n_cycles = int(n_cycles)
         self.desc.stamps_armed = 1 if (armed and self.time_light) else 0
+        self.desc.sync_cleared = 1 if (armed and self.sync_words is not None) else 0
         keep = self.desc.rewards
+        fp = None
         if not final:
             assert self.desc.state_alt, "only the fused-step rollout can leave its books open"
             self.desc.rewards = None
+        elif pack is not None:
+            out, dist, n_roles, n_local, hof, pitch, first = pack
+            fp = L.FinalPack(L._p(out), L._p(dist), int(n_roles), int(n_local), int(hof), int(pitch), int(first), 0)
+            self.desc.pack = L.C.addressof(fp)
         try:
             L.call("coevo_mpe_rollout", L.C.byref(self.desc), self.ctx if (self.overlap or self.n_cohorts > 1) else None, 0)
         finally:
             self.desc.rewards = keep
+            self.desc.pack = None
             self.desc.stamps_armed = 0
+            self.desc.sync_cleared = 0
         if self.time_light:
             self._pending_stamps = int(n_cycles)
 
@@ -355,8 +371,9 @@ class DeviceRollout:
         d.rewards = None
         d.light_stamps = (self.stamps.data_ptr() + 16 * L.STAMP_SLOTS * k * int(n_cycles)) if self.time_light else None
         d.stamps_armed = 1 if (armed and self.time_light) else 0
-        if self.sync_words is not None:   # this cohort's own scratch (the launch zeroes it)
+        if self.sync_words is not None:   # this cohort's own scratch (zeroed by the launch, or by the reset launch: armed)
             d.sync_words = self.sync_words.data_ptr() + 4 * k * self.sync_words_per_cohort
+            d.sync_cleared = 1 if armed else 0
         L._check(L.load().coevo_mpe_rollout(L.C.byref(d), self.ctx, 0, stream.cuda_stream), "coevo_mpe_rollout")
         if self.time_light:
             self._pending_stamps = int(n_cycles)

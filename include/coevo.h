@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define COEVO_VERSION 103   /* 103: coevo_mpe_rollout_persistent, coevo_rollout_desc.sync_words (184 bytes); 102: host-cores placement (coevo_host_placement_choose, coevo_host_rollout_placement / _alloc),
+#define COEVO_VERSION 103   /* 103: coevo_mpe_rollout_persistent, coevo_rollout_desc.sync_words / .pack (192 bytes), coevo_final_pack; 102: host-cores placement (coevo_host_placement_choose, coevo_host_rollout_placement / _alloc),
                              * wide small-shard cycle kernel; 101: offspring noise = Philox4x32-7 (100: -10; other numbers for the same seed), host-cores
                              * rollout entry points, coevo_noise_rounds */
 
@@ -121,6 +121,10 @@ int coevo_mpe_reset_multi(double *state, int n_games, const coevo_reset_seg *seg
  * (coevo_rollout_desc.light_stamps with stamps_armed = 1) */
 int coevo_mpe_reset_multi_arm(double *state, int n_games, const coevo_reset_seg *segs /* host */, int n_segs,
                               coevo_pcg64 rng, uint64_t *stamps, int n_stamps, void *stream);
+/* ... and / or zeroes n_zero 32-bit words (the sync words of the persistent rollout it precedes: coevo_rollout_desc.sync_cleared
+ * = 1); stamps and zero_words may each be NULL */
+int coevo_mpe_reset_multi_prep(double *state, int n_games, const coevo_reset_seg *segs /* host */, int n_segs,
+                               coevo_pcg64 rng, uint64_t *stamps, int n_stamps, int32_t *zero_words, int n_zero, void *stream);
 /* the same with the generation taken from a device counter: first ordinal = first_ordinal + (*gen_dev) *
  * ordinals_per_gen (clamped at 0), so a captured hipGraph of a whole generation can be replayed unchanged */
 int coevo_mpe_reset_gen(double *state, int n_games, int game_first, int count, coevo_pcg64 rng, int64_t first_ordinal,
@@ -231,6 +235,13 @@ int coevo_mpe_policy_cycle(const float *slab, const coevo_fc_task *tasks, int n_
                            const double *state, int n_games, const int32_t *row_game, const int32_t *row_slot,
                            int32_t *actions, int32_t *status, void *stream);
 
+/* what coevo_mpe_final_step_pack writes beside the rewards (a population-sharded run: this rank's record of the all-gather) */
+typedef struct {
+    double *out;          /* [n_roles][n_local][4] */
+    const float *dist;    /* [n_roles][dist_pitch]; this rank's individuals start at dist_first */
+    int32_t n_roles, n_local, hof, dist_pitch, dist_first, reserved;
+} coevo_final_pack;
+
 /* A whole batch of games in one call (play_game/play_MPE at batch scale): n_cycles world cycles, each = the
  * shared-opponent policy launch (tasks `heavy`, > 8 rows each, matrix cores) on a side stream concurrently with the
  * per-individual policy launch (tasks `light`, <= 8 rows each, weight streaming) on `stream`, then coevo_mpe_step;
@@ -270,10 +281,13 @@ typedef struct {
                                     cohort); 0 = none.  Only sizes the merged launch (coevo_mpe_policy_cycle_merged) */
     int32_t stamps_armed;        /* != 0: the caller has re-armed light_stamps to {UINT64_MAX, 0} itself (coevo_mpe_reset_multi_arm,
                                     in the reset launch that precedes the rollout anyway): no launch of its own for it */
-    int32_t reserved;
+    int32_t sync_cleared;        /* != 0: ... and zeroed sync_words (this call's cohort region) there too (coevo_mpe_reset_multi_prep) */
     int32_t *sync_words;         /* device int32 [n_cohorts][coevo_mpe_persistent_sync_words(n_games)] or NULL.  Given: a cohort
                                     whose workgroups are all resident at once (coevo_mpe_persistent_fits) runs its n_cycles as ONE persistent launch
                                     (coevo_mpe_rollout_persistent) */
+    const coevo_final_pack *pack; /* fused step, `rewards` given: the closing step also writes this rank's record of the fitness
+                                    all-gather (coevo_mpe_final_step_pack), or NULL.  With one cohort in a persistent launch the
+                                    closing step itself runs inside that launch */
 } coevo_rollout_desc;
 #define COEVO_MAX_COHORTS 8
 void *coevo_rollout_ctx_create(int n_timing_pairs);
@@ -331,7 +345,10 @@ int coevo_mpe_policy_cycle_merged(const float *slab, const coevo_fc_task *heavy_
  * tagged 32-bit word and waits for the two other rows of its game (bounded: COEVO_ST_SYNC_TIMEOUT in the status word).
  * state = buffer 0 (the reset state), state_alt = buffer 1; on return they and actions_by_game [2][n_games][3] hold exactly
  * what the last of the per-cycle launches leaves for coevo_mpe_final_step(state of cycle n_cycles - 1, cycle n_cycles - 1).
- * sync_words: device int32 [coevo_mpe_persistent_sync_words(n_games)], scratch of this call (zeroed by it on `stream`).
+ * sync_words: device int32 [coevo_mpe_persistent_sync_words(n_games)], scratch of this call (zeroed by it on `stream` unless
+ * sync_cleared != 0: the caller zeroed them in a launch of its own that precedes this one, coevo_mpe_reset_multi_prep).
+ * rewards ([n_games][3] fp64) given: each game's owner row also closes the books itself (coevo_mpe_final_step's arithmetic,
+ * and coevo_mpe_final_step_pack's record when `pack` is given) - no closing launch is needed; NULL: the caller closes them.
  * stamps: [n_cycles][COEVO_STAMP_SLOTS][2] or NULL, per cycle {earliest start after the wait, latest action posted}.
  * Every task's games must have all three of their rows among the tasks of this call.  COEVO_PERSISTENT=0 in the environment
  * makes coevo_mpe_rollout keep the per-cycle launches (A/B). */
@@ -342,7 +359,8 @@ int coevo_mpe_rollout_persistent(const float *slab, const coevo_fc_task *heavy_t
                                  double *state, double *state_alt, int n_games, const int32_t *row_game,
                                  const int32_t *row_slot, int32_t *actions_by_game, const int32_t *game_limit, int n_cycles,
                                  int pos_first, int32_t *status, uint64_t *stamps, int32_t *sync_words,
-                                 int concurrent_launches, void *stream);
+                                 int concurrent_launches, double *rewards, const coevo_final_pack *pack, int sync_cleared,
+                                 void *stream);
 int coevo_mpe_final_step(const double *state, int n_games, const int32_t *actions_by_game, int cycle,
                          const int32_t *game_limit, int pos_first, double *rewards, void *stream);
 /* ... + this rank's record of the fitness all-gather in the same launch (a population-sharded run; genetic_algorithm.py:

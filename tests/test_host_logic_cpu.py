@@ -271,7 +271,8 @@ def test_job_struct_layouts_match_the_header():
     assert L.PerturbJob.child_first.offset == 48 and L.FinalizeJob.n_blocks.offset == 24
     assert L.ResetSeg.first_ordinal.offset == 8
     assert C.sizeof(L.GaAdaptArgs) == 88 and L.GaAdaptArgs.sig_min.offset == 56 and L.GaAdaptArgs.eval_first_game.offset == 72
-    assert C.sizeof(L.RolloutDesc) == 184 and L.RolloutDesc.stamps_armed.offset == 168 and L.RolloutDesc.sync_words.offset == 176
+    assert C.sizeof(L.RolloutDesc) == 192 and L.RolloutDesc.stamps_armed.offset == 168 and L.RolloutDesc.sync_words.offset == 176
+    assert L.RolloutDesc.pack.offset == 184 and C.sizeof(L.FinalPack) == 40
 
 
 def test_bench_reads_tracked_pmc_traffic():

@@ -404,7 +404,7 @@ def test_persistent_rollout_times_out_instead_of_hanging():
     rc = lib.coevo_mpe_rollout_persistent(
         L._p(slab), L._p(plan.heavy), len(plan.heavy_np), L._p(plan.light), len(plan.light_np) - 1, plan.light_max, plan.heavy_max,
         L._p(ro.state2[0]), L._p(ro.state2[1]), plan.n_games, L._p(plan.row_game), L._p(plan.row_slot), L._p(ro.actions_by_game),
-        L._p(ro.limits), 3, ro.pos_first, L._p(ro.status), None, L._p(ro.sync_words), 1, L._stream())
+        L._p(ro.limits), 3, ro.pos_first, L._p(ro.status), None, L._p(ro.sync_words), 1, None, None, 0, L._stream())
     assert rc == 0
     torch.cuda.synchronize()
     assert int(ro.status.item()) & 32
