@@ -97,10 +97,15 @@ class DistContext:
                                                     torch.cuda.device_count())
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank % max(torch.cuda.device_count(), 1))
+            if shared_device:
+                # several ranks on ONE device (a rehearsal): their persistent rollout launches would wait for workgroups that
+                # the other ranks' launches keep off the chip (coevo_mpe_persistent_fits counts one process) - launches per cycle
+                os.environ.setdefault("COEVO_PERSISTENT", "0")
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
             if self.rank == 0:
                 print(f"[coevonet_amd.dist] backend={backend} world={self.world}"
-                      + (" (ranks share a device: gathers go through the host)" if shared_device else ""),
+                      + (" (ranks share a device: gathers go through the host, rollouts are launched per env-cycle)"
+                         if shared_device else ""),
                       file=sys.stderr, flush=True)
         self._timed = None   # start_gather_timing(): [(start event, end event)] around every gather_* call
 
